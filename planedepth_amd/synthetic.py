@@ -1,0 +1,86 @@
+"""Seeded synthetic stand-ins for the KITTI minibatch and the depth decoder's outputs.
+
+There is no dataset (and no network) on the build or GPU boxes, so tests, the golden-vector generator and
+``bench.py`` all draw the hot path's inputs from here: tensors with the shapes, value ranges and dict layout
+the reference's data pipeline and decoder produce (SURVEY.md rows A1 / D-inputs).
+CPU tensors are returned; callers move them to the device.
+"""
+import numpy as np
+import torch
+
+
+def intrinsics(B, H, W):
+    """K as datasets/mono_dataset.py builds it (normalised 0.58 / 1.92 focal, centred), inv_K = pinv(K)."""
+    K = np.array([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    inv_K = np.linalg.pinv(K)
+    K = torch.from_numpy(K)[None].repeat(B, 1, 1)
+    inv_K = torch.from_numpy(inv_K)[None].repeat(B, 1, 1)
+    return K, inv_K
+
+
+def small_pose(gen, B, rot=0.01, trans=0.05, stereo=False):
+    """A rigid motion [B,4,4]: stereo = identity with tx=-0.1, otherwise a small random rotation + translation."""
+    T = torch.eye(4)[None].repeat(B, 1, 1)
+    if stereo:
+        T[:, 0, 3] = -0.1
+        return T
+    w = torch.randn(B, 3, generator=gen) * rot
+    th = w.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    k = w / th
+    Kx = torch.zeros(B, 3, 3)
+    Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0] = -k[:, 2], k[:, 1], k[:, 2]
+    Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 0], -k[:, 1], k[:, 0]
+    s, c = torch.sin(th)[:, :, None], torch.cos(th)[:, :, None]
+    T[:, :3, :3] = torch.eye(3)[None] + s * Kx + (1 - c) * torch.matmul(Kx, Kx)
+    T[:, :3, 3] = torch.randn(B, 3, generator=gen) * trans
+    return T
+
+
+def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False, special_disp=None,
+               stereo_T=True, with_mask_novel=False, render_probability=False):
+    """Synthetic decoder outputs + dataset inputs in the reference's dict format."""
+    g = torch.Generator().manual_seed(seed)
+    color_l = torch.rand(B, 3, H, W, generator=g)
+    color_r = torch.rand(B, 3, H, W, generator=g)
+    logits = torch.randn(B, N, H, W, generator=g)
+    sigma = torch.rand(B, N, H, W, generator=g).clamp(0.01, 1.0)
+    res = torch.rand(B, N, 1, 1, generator=g) - 0.5
+    level = torch.arange(N, dtype=torch.float32)[None, :, None, None] + res
+    disp_pp = disp_max * (disp_min / disp_max) ** (level / (N - 1))  # [B,N,1,1], the learnable per-plane disparity
+    if special_disp is not None:
+        disp_pp = torch.tensor(special_disp, dtype=torch.float32)[None, :, None, None].repeat(B, 1, 1, 1)
+    padding_mask = torch.ones(B, N, H, W)
+    row_gain = torch.ones(1, N, H, 1)
+    if n_xz:  # last n_xz planes behave like ground planes: disparity grows with the row, masked above the horizon
+        ycoord = torch.linspace(-1, 1, H)[None, None, :, None]
+        row_gain = row_gain.clone()
+        row_gain[:, N - n_xz:] = (0.4 + 0.6 * ycoord.clamp_min(0.0)).expand(1, n_xz, H, 1)
+        padding_mask[:, N - n_xz:] = (ycoord >= 1e-7).float().expand(B, n_xz, H, W)
+    K, inv_K = intrinsics(B, H, W)
+    case = dict(color_l=color_l, color_r=color_r, logits=logits, sigma=sigma, disp_pp=disp_pp, row_gain=row_gain,
+                padding_mask=padding_mask, K=K, inv_K=inv_K,
+                Rt=small_pose(g, B, stereo=stereo_T), g_rgb_rec=torch.randn(B, 3, H, W, generator=g),
+                dense_disp=bool(dense_disp or n_xz))
+    if with_mask_novel:
+        case["mask_novel"] = (torch.rand(B, 1, H, W, generator=g) > 0.3).float() * torch.rand(B, 1, H, W, generator=g)
+    if render_probability:
+        case["dists"] = torch.rand(B, N - 1, H, W, generator=g) * 2.0
+    return case
+
+
+def survey_fullsize_case(B=1, N=49, H=192, W=640):
+    """Inputs exactly as SURVEY.md §8(c) C-golden / BASELINE.md §3 describe them (seed 1234, that draw order)."""
+    g = torch.Generator().manual_seed(1234)
+    color_l = torch.rand(B, 3, H, W, generator=g)
+    color_r = torch.rand(B, 3, H, W, generator=g)
+    logits = torch.randn(B, N, H, W, generator=g)
+    sigma = torch.rand(B, N, H, W, generator=g).clamp(0.01, 1.0)
+    res = torch.rand(B, N, 1, 1, generator=g) - 0.5
+    disp_pp = 300.0 * (2.0 / 300.0) ** ((torch.arange(N, dtype=torch.float32)[None, :, None, None] + res) / (N - 1))
+    K, inv_K = intrinsics(B, H, W)
+    Rt = torch.eye(4)[None].repeat(B, 1, 1)
+    Rt[:, 0, 3] = -0.1
+    g2 = torch.Generator().manual_seed(4321)
+    return dict(color_l=color_l, color_r=color_r, logits=logits, sigma=sigma, disp_pp=disp_pp,
+                row_gain=torch.ones(1, N, H, 1), padding_mask=torch.ones(B, N, H, W), K=K, inv_K=inv_K, Rt=Rt,
+                g_rgb_rec=torch.randn(B, 3, H, W, generator=g2) * 1e-5, dense_disp=False)

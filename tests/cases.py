@@ -1,0 +1,59 @@
+"""Shared helpers: load golden fixtures and drive the ORACLE on them (test infrastructure)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import planedepth_oracle as orc
+
+SMALL = ["disp_mix_r", "disp_mix_l", "disp_mix_automask", "disp_l1", "disp_l1_automask", "disp_mix_xz",
+         "disp_mix_oob", "disp_mix_integer_d", "disp_mix_masknovel", "disp_l1_masknovel",
+         "homo_mix_stereo", "homo_mix_pose", "homo_l1_pose", "disp_mix_render"]
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    inp = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    out = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out_")}
+    return inp, out, meta["run"]
+
+
+def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
+    """Mirror of make_golden.run_reference, but through the oracle.  Returns the same keys."""
+    c = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in case.items()}
+    B, N, H, W = c["logits"].shape
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    logits, sigma, disp_pp, Rt = leaf(c["logits"]), leaf(c["sigma"]), leaf(c["disp_pp"]), leaf(c["Rt"])
+    disp_layered = disp_pp.expand(-1, -1, H, W) * c["row_gain"]
+    distance = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
+    norm = torch.tensor([0.0, 0.0, 1.0], dtype=dtype)[None, None].expand(B, N, -1)
+    mix = run.get("use_mixture_loss", True)
+    # the reference reads the target from inputs[("color", side)]; for side "l" that IS the source image
+    tgt = c["color_l"] if run.get("target_side", "r") == "l" else c["color_r"]
+    r = orc.warp_and_loss(c["color_l"], tgt, logits, sigma if mix else None,
+                          warp_type=run.get("warp_type", "disp_warp"), target_side=run.get("target_side", "r"),
+                          disp_layered=disp_layered, padding_mask=c["padding_mask"], distance=distance, norm=norm,
+                          T=Rt, K=c["K"], inv_K=c["inv_K"], use_mixture_loss=mix, automask=run.get("automask", False),
+                          mask_novel=c.get("mask_novel"), render_probability=run.get("render_probability", False),
+                          dists=c.get("dists"), sampler=sampler)
+    (r["ph_loss"] + (r["rgb_rec"] * c["g_rgb_rec"]).sum()).backward()
+    z = torch.zeros_like
+    res = dict(rgb_rec=r["rgb_rec"], ph_loss=r["ph_loss"], ph_map=r["ph_map"],
+               rgb_rec_layered=r["sweep"]["rgb_rec_layered"], logit_rec=r["sweep"]["logit_rec"],
+               probability_rec=r["sweep"]["probability_rec"],
+               g_logits=logits.grad, g_sigma=sigma.grad if sigma.grad is not None else z(sigma),
+               g_disp_pp=disp_pp.grad if disp_pp.grad is not None else z(disp_pp),
+               g_Rt=Rt.grad if Rt.grad is not None else z(Rt))
+    if mix:
+        res["sigma_rec"] = r["sweep"]["sigma_rec"]
+        res["pi_rec"] = r["sweep"]["pi_rec"]
+    return {k: v.detach() for k, v in res.items()}
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, tiny): the normalised max error used for every fp32 parity check."""
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

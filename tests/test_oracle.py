@@ -1,0 +1,100 @@
+"""The oracle against the golden vectors captured from the reference (CPU; runs everywhere)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cases import SMALL, load_fixture, rel_err, run_oracle
+from conftest import GOLDEN
+from oracle import planedepth_oracle as orc
+
+# The oracle repeats the reference's op sequence in the same dtype, so agreement is at rounding level.
+TOL = 2e-6
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_small_fixture(name):
+    case, want, run = load_fixture(name)
+    got = run_oracle(case, run)
+    for k, w in want.items():
+        if k in ("smooth_loss", "total_loss"):
+            continue
+        assert got[k].shape == w.shape, k
+        if float(w.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+        else:
+            assert rel_err(got[k], w) < TOL, (name, k, rel_err(got[k], w))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_restated_sampler_equals_torch_grid_sample(name):
+    """bilinear_sample (the published formula) == torch's own grid_sample kernel, forward and backward."""
+    case, want, run = load_fixture(name)
+    a = run_oracle(case, run)
+    b = run_oracle(case, run, sampler=lambda f, g, p: F.grid_sample(f, g, padding_mode=p, align_corners=True))
+    for k in a:
+        if float(b[k].abs().max()) > 0:
+            assert rel_err(a[k], b[k]) < TOL, (name, k)
+
+
+def test_modules():
+    z = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "modules.npz")).items()}
+    B, _, H, W = z["bp_depth"].shape
+    cam = orc.backproject_depth(z["bp_depth"], z["bp_inv_K"])
+    assert rel_err(cam, z["bp_cam"]) < TOL
+    assert rel_err(orc.project_3d(cam, z["bp_K"], z["bp_T"], H, W), z["pj_grid"]) < TOL
+    N = z["hw_d"].shape[1]
+    ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+    grid, mask = orc.homography_grid(z["hw_d"], z["hw_n"], ex(z["bp_T"]), ex(z["bp_K"]), ex(z["bp_inv_K"]), H, W)
+    assert rel_err(grid, z["hw_grid"]) < TOL
+    assert torch.equal(mask.float(), z["hw_mask"])
+    assert rel_err(orc.ssim(z["ssim_x"], z["ssim_y"]), z["ssim_out"]) < TOL
+    x = z["ssim_x"].clone().requires_grad_(True)
+    rl = orc.reprojection_loss(x, z["ssim_y"], use_ssim=True)
+    assert rel_err(rl, z["reproj_ssim"]) < TOL
+    (rl * z["reproj_gw"]).sum().backward()
+    assert rel_err(x.grad, z["reproj_g_pred"]) < 2e-5
+    assert rel_err(orc.reprojection_loss(z["ssim_x"], z["ssim_y"], use_ssim=False), z["reproj_l1"]) < TOL
+    assert rel_err(orc.multimodal_loss(z["mm_err"], z["mm_sigma"], z["mm_pi"], "lap"), z["mm_lap"]) < TOL
+    assert rel_err(orc.multimodal_loss(z["mm_err"], z["mm_sigma"], z["mm_pi"]), z["mm_gauss"]) < TOL
+    assert rel_err(orc.laplacian(z["mm_err"], z["mm_sigma"]), z["lap"]) < TOL
+    assert rel_err(orc.gaussian(z["mm_err"], z["mm_sigma"]), z["gauss"]) < TOL
+    assert rel_err(orc.smooth_loss_disp(z["sm_disp"], z["sm_img"], 2), z["sm_loss"]) < TOL
+    g = z["pj_grid"]
+    assert rel_err(orc.bilinear_sample(z["ssim_x"], g, "border"), z["gs_border"]) < TOL
+    assert rel_err(orc.bilinear_sample(z["ssim_x"], g, "zeros"), z["gs_zeros"]) < TOL
+
+
+def test_fp64_gradcheck_of_restatement():
+    """Finite-difference check (fp64) that autograd through the restatement is the true gradient."""
+    torch.manual_seed(3)
+    B, N, H, W = 1, 3, 4, 6
+    src, tgt = torch.rand(B, 3, H, W, dtype=torch.float64), torch.rand(B, 3, H, W, dtype=torch.float64)
+    logits = torch.randn(B, N, H, W, dtype=torch.float64, requires_grad=True)
+    sigma = (torch.rand(B, N, H, W, dtype=torch.float64) * 0.8 + 0.1).requires_grad_(True)
+    dpp = torch.tensor([0.6, 1.3, 2.45], dtype=torch.float64)[None, :, None, None].requires_grad_(True)
+    mask = torch.ones(B, N, H, W, dtype=torch.float64)
+    gw = torch.randn(B, 3, H, W, dtype=torch.float64)
+
+    def f(lg, sg, dp):
+        r = orc.warp_and_loss(src, tgt, lg, sg, disp_layered=dp.expand(-1, -1, H, W), padding_mask=mask)
+        return r["ph_loss"] + (r["rgb_rec"] * gw).sum()
+
+    assert torch.autograd.gradcheck(f, (logits, sigma, dpp), eps=1e-7, atol=1e-6, rtol=1e-5)
+
+
+def test_fullsize_known_answers():
+    """192x640x49 scalars captured from the reference — forward values only here (seconds on CPU)."""
+    from planedepth_amd.synthetic import survey_fullsize_case
+    with open(os.path.join(GOLDEN, "kat_fullsize.json")) as f:
+        kat = json.load(f)
+    case = survey_fullsize_case()
+    for name in ("full_disp_mix", "full_homo_mix"):
+        got = run_oracle(case, kat[name]["run"])
+        assert abs(float(got["ph_loss"]) - kat[name]["ph_loss"]) < 2e-6 * kat[name]["ph_loss"]
+        assert abs(float(got["rgb_rec"].double().sum()) - kat[name]["sum_rgb_rec"]) < 1e-6 * kat[name]["sum_rgb_rec"]
+        assert abs(float(got["g_logits"].double().abs().sum()) - kat[name]["l1_g_logits"]) < 1e-4 * kat[name]["l1_g_logits"]
+        assert abs(float(got["g_sigma"].double().abs().sum()) - kat[name]["l1_g_sigma"]) < 1e-4 * kat[name]["l1_g_sigma"]
