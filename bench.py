@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the warp+loss hot path (forward + backward) on MI355X.
+
+Metric (BASELINE.json): images/sec (warp+loss fwd+bwd), 192x640x49 planes, 1/2/4/8 GPU.
+A "step" = one pass of the hot path over one synthetic minibatch per GPU:
+    pred_novel_images (plane sweep, disp_warp, stereo target "r", mixture loss) -> compute_losses (photometric part)
+    -> backward to logits / sigma / per-plane disparities, with an upstream gradient on rgb_rec as well.
+Workload at N=1 = BASELINE.json configs[1]: batch 8, 192x640, 49 planes, --use_mixture_loss --plane_residual.
+Multi-GPU: the path shards over batch elements with no data-path collective: every rank runs its own
+shard (weak scaling); ranks only meet in the timing barrier and the max-over-ranks reduction.
+
+One JSON line is printed by rank 0.  Besides the driver's contract it carries
+  "roofline":     HBM roofline of the dominant kernel (algorithmic bytes / measured kernel time, HIP events)
+  "cpu_baseline": the CPU oracle (a port of the reference's op sequence) timed on this box's host cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--planes", type=int, default=49)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--warp_type", default="disp_warp", choices=["disp_warp", "homography_warp"])
+    ap.add_argument("--no_mixture", action="store_true")
+    ap.add_argument("--automask", action="store_true")
+    ap.add_argument("--no_padding_mask", action="store_true", help="do not feed the decoder's all-ones padding mask")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def make_batch(args, device, seed):
+    from planedepth_amd.synthetic import survey_fullsize_case
+    torch.manual_seed(seed)
+    c = survey_fullsize_case(B=args.batch, N=args.planes, H=args.height, W=args.width, seed=1234 + seed)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in c.items()}
+
+
+def build_step(args, c, device):
+    """Returns step() running the product path exactly as a patched Trainer would (dict contract of trainer.py)."""
+    import planedepth_amd
+    B, N, H, W = c["logits"].shape
+    mix = not args.no_mixture
+    logits = c["logits"].clone().requires_grad_(True)
+    sigma = c["sigma"].clone().requires_grad_(True)
+    disp_pp = c["disp_pp"].clone().requires_grad_(True)  # per-plane disparities incl. the learnt residual
+    Rt = c["Rt"].clone()
+    opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
+                                render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False)
+    zero = torch.zeros((), device=device)
+    ns = types.SimpleNamespace(opt=opt, target_sides=["r"], perceptual_loss=lambda *a, **k: zero)
+    inputs = {("color", "l"): c["color_l"], ("color", "r"): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
+    norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
+    shape_probe = torch.empty(B, N, H, W, device="meta")
+    g_rgb = c["g_rgb_rec"]
+    pm = None if args.no_padding_mask else c["padding_mask"]
+    if pm is None:
+        pm_arg = None
+    else:
+        pm_arg = pm
+
+    def step():
+        logits.grad = sigma.grad = disp_pp.grad = None
+        outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
+                   "disp_layered": disp_pp.expand(-1, -1, H, W), "padding_mask": pm_arg,
+                   "distance": 0.1 * 0.58 * W / disp_pp[:, :, 0, 0], "norm": norm, ("Rt", "r"): Rt}
+        planedepth_amd.pred_novel_images(ns, inputs, outputs)
+        # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
+        ph = outputs[("ph_map", "r")].mean()
+        rgb_rec = outputs[("rgb_rec", "r")]
+        torch.autograd.backward([ph, rgb_rec], [None, g_rgb])
+        return ph
+
+    return step, (logits, sigma, disp_pp)
+
+
+def algorithmic_bytes(args):
+    """per image per target side, fp32.  mixture: fwd (2N+9) HW 4, bwd (4N+9) HW 4."""
+    HW = args.height * args.width
+    N = args.planes
+    k = 2 if not args.no_mixture else 1
+    fwd = (k * N + 9) * HW * 4
+    bwd = (2 * k * N + 9) * HW * 4
+    return fwd, bwd
+
+
+def kernel_times(args, c, device, iters):
+    """Average duration of the forward and backward launches, HIP events on the stream the kernels run on."""
+    from planedepth_amd import _capi as C
+    lib = C.load()
+    B, N, H, W = c["logits"].shape
+    mix = not args.no_mixture
+    if args.warp_type != "disp_warp":
+        return None
+    flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
+    d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, 0)
+    plane = c["disp_pp"][:, :, 0, 0].contiguous()
+    pm = None if args.no_padding_mask else c["padding_mask"]
+    k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
+    rgb = torch.empty(B, 3, H, W, device=device)
+    ph = torch.empty(B, 1, H, W, device=device)
+    stash = torch.empty(B, k, H, W, device=device)
+    gl, gs, gp = torch.empty_like(c["logits"]), torch.empty_like(c["sigma"]), torch.empty_like(plane)
+    ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=device)
+    gph = torch.full((B, 1, H, W), 1.0 / (B * H * W), device=device)
+    st = C.stream_handle(device)
+    sig = c["sigma"] if mix else None
+
+    def fwd():
+        C.check(lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
+                                       C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(ph),
+                                       C.ptr(stash), st), "fwd")
+
+    def bwd():
+        C.check(lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
+                                       C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(stash),
+                                       C.ptr(c["g_rgb_rec"]), C.ptr(gph), C.ptr(gl), C.ptr(gs if mix else None),
+                                       C.ptr(gp), C.ptr(ws), st), "bwd")
+
+    out = {}
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        fn()
+        torch.cuda.synchronize(device)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(device)
+        out[name] = sum(a.elapsed_time(b) for a, b in ev) / iters  # ms
+    return out
+
+
+def cpu_baseline(args, budget_s):
+    """The oracle (port of the reference's op-by-op PyTorch path) on the host cores: B=1 sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import run_oracle
+    from planedepth_amd.synthetic import survey_fullsize_case
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    case = survey_fullsize_case(B=1, N=args.planes, H=args.height, W=args.width)
+    run = dict(warp_type=args.warp_type, use_mixture_loss=not args.no_mixture, automask=args.automask)
+    run_oracle(case, run)  # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 7 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        run_oracle(case, run)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle (torch CPU restatement of trainer.py:523-603,717-742) fwd+bwd, B=1, N=%d, %dx%d, median of %d"
+                      % (args.planes, args.height, args.width, len(times)),
+            "ms_per_image": round(med * 1e3, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm; used for the timing barrier/reduction only
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import __graft_entry__ as entry
+    entry.build()
+
+    c = make_batch(args, device, seed=rank)
+    step, _ = build_step(args, c, device)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_images = args.batch * world * args.steps
+    value = total_images / elapsed
+    result = {
+        "metric": "images/sec (warp+loss fwd+bwd), 192x640x49 planes", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %s, stereo target r, %s loss, batch %d/GPU, %dx%d, %d planes, "
+                               "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
+                               % (args.warp_type, "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
+                                  args.height, args.width, args.planes),
+                   "global_batch": args.batch * world, "planes": args.planes, "height": args.height,
+                   "width": args.width, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+                   "padding_mask": "decoder's dense all-ones [B,N,H,W]" if not args.no_padding_mask else "none"},
+    }
+    if rank == 0:
+        kt = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))
+        if kt:
+            fwd_b, bwd_b = algorithmic_bytes(args)
+            dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
+            per_launch = (bwd_b if dom == "bwd" else fwd_b) * args.batch
+            ach = per_launch / (kt[dom] * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": "pd_plane_sweep_" + dom, "achieved": round(ach, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "algorithmic_bytes_per_launch": per_launch,
+                                  "avg_launch_ms": round(kt[dom], 4)}
+            result["kernels"] = {
+                "fwd_ms": round(kt["fwd"], 4), "bwd_ms": round(kt["bwd"], 4),
+                "fwd_GBs": round(fwd_b * args.batch / (kt["fwd"] * 1e-3) / 1e9, 1),
+                "bwd_GBs": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9, 1),
+                "whole_path_frac_of_peak": round((fwd_b + bwd_b) * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * planedepth_hip.h — C ABI of the MI355X (gfx950) implementation of PlaneDepth's
+ * photometric-reconstruction hot path.
+ *
+ * The reference (svip-lab/PlaneDepth) has NO native/FFI boundary for this path: it is
+ * Python calling stock ATen ops.  This header is therefore the
+ * boundary a maintainer would bind with ctypes; every entry point
+ * cites the reference code it replaces.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous NCHW device pointers owned by the caller
+ *     (outputs are caller-allocated; nothing is allocated, freed or synchronised here);
+ *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous;
+ *   - every function returns PD_OK (0) or a PD_ERR_* code; pd_last_error() returns a
+ *     thread-local human-readable message for the last non-zero return on this thread;
+ *   - no global mutable state: safe to call from any thread (e.g. the autograd thread).
+ */
+#ifndef PLANEDEPTH_HIP_H
+#define PLANEDEPTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pd_stream_t; /* hipStream_t */
+
+enum pd_status {
+  PD_OK = 0,
+  PD_ERR_ARG = 1,         /* NULL pointer / bad shape / bad enum */
+  PD_ERR_UNSUPPORTED = 2, /* valid request this build does not implement */
+  PD_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after a launch */
+};
+
+/* How the per-plane sampling grid is generated (reference: opt.warp_type, trainer.py:533-560). */
+enum pd_warp_mode {
+  PD_WARP_DISP = 0,      /* trainer.py:540-554: x -> x + sign*disp_layered, y unchanged          */
+  PD_WARP_HOMOGRAPHY = 1 /* layers.py:221-233: p = H_t2s [x,y,1]^T, projective divide, mask      */
+};
+
+enum pd_sweep_flags {
+  PD_MIXTURE = 1,     /* opt.use_mixture_loss: sigma channel, Laplacian-mixture NLL (trainer.py:594-602, 728-730) */
+  PD_AUTOMASK = 2,    /* opt.automask: min with the identity-reprojection loss (trainer.py:731-734, 739-741)      */
+  PD_RENDER_PROB = 4, /* opt.render_probability: alpha compositing instead of softmax (trainer.py:584-591)        */
+  PD_DISP_DENSE = 8   /* disp mode: `plane` is a dense [B,N,H,W] map (xz/yz planes) instead of [B,N] scalars      */
+};
+
+enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
+
+typedef struct pd_sweep_desc {
+  int32_t B, N, H, W;
+  int32_t mode;  /* pd_warp_mode */
+  int32_t flags; /* OR of pd_sweep_flags */
+  float sign;    /* PD_WARP_DISP: +1 for target "r" (x + d), -1 for target "l" (x - d), 0 = grid untouched */
+  int32_t reserved;
+} pd_sweep_desc;
+
+int pd_version(void);
+const char* pd_last_error(void);
+
+/* Floats per image the forward pass stashes for the backward pass (softmax statistics + mask bits). */
+size_t pd_sweep_stash_floats(const pd_sweep_desc* d);
+/* Floats of scratch pd_plane_sweep_bwd needs for its per-block partial reductions of the plane-parameter gradient. */
+size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d);
+
+/*
+ * Fused replacement for Trainer.pred_novel_images (trainer.py:523-603, one target view) plus the photometric part
+ * of Trainer.compute_losses (trainer.py:717-742) — SURVEY.md rows A1, A2/A3, A5-A9.
+ *
+ *   src, tgt      [B,3,H,W]  source colour (inputs[(color,"l")]) and target colour
+ *   logits        [B,N,H,W]  outputs["logits"];  sigma [B,N,H,W] outputs["sigma"] (NULL unless PD_MIXTURE)
+ *   plane         PD_WARP_DISP:       outputs["disp_layered"] as [B,N] (or [B,N,H,W] with PD_DISP_DENSE)
+ *                 PD_WARP_HOMOGRAPHY: H_t2s [B*N,3,3] (layers.py:219)
+ *   plane_aux     PD_WARP_HOMOGRAPHY: R·n [B*N,3] (layers.py:223); else NULL
+ *   inv_K3        PD_WARP_HOMOGRAPHY: inv_K[:, :3, :3] as [B,3,3]; else NULL
+ *   padding_mask  PD_WARP_DISP: outputs["padding_mask"] [B,N,H,W] float 0/1, or NULL (= all ones);
+ *                 PD_WARP_HOMOGRAPHY: must be NULL (the mask is computed, layers.py:223-226)
+ *   dists         [B,N-1,H,W] outputs["dists"] with PD_RENDER_PROB, else NULL
+ * outputs
+ *   rgb_rec       [B,3,H,W]  outputs[("rgb_rec", side)]
+ *   ph_map        [B,1,H,W]  per-pixel photometric loss BEFORE the mean / mask_novel product of trainer.py:735-742
+ *   stash         [B, pd_sweep_stash_floats/(H*W), H, W] opaque, consumed by pd_plane_sweep_bwd
+ */
+int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                       const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                       const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map, float* stash,
+                       pd_stream_t stream);
+
+/*
+ * Backward of the above: what autograd computes through trainer.py:567-603 + 728-742 in the reference
+ * (grid_sampler_2d_backward, softmax/clamp/div/sum/log/abs backward ...).
+ *   g_rgb_rec [B,3,H,W] upstream gradient of rgb_rec (perceptual loss etc.), may be NULL (= zeros)
+ *   g_ph_map  [B,1,H,W] upstream gradient of ph_map, may be NULL (= zeros)
+ * outputs (each may be NULL to skip it)
+ *   g_logits, g_sigma  [B,N,H,W]  — fully overwritten
+ *   g_plane            same shape as `plane` (disp: [B,N] or dense [B,N,H,W]; homography: [B*N,3,3]) — overwritten
+ *   workspace          pd_sweep_bwd_workspace_floats(d) floats of scratch (only needed when g_plane != NULL)
+ */
+int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                       const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                       const float* padding_mask, const float* dists, const float* rgb_rec, const float* stash,
+                       const float* g_rgb_rec, const float* g_ph_map, float* g_logits, float* g_sigma, float* g_plane,
+                       float* workspace, pd_stream_t stream);
+
+/*
+ * The per-plane tensors the reference stores in `outputs` and the fused path never needs (trainer.py:582-602):
+ * rgb_rec_layered [B,N,3,H,W], logit_rec, probability_rec, sigma_rec, pi_rec [B,N,H,W].  Any output may be NULL.
+ * Forward only (values for logging / inspection; gradients flow through pd_plane_sweep_fwd/bwd).
+ */
+int pd_plane_sweep_layers(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                          const float* plane, const float* plane_aux, const float* inv_K3, const float* padding_mask,
+                          const float* dists, float* rgb_rec_layered, float* logit_rec, float* probability_rec,
+                          float* sigma_rec, float* pi_rec, pd_stream_t stream);
+
+/*
+ * SSIM (layers.py:276-306: 3x3 box, ReflectionPad2d(1), clamp((1-n/d)/2,0,1)) and
+ * Trainer.compute_reprojection_loss (trainer.py:687-699) — SURVEY.md row A10.
+ *   pd_ssim_fwd:        x,y [B,C,H,W] -> out [B,C,H,W]
+ *   pd_reproj_loss_fwd: pred,target [B,3,H,W] -> loss [B,1,H,W] = use_ssim ? 0.85*mean_c ssim + 0.15*mean_c|t-p| : mean_c|t-p|
+ *   pd_reproj_loss_bwd: g_loss [B,1,H,W] -> g_pred [B,3,H,W] (overwritten); g_target may be NULL
+ *   pd_ssim_bwd:        g_out [B,C,H,W] -> g_x, g_y [B,C,H,W] (either may be NULL)
+ */
+int pd_ssim_fwd(int B, int C, int H, int W, const float* x, const float* y, float* out, pd_stream_t stream);
+int pd_ssim_bwd(int B, int C, int H, int W, const float* x, const float* y, const float* g_out, float* g_x, float* g_y,
+                pd_stream_t stream);
+int pd_reproj_loss_fwd(int B, int H, int W, int use_ssim, const float* pred, const float* target, float* loss,
+                       pd_stream_t stream);
+int pd_reproj_loss_bwd(int B, int H, int W, int use_ssim, const float* pred, const float* target, const float* g_loss,
+                       float* g_pred, float* g_target, pd_stream_t stream);
+
+/*
+ * Geometry modules.
+ *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
+ *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]
+ *   pd_project3d       Project3D.forward, layers.py:169-182: cam [B,4,H*W], P=(K@T)[:, :3, :] [B,3,4] -> grid [B,H,W,2]
+ *   pd_project3d_bwd   g_grid -> g_cam [B,4,H*W] (may be NULL) and g_P [B,3,4] (may be NULL; needs workspace of
+ *                      12 * B * ceil(H*W/256) floats)
+ *   pd_homography_grid HomographyWarp.forward per-pixel part, layers.py:221-233: H_t2s [M,3,3], Rn [M,3],
+ *                      inv_K3 [M,3,3] -> grid [M,H,W,2], mask [M,H,W] (uint8 0/1)
+ *   pd_homography_grid_bwd  g_grid [M,H,W,2] -> g_H [M,3,3] (workspace: 9 * M * ceil(H*W/256) floats)
+ */
+int pd_backproject(int B, int H, int W, const float* depth, const float* inv_K, float* cam, pd_stream_t stream);
+int pd_backproject_bwd(int B, int H, int W, const float* inv_K, const float* g_cam, float* g_depth, pd_stream_t stream);
+int pd_project3d(int B, int H, int W, float eps, const float* cam, const float* P, float* grid, pd_stream_t stream);
+int pd_project3d_bwd(int B, int H, int W, float eps, const float* cam, const float* P, const float* g_grid,
+                     float* g_cam, float* g_P, float* workspace, pd_stream_t stream);
+int pd_homography_grid(int M, int H, int W, const float* H_t2s, const float* Rn, const float* inv_K3, float* grid,
+                       uint8_t* mask, pd_stream_t stream);
+int pd_homography_grid_bwd(int M, int H, int W, const float* H_t2s, const float* g_grid, float* g_H, float* workspace,
+                           pd_stream_t stream);
+
+/*
+ * F.grid_sample(input, grid, mode="bilinear", padding_mode=zeros|border, align_corners=True) as the reference calls it
+ * (trainer.py:444-463, 573-577, 624-628) — SURVEY.md row A5.
+ *   input [M,C,Hi,Wi], grid [M,Ho,Wo,2] -> out [M,C,Ho,Wo]
+ *   bwd: g_out -> g_input [M,C,Hi,Wi] (must be ZERO-FILLED by the caller; accumulated with atomics; may be NULL),
+ *                 g_grid [M,Ho,Wo,2] (overwritten; may be NULL)
+ */
+int pd_grid_sample_fwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding_mode, const float* input,
+                       const float* grid, float* out, pd_stream_t stream);
+int pd_grid_sample_bwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding_mode, const float* input,
+                       const float* grid, const float* g_out, float* g_input, float* g_grid, pd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLANEDEPTH_HIP_H */

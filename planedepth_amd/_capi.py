@@ -1,0 +1,104 @@
+"""ctypes binding of ``libplanedepth_hip.so`` (C ABI declared in ``include/planedepth_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent, importing the product
+ops raises.  The library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (imported first so the process already holds torch's libamdhip64 — one HIP runtime only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplanedepth_hip.so")
+
+PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
+PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE = 1, 2, 4, 8
+PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
+
+
+class SweepDesc(ctypes.Structure):
+    """Mirror of ``pd_sweep_desc``."""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("mode", ctypes.c_int32), ("flags", ctypes.c_int32), ("sign", ctypes.c_float),
+                ("reserved", ctypes.c_int32)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_D = ctypes.POINTER(SweepDesc)
+
+# name -> (restype, argtypes); must list every symbol include/planedepth_hip.h declares
+SIGNATURES = {
+    "pd_version": (_I, []),
+    "pd_last_error": (ctypes.c_char_p, []),
+    "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
+    "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),
+    "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 13),
+    "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 18),
+    "pd_plane_sweep_layers": (_I, [_D] + [_P] * 14),
+    "pd_ssim_fwd": (_I, [_I] * 4 + [_P] * 4),
+    "pd_ssim_bwd": (_I, [_I] * 4 + [_P] * 6),
+    "pd_reproj_loss_fwd": (_I, [_I] * 4 + [_P] * 4),
+    "pd_reproj_loss_bwd": (_I, [_I] * 4 + [_P] * 6),
+    "pd_backproject": (_I, [_I] * 3 + [_P] * 4),
+    "pd_backproject_bwd": (_I, [_I] * 3 + [_P] * 4),
+    "pd_project3d": (_I, [_I] * 3 + [_F] + [_P] * 4),
+    "pd_project3d_bwd": (_I, [_I] * 3 + [_F] + [_P] * 7),
+    "pd_homography_grid": (_I, [_I] * 3 + [_P] * 6),
+    "pd_homography_grid_bwd": (_I, [_I] * 3 + [_P] * 5),
+    "pd_grid_sample_fwd": (_I, [_I] * 7 + [_P] * 4),
+    "pd_grid_sample_bwd": (_I, [_I] * 7 + [_P] * 6),
+}
+
+_lib = None
+
+
+class PlaneDepthHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once and attach prototypes.  Raises if it is missing — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PlaneDepthHipError(
+            "planedepth_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pd_last_error().decode(errors="replace")
+        raise PlaneDepthHipError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle(device=None):
+    """The raw hipStream_t torch is currently enqueueing on (so our launches order with torch's ops)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_tensor(name, t, shape=None, dtype=torch.float32):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise PlaneDepthHipError("%s is on %s: planedepth_amd runs on the GPU only (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    return t

@@ -1,0 +1,118 @@
+// Shared device/host helpers for the planedepth_hip kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "planedepth_hip.h"
+
+namespace pd {
+
+constexpr int kWave = 64;    // CDNA wavefront width
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+// ---- host side -------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PD_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      pd::set_error(__VA_ARGS__);    \
+      return PD_ERR_ARG;             \
+    }                                \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device side -----------------------------------------------------------------------------------------------
+// Bilinear footprint of one sample under F.grid_sample(align_corners=True) semantics: the four taps
+// (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1) with torch's weights  nw=(x1-ix)(y1-iy), ne=(ix-x0)(y1-iy), ...
+struct Tap {
+  int x0, y0;
+  float wx0, wx1, wy0, wy1;  // (x1-ix), (ix-x0), (y1-iy), (iy-y0)
+  bool vx0, vx1, vy0, vy1;   // column x0 / x0+1 and row y0 / y0+1 inside the image
+};
+
+__device__ __forceinline__ Tap make_tap(float ix, float iy, int W, int H) {
+  Tap t;
+  const float xf = floorf(ix), yf = floorf(iy);
+  const float xf1 = xf + 1.0f, yf1 = yf + 1.0f;
+  t.wx0 = xf1 - ix;
+  t.wx1 = ix - xf;
+  t.wy0 = yf1 - iy;
+  t.wy1 = iy - yf;
+  // validity is decided on the float value (NaN / huge coordinates are simply "outside")
+  t.vx0 = (xf >= 0.0f) && (xf <= (float)(W - 1));
+  t.vx1 = (xf1 >= 0.0f) && (xf1 <= (float)(W - 1));
+  t.vy0 = (yf >= 0.0f) && (yf <= (float)(H - 1));
+  t.vy1 = (yf1 >= 0.0f) && (yf1 <= (float)(H - 1));
+  t.x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W);
+  t.y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H);
+  return t;
+}
+
+// Sample one [H,W] plane.  Out-of-image taps contribute zero (padding_mode="zeros").
+__device__ __forceinline__ float bilinear(const float* __restrict__ p, const Tap& t, int W) {
+  const float* r0 = p + (long)t.y0 * W + t.x0;
+  const float* r1 = r0 + W;
+  const float nw = (t.vx0 && t.vy0) ? r0[0] : 0.0f;
+  const float ne = (t.vx1 && t.vy0) ? r0[1] : 0.0f;
+  const float sw = (t.vx0 && t.vy1) ? r1[0] : 0.0f;
+  const float se = (t.vx1 && t.vy1) ? r1[1] : 0.0f;
+  return nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
+}
+
+// d(sample)/d(ix), d(sample)/d(iy) in pixel units (torch's grid_sampler_2d_backward before the (size-1)/2 factor).
+__device__ __forceinline__ void bilinear_grad(const float* __restrict__ p, const Tap& t, int W, float& dx, float& dy) {
+  const float* r0 = p + (long)t.y0 * W + t.x0;
+  const float* r1 = r0 + W;
+  const float nw = (t.vx0 && t.vy0) ? r0[0] : 0.0f;
+  const float ne = (t.vx1 && t.vy0) ? r0[1] : 0.0f;
+  const float sw = (t.vx0 && t.vy1) ? r1[0] : 0.0f;
+  const float se = (t.vx1 && t.vy1) ? r1[1] : 0.0f;
+  dx = (ne - nw) * t.wy0 + (se - sw) * t.wy1;
+  dy = (sw - nw) * t.wx0 + (se - ne) * t.wx1;
+}
+
+// Value and both derivatives from one set of loads.
+__device__ __forceinline__ float bilinear_vg(const float* __restrict__ p, const Tap& t, int W, float& dx, float& dy) {
+  const float* r0 = p + (long)t.y0 * W + t.x0;
+  const float* r1 = r0 + W;
+  const float nw = (t.vx0 && t.vy0) ? r0[0] : 0.0f;
+  const float ne = (t.vx1 && t.vy0) ? r0[1] : 0.0f;
+  const float sw = (t.vx0 && t.vy1) ? r1[0] : 0.0f;
+  const float se = (t.vx1 && t.vy1) ? r1[1] : 0.0f;
+  dx = (ne - nw) * t.wy0 + (se - sw) * t.wy1;
+  dy = (sw - nw) * t.wx0 + (se - ne) * t.wx1;
+  return nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
+}
+
+// Adjoint of `bilinear`: scatter g to the (valid) taps with hardware fp32 atomics (global_atomic_add_f32).
+__device__ __forceinline__ void bilinear_scatter(float* __restrict__ p, const Tap& t, int W, float g) {
+  float* r0 = p + (long)t.y0 * W + t.x0;
+  float* r1 = r0 + W;
+  if (t.vx0 && t.vy0) unsafeAtomicAdd(r0, g * (t.wx0 * t.wy0));
+  if (t.vx1 && t.vy0) unsafeAtomicAdd(r0 + 1, g * (t.wx1 * t.wy0));
+  if (t.vx0 && t.vy1) unsafeAtomicAdd(r1, g * (t.wx0 * t.wy1));
+  if (t.vx1 && t.vy1) unsafeAtomicAdd(r1 + 1, g * (t.wx1 * t.wy1));
+}
+
+// Pixel -> normalised [-1,1] -> pixel, with the reference's exact op order (trainer.py:550-552 then grid_sample's
+// un-normalisation).  The round trip is NOT the identity in fp32, so it is reproduced, not skipped.
+__device__ __forceinline__ float normalise_roundtrip(float px, float size_m1) {
+  const float g = (px / size_m1 - 0.5f) * 2.0f;
+  return (g + 1.0f) * 0.5f * size_m1;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+}  // namespace pd

@@ -1,0 +1,27 @@
+// Host-side plumbing shared by every entry point: thread-local error text, launch check, version.
+#include <stdarg.h>
+
+#include "pd_common.h"
+
+namespace pd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return PD_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return PD_ERR_LAUNCH;
+}
+
+}  // namespace pd
+
+extern "C" int pd_version(void) { return 100; /* 0.1.0 */ }
+extern "C" const char* pd_last_error(void) { return pd::g_err; }

@@ -1,0 +1,236 @@
+// Geometry modules of the reference as standalone kernels:
+//   BackprojectDepth.forward  layers.py:150-156     cam = depth * (K^-1 [x,y,1]) , homogeneous
+//   Project3D.forward         layers.py:169-182     grid = normalise( (P cam).xy / ((P cam).z + eps) )
+//   HomographyWarp.forward    layers.py:221-233     per-pixel part: p = H_t2s [x,y,1], mask, clamp z, divide, normalise
+// The [*,3,3] / [*,4,4] matrix algebra in front of them (K@T, R + t n^T/d, torch.inverse) is O(B*N) work and stays in
+// torch on the host side of the boundary (planedepth_amd/layers.py) — see DESIGN.md.
+#include "pd_common.h"
+
+namespace pd {
+
+__global__ __launch_bounds__(kBlock) void backproject_kernel(int HW, int W, const float* __restrict__ depth,
+                                                             const float* __restrict__ inv_K, float* __restrict__ cam) {
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int b = blockIdx.y;
+  const float* Ki = inv_K + (long)b * 16;  // [4,4] row-major; uses [:3,:3]
+  const float y = (float)(pix / W), x = (float)(pix % W);
+  const float d = depth[(long)b * HW + pix];
+  float* o = cam + (long)b * 4 * HW + pix;
+  o[0] = d * (Ki[0] * x + Ki[1] * y + Ki[2]);
+  o[HW] = d * (Ki[4] * x + Ki[5] * y + Ki[6]);
+  o[2 * HW] = d * (Ki[8] * x + Ki[9] * y + Ki[10]);
+  o[3 * HW] = 1.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void backproject_bwd_kernel(int HW, int W, const float* __restrict__ inv_K,
+                                                                 const float* __restrict__ g_cam,
+                                                                 float* __restrict__ g_depth) {
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int b = blockIdx.y;
+  const float* Ki = inv_K + (long)b * 16;
+  const float y = (float)(pix / W), x = (float)(pix % W);
+  const float* g = g_cam + (long)b * 4 * HW + pix;
+  g_depth[(long)b * HW + pix] = g[0] * (Ki[0] * x + Ki[1] * y + Ki[2]) + g[HW] * (Ki[4] * x + Ki[5] * y + Ki[6]) +
+                                g[2 * HW] * (Ki[8] * x + Ki[9] * y + Ki[10]);
+}
+
+__global__ __launch_bounds__(kBlock) void project3d_kernel(int H, int W, float eps, const float* __restrict__ cam,
+                                                           const float* __restrict__ P, float* __restrict__ grid) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int b = blockIdx.y;
+  const float* Pm = P + (long)b * 12;  // [3,4]
+  const float* c = cam + (long)b * 4 * HW + pix;
+  const float X = c[0], Y = c[HW], Z = c[2 * HW], Wh = c[3 * HW];
+  const float p0 = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3] * Wh;
+  const float p1 = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7] * Wh;
+  const float z = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11] * Wh + eps;
+  float2 o;
+  o.x = ((p0 / z) / (float)(W - 1) - 0.5f) * 2.0f;
+  o.y = ((p1 / z) / (float)(H - 1) - 0.5f) * 2.0f;
+  reinterpret_cast<float2*>(grid)[(long)b * HW + pix] = o;
+}
+
+// g_cam[b,:,pix] and per-block partial sums of g_P[b,3,4]
+__global__ __launch_bounds__(kBlock) void project3d_bwd_kernel(int H, int W, float eps, const float* __restrict__ cam,
+                                                               const float* __restrict__ P,
+                                                               const float* __restrict__ g_grid,
+                                                               float* __restrict__ g_cam, float* __restrict__ partials) {
+  __shared__ float red[12];
+  const int HW = H * W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  if (threadIdx.x < 12) red[threadIdx.x] = 0.0f;
+  __syncthreads();
+  float gk[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gk[k] = 0.0f;
+  if (pix < HW) {
+    const float* Pm = P + (long)b * 12;
+    const float* c = cam + (long)b * 4 * HW + pix;
+    const float v[4] = {c[0], c[HW], c[2 * HW], c[3 * HW]};
+    const float p0 = Pm[0] * v[0] + Pm[1] * v[1] + Pm[2] * v[2] + Pm[3] * v[3];
+    const float p1 = Pm[4] * v[0] + Pm[5] * v[1] + Pm[6] * v[2] + Pm[7] * v[3];
+    const float z = Pm[8] * v[0] + Pm[9] * v[1] + Pm[10] * v[2] + Pm[11] * v[3] + eps;
+    const float2 g = reinterpret_cast<const float2*>(g_grid)[(long)b * HW + pix];
+    const float gpx = g.x * 2.0f / (float)(W - 1), gpy = g.y * 2.0f / (float)(H - 1);
+    const float g0 = gpx / z, g1 = gpy / z, g2 = -(gpx * p0 + gpy * p1) / (z * z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gk[j] = g0 * v[j];
+      gk[4 + j] = g1 * v[j];
+      gk[8 + j] = g2 * v[j];
+    }
+    if (g_cam) {
+      float* gc = g_cam + (long)b * 4 * HW + pix;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gc[(long)j * HW] = g0 * Pm[j] + g1 * Pm[4 + j] + g2 * Pm[8 + j];
+    }
+  }
+  if (partials) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float s = wave_sum(gk[k]);
+      if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[k], s);
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) partials[((long)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = red[threadIdx.x];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void homography_grid_kernel(int H, int W, const float* __restrict__ Ht2s,
+                                                                 const float* __restrict__ Rn,
+                                                                 const float* __restrict__ invK3,
+                                                                 float* __restrict__ grid, uint8_t* __restrict__ mask) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int m = blockIdx.y;
+  const float* Hm = Ht2s + (long)m * 9;
+  const float* Ki = invK3 + (long)m * 9;
+  const float* rn = Rn + (long)m * 3;
+  const float fy = (float)(pix / W), fx = (float)(pix % W);
+  const float p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
+  const float p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
+  const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
+  const float facing = (Ki[0] * fx + Ki[1] * fy + Ki[2]) * rn[0] + (Ki[3] * fx + Ki[4] * fy + Ki[5]) * rn[1] +
+                       (Ki[6] * fx + Ki[7] * fy + Ki[8]) * rn[2];
+  const float zc = (z < 1e-7f) ? 1e-7f : z;
+  float2 o;
+  o.x = ((p0 / zc) / (float)(W - 1) - 0.5f) * 2.0f;
+  o.y = ((p1 / zc) / (float)(H - 1) - 0.5f) * 2.0f;
+  reinterpret_cast<float2*>(grid)[(long)m * HW + pix] = o;
+  if (mask) mask[(long)m * HW + pix] = (facing > 0.0f && z > 1e-7f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void homography_grid_bwd_kernel(int H, int W, const float* __restrict__ Ht2s,
+                                                                     const float* __restrict__ g_grid,
+                                                                     float* __restrict__ partials) {
+  __shared__ float red[9];
+  const int HW = H * W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int m = blockIdx.y;
+  if (threadIdx.x < 9) red[threadIdx.x] = 0.0f;
+  __syncthreads();
+  float gk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gk[k] = 0.0f;
+  if (pix < HW) {
+    const float* Hm = Ht2s + (long)m * 9;
+    const float fy = (float)(pix / W), fx = (float)(pix % W);
+    const float p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
+    const float p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
+    const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
+    const bool clamped = z < 1e-7f;
+    const float zc = clamped ? 1e-7f : z;
+    const float2 g = reinterpret_cast<const float2*>(g_grid)[(long)m * HW + pix];
+    const float gpx = g.x * 2.0f / (float)(W - 1), gpy = g.y * 2.0f / (float)(H - 1);
+    const float g0 = gpx / zc, g1 = gpy / zc, g2 = clamped ? 0.0f : -(gpx * p0 + gpy * p1) / (zc * zc);
+    gk[0] = g0 * fx; gk[1] = g0 * fy; gk[2] = g0;
+    gk[3] = g1 * fx; gk[4] = g1 * fy; gk[5] = g1;
+    gk[6] = g2 * fx; gk[7] = g2 * fy; gk[8] = g2;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float s = wave_sum(gk[k]);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[k], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) partials[((long)m * gridDim.x + blockIdx.x) * 9 + threadIdx.x] = red[threadIdx.x];
+}
+
+__global__ void reduce_small_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblk, int M) {
+  const int j = threadIdx.x;
+  const int b = blockIdx.x;
+  if (j >= M) return;
+  float acc = 0.0f;
+  for (int i = 0; i < nblk; ++i) acc += partials[((long)b * nblk + i) * M + j];
+  out[(long)b * M + j] = acc;
+}
+
+}  // namespace pd
+
+using namespace pd;
+
+extern "C" int pd_backproject(int B, int H, int W, const float* depth, const float* inv_K, float* cam,
+                              pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "bad shape");
+  PD_REQUIRE(depth && inv_K && cam, "NULL pointer");
+  backproject_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(H * W, W, depth, inv_K, cam);
+  return check_launch("backproject_kernel");
+}
+
+extern "C" int pd_backproject_bwd(int B, int H, int W, const float* inv_K, const float* g_cam, float* g_depth,
+                                  pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "bad shape");
+  PD_REQUIRE(inv_K && g_cam && g_depth, "NULL pointer");
+  backproject_bwd_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(H * W, W, inv_K, g_cam,
+                                                                                                g_depth);
+  return check_launch("backproject_bwd_kernel");
+}
+
+extern "C" int pd_project3d(int B, int H, int W, float eps, const float* cam, const float* P, float* grid,
+                            pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && B <= 65535 && H > 1 && W > 1, "bad shape");
+  PD_REQUIRE(cam && P && grid, "NULL pointer");
+  project3d_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(H, W, eps, cam, P, grid);
+  return check_launch("project3d_kernel");
+}
+
+extern "C" int pd_project3d_bwd(int B, int H, int W, float eps, const float* cam, const float* P, const float* g_grid,
+                                float* g_cam, float* g_P, float* workspace, pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && B <= 65535 && H > 1 && W > 1, "bad shape");
+  PD_REQUIRE(cam && P && g_grid, "NULL pointer");
+  PD_REQUIRE(!g_P || workspace, "g_P needs workspace");
+  const int nblk = ceil_div(H * W, kBlock);
+  project3d_bwd_kernel<<<dim3(nblk, B), kBlock, 0, (hipStream_t)stream>>>(H, W, eps, cam, P, g_grid, g_cam,
+                                                                          g_P ? workspace : nullptr);
+  int rc = check_launch("project3d_bwd_kernel");
+  if (rc || !g_P) return rc;
+  reduce_small_kernel<<<B, 64, 0, (hipStream_t)stream>>>(workspace, g_P, nblk, 12);
+  return check_launch("reduce_small_kernel");
+}
+
+extern "C" int pd_homography_grid(int M, int H, int W, const float* H_t2s, const float* Rn, const float* inv_K3,
+                                  float* grid, uint8_t* mask, pd_stream_t stream) {
+  PD_REQUIRE(M > 0 && M <= 65535 && H > 1 && W > 1, "bad shape");
+  PD_REQUIRE(H_t2s && Rn && inv_K3 && grid, "NULL pointer");
+  homography_grid_kernel<<<dim3(ceil_div(H * W, kBlock), M), kBlock, 0, (hipStream_t)stream>>>(H, W, H_t2s, Rn, inv_K3,
+                                                                                                grid, mask);
+  return check_launch("homography_grid_kernel");
+}
+
+extern "C" int pd_homography_grid_bwd(int M, int H, int W, const float* H_t2s, const float* g_grid, float* g_H,
+                                      float* workspace, pd_stream_t stream) {
+  PD_REQUIRE(M > 0 && M <= 65535 && H > 1 && W > 1, "bad shape");
+  PD_REQUIRE(H_t2s && g_grid && g_H && workspace, "NULL pointer");
+  const int nblk = ceil_div(H * W, kBlock);
+  homography_grid_bwd_kernel<<<dim3(nblk, M), kBlock, 0, (hipStream_t)stream>>>(H, W, H_t2s, g_grid, workspace);
+  int rc = check_launch("homography_grid_bwd_kernel");
+  if (rc) return rc;
+  reduce_small_kernel<<<M, 64, 0, (hipStream_t)stream>>>(workspace, g_H, nblk, 9);
+  return check_launch("reduce_small_kernel");
+}

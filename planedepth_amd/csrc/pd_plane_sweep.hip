@@ -1,0 +1,547 @@
+// Fused orthogonal-plane sweep: grid generation -> bilinear warp of (rgb, logit, sigma) -> mask -> softmax over
+// planes -> mixture weights -> composite + photometric loss, forward and backward, for gfx950.
+//
+// Replaces Trainer.pred_novel_images (reference trainer.py:523-603) and the photometric part of
+// Trainer.compute_losses (trainer.py:717-742, layers.py:454-466).  The reference materialises
+// [B,N,5,H,W] intermediates (~1 GB / image); here one thread owns one target pixel and STREAMS over the N
+// planes with an online softmax, so HBM sees logits+sigma once per pass and nothing else of size N*HW.
+//
+// Kernels in this file (general path; the row-shift specialisation of the backward lives in
+// pd_plane_sweep_rowshift.hip):
+//   sweep_fwd_kernel      one pass over N: rgb_rec, ph_map, stash (lse, S, Mx, automask flag, mask bits)
+//   sweep_bwd_kernel      one pass over N: re-sample, per-plane gradients, atomic scatter to g_logits/g_sigma,
+//                         block-reduced plane-parameter gradient partials
+//   reduce_partials_kernel  deterministic second stage for the plane-parameter gradient
+//   sweep_layers_kernel   optional materialisation of the per-plane tensors the reference stores in `outputs`
+#include "pd_common.h"
+
+namespace pd {
+
+constexpr int kStashBase = 4;  // lse, S, Mx, flags
+constexpr float kSigmaMin = 0.01f, kSigmaMax = 1.0f, kLogEps = 1e-7f, kZMin = 1e-7f;
+
+struct SweepArgs {
+  int B, N, H, W;
+  int flags;
+  float sign;
+  int stash_k;     // floats per pixel in the stash: kStashBase + ceil(N/32) mask words in disp mode
+  int has_mask;    // disp mode with a padding_mask tensor: mask bits live in the stash words
+  const float* src;
+  const float* tgt;
+  const float* logits;
+  const float* sigma;
+  const float* plane;
+  const float* plane_aux;
+  const float* inv_K3;
+  const float* padding_mask;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sampling position of target pixel (x,y) on plane n of image b, plus the padding mask.
+// DISP:        trainer.py:540-554   (x + sign*d, y) normalised by (W-1, H-1)
+// HOMOGRAPHY:  layers.py:221-233    p = H_t2s [x,y,1]; mask = ((K^-1 p_t).(R n) > 0) & (z > 1e-7); z<1e-7 -> 1e-7
+// ---------------------------------------------------------------------------------------------------------------
+struct PlaneGeom {   // per (pixel, plane) state needed again for the grid gradient
+  float ix, iy;
+  float p0, p1, zc;  // homography only
+  bool z_clamped;
+};
+
+template <int MODE>
+__device__ __forceinline__ PlaneGeom plane_coords(const SweepArgs& a, int b, int n, int x, int y, float iy_disp,
+                                                  bool& mask) {
+  PlaneGeom g;
+  if (MODE == PD_WARP_DISP) {
+    float d;
+    if (a.flags & PD_DISP_DENSE)
+      d = a.plane[(((long)b * a.N + n) * a.H + y) * a.W + x];
+    else
+      d = a.plane[b * a.N + n];
+    g.ix = normalise_roundtrip((float)x + a.sign * d, (float)(a.W - 1));
+    g.iy = iy_disp;
+    g.p0 = g.p1 = g.zc = 0.0f;
+    g.z_clamped = false;
+    mask = true;  // caller applies the padding_mask tensor
+  } else {
+    const float* Hm = a.plane + ((long)b * a.N + n) * 9;
+    const float* Rn = a.plane_aux + ((long)b * a.N + n) * 3;
+    const float* Ki = a.inv_K3 + (long)b * 9;
+    const float fx = (float)x, fy = (float)y;
+    g.p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
+    g.p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
+    const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
+    const float r0 = Ki[0] * fx + Ki[1] * fy + Ki[2];
+    const float r1 = Ki[3] * fx + Ki[4] * fy + Ki[5];
+    const float r2 = Ki[6] * fx + Ki[7] * fy + Ki[8];
+    const float facing = r0 * Rn[0] + r1 * Rn[1] + r2 * Rn[2];
+    mask = (facing > 0.0f) && (z > kZMin);
+    g.z_clamped = (z < kZMin);
+    g.zc = g.z_clamped ? kZMin : z;
+    g.ix = normalise_roundtrip(g.p0 / g.zc, (float)(a.W - 1));
+    g.iy = normalise_roundtrip(g.p1 / g.zc, (float)(a.H - 1));
+  }
+  return g;
+}
+
+__device__ __forceinline__ bool read_mask(const SweepArgs& a, int b, int n, int x, int y) {
+  return a.padding_mask[(((long)b * a.N + n) * a.H + y) * a.W + x] != 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, bool MIX>
+__global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+                                                           float* __restrict__ ph_map, float* __restrict__ stash) {
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= HW) return;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const bool automask = a.flags & PD_AUTOMASK;
+  const bool has_mask = (MODE == PD_WARP_DISP) && a.has_mask;
+
+  const float* srcb = a.src + (long)b * 3 * HW;
+  const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+  const float t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+  const float t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+  float ea = 0.0f;  // identity-reprojection error mean_c |src - tgt| (trainer.py:732 / 740)
+  if (automask)
+    ea = (fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2)) / 3.0f;
+  const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
+
+  float m_run = -INFINITY, Z = 0.0f, S = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Mx = 0.0f, Ma = 0.0f;
+  uint32_t bits = 0;
+  for (int n = 0; n < a.N; ++n) {
+    bool mk;
+    const PlaneGeom g = plane_coords<MODE>(a, b, n, x, y, iy_disp, mk);
+    if (has_mask) {
+      mk = read_mask(a, b, n, x, y);
+      if (mk) bits |= 1u << (n & 31);
+      if ((n & 31) == 31 || n == a.N - 1) {
+        stash[((long)b * a.stash_k + kStashBase + (n >> 5)) * HW + pix] = __uint_as_float(bits);
+        bits = 0;
+      }
+    }
+    float l = 0.0f, s = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    if (mk) {  // rec_features * padding_mask (trainer.py:580): a masked plane samples as all-zero features
+      const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
+      const long pl = ((long)b * a.N + n) * HW;
+      l = bilinear(a.logits + pl, t, a.W);
+      if (MIX) s = bilinear(a.sigma + pl, t, a.W);
+      c0 = bilinear(srcb, t, a.W);
+      c1 = bilinear(srcb + HW, t, a.W);
+      c2 = bilinear(srcb + 2 * HW, t, a.W);
+    }
+    // online softmax over planes (trainer.py:593): rescale the running sums when the max moves
+    if (l > m_run) {
+      const float sc = fast_exp(m_run - l);
+      Z *= sc; S *= sc; C0 *= sc; C1 *= sc; C2 *= sc; Mx *= sc; Ma *= sc;
+      m_run = l;
+    }
+    const float p = fast_exp(l - m_run);
+    Z += p;
+    if (MIX) {
+      const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);  // trainer.py:597
+      const float inv = 1.0f / sg;
+      const float u = p * inv;                                 // pi / sigma  (trainer.py:600)
+      S += u;
+      C0 += c0 * u; C1 += c1 * u; C2 += c2 * u;
+      const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;  // trainer.py:729
+      Mx += u * (0.5f * fast_exp(-e * inv));                                      // pi * laplacian(e; sigma)
+      if (automask) Ma += u * (0.5f * fast_exp(-ea * inv));
+    } else {
+      C0 += c0 * p; C1 += c1 * p; C2 += c2 * p;
+    }
+  }
+  const float invZ = 1.0f / Z;
+  float r0, r1, r2, ph, sel = 0.0f;
+  float* st = stash + (long)b * a.stash_k * HW + pix;
+  if (MIX) {
+    const float invS = 1.0f / S;
+    r0 = C0 * invS; r1 = C1 * invS; r2 = C2 * invS;
+    const float mx = Mx * invZ;
+    ph = -__logf(mx + kLogEps);  // layers.py:466
+    if (automask) {
+      const float pa = -__logf(Ma * invZ + kLogEps);
+      if (pa < ph) { ph = pa; sel = 1.0f; }  // torch.min over cat([ph, ph_auto]) keeps the first on ties
+    }
+    st[HW] = S * invZ;
+    st[2 * HW] = mx;
+  } else {
+    r0 = C0 * invZ; r1 = C1 * invZ; r2 = C2 * invZ;
+    ph = (fabsf(r0 - t0) + fabsf(r1 - t1) + fabsf(r2 - t2)) / 3.0f;  // trainer.py:738
+    if (automask && ea < ph) { ph = ea; sel = 1.0f; }
+    st[HW] = 0.0f;
+    st[2 * HW] = 0.0f;
+  }
+  st[0] = m_run + __logf(Z);
+  st[3 * HW] = sel;
+  rgb_rec[((long)b * 3 + 0) * HW + pix] = r0;
+  rgb_rec[((long)b * 3 + 1) * HW + pix] = r1;
+  rgb_rec[((long)b * 3 + 2) * HW + pix] = r2;
+  ph_map[(long)b * HW + pix] = ph;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward (general: any warp, atomics for the bilinear adjoint)
+// ---------------------------------------------------------------------------------------------------------------
+struct BwdOut {
+  float* g_logits;
+  float* g_sigma;
+  float* g_plane;    // dense disp: written directly; otherwise via partials
+  float* partials;   // [B][nblk][N*K]  (K = 1 disp, 9 homography)
+  const float* rgb_rec;
+  const float* stash;
+  const float* g_rgb_rec;
+  const float* g_ph_map;
+};
+
+template <int MODE, bool MIX>
+__global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o) {
+  extern __shared__ float red[];  // [N*K] block accumulators of the plane-parameter gradient
+  constexpr int K = (MODE == PD_WARP_DISP) ? 1 : 9;
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  const bool want_plane = (o.g_plane != nullptr);
+  const bool dense = (MODE == PD_WARP_DISP) && (a.flags & PD_DISP_DENSE);
+  const bool reduce_plane = want_plane && !dense;
+  if (reduce_plane) {
+    for (int i = threadIdx.x; i < a.N * K; i += kBlock) red[i] = 0.0f;
+    __syncthreads();
+  }
+  const bool active = pix < HW;
+  const int y = active ? pix / a.W : 0, x = active ? pix - y * a.W : 0;
+  const bool has_mask = (MODE == PD_WARP_DISP) && a.has_mask;
+  const float* srcb = a.src + (long)b * 3 * HW;
+  const int SK = a.stash_k;
+
+  float t0 = 0, t1 = 0, t2 = 0, lse = 0, Sn = 1, mx = 1, gp = 0, gr0 = 0, gr1 = 0, gr2 = 0, r0 = 0, r1 = 0, r2 = 0;
+  if (active) {
+    t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+    t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+    t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+    const float* st = o.stash + (long)b * SK * HW + pix;
+    lse = st[0];
+    Sn = st[HW];
+    mx = st[2 * HW];
+    const float sel = st[3 * HW];
+    gp = (o.g_ph_map && sel == 0.0f) ? o.g_ph_map[(long)b * HW + pix] : 0.0f;
+    r0 = o.rgb_rec[((long)b * 3 + 0) * HW + pix];
+    r1 = o.rgb_rec[((long)b * 3 + 1) * HW + pix];
+    r2 = o.rgb_rec[((long)b * 3 + 2) * HW + pix];
+    if (o.g_rgb_rec) {
+      gr0 = o.g_rgb_rec[((long)b * 3 + 0) * HW + pix];
+      gr1 = o.g_rgb_rec[((long)b * 3 + 1) * HW + pix];
+      gr2 = o.g_rgb_rec[((long)b * 3 + 2) * HW + pix];
+    }
+    if (!MIX) {  // L1 branch: ph = mean_c |rgb_rec - tgt| feeds straight into the rgb_rec gradient
+      gr0 += gp * sgn(r0 - t0) / 3.0f;
+      gr1 += gp * sgn(r1 - t1) / 3.0f;
+      gr2 += gp * sgn(r2 - t2) / 3.0f;
+    }
+  }
+  const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
+  const float A = MIX ? gp / (mx + kLogEps) : 0.0f;   // -d ph / d Mx  (layers.py:466)
+  const float invS = MIX ? 1.0f / Sn : 1.0f;
+  const float gdotr = gr0 * r0 + gr1 * r1 + gr2 * r2;
+  const float halfWm1 = (float)(a.W - 1) / 2, halfHm1 = (float)(a.H - 1) / 2;
+
+  uint32_t bits = 0;
+  for (int n = 0; n < a.N; ++n) {
+    float gk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gk[k] = 0.0f;
+    if (active) {
+      bool mk;
+      const PlaneGeom g = plane_coords<MODE>(a, b, n, x, y, iy_disp, mk);
+      if (has_mask) {
+        if ((n & 31) == 0) bits = __float_as_uint(o.stash[((long)b * SK + kStashBase + (n >> 5)) * HW + pix]);
+        mk = (bits >> (n & 31)) & 1u;
+      }
+      const long pl = ((long)b * a.N + n) * HW;
+      float gd_dense = 0.0f;
+      if (mk) {
+        const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
+        float dlx, dly, dsx = 0, dsy = 0, d0x, d0y, d1x, d1y, d2x, d2y;
+        const float l = bilinear_vg(a.logits + pl, t, a.W, dlx, dly);
+        const float c0 = bilinear_vg(srcb, t, a.W, d0x, d0y);
+        const float c1 = bilinear_vg(srcb + HW, t, a.W, d1x, d1y);
+        const float c2 = bilinear_vg(srcb + 2 * HW, t, a.W, d2x, d2y);
+        const float p = fast_exp(l - lse);  // pi_n
+        float g_l, g_s = 0.0f, gc0, gc1, gc2;
+        if (MIX) {
+          const float s = bilinear_vg(a.sigma + pl, t, a.W, dsx, dsy);
+          const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
+          const float inv = 1.0f / sg;
+          const float u = p * inv;
+          const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;
+          const float q = 0.5f * fast_exp(-e * inv) * inv;                        // laplacian(e; sigma)
+          const float gu = (gr0 * c0 + gr1 * c1 + gr2 * c2 - gdotr) * invS;       // d(rgb_rec . g)/d u_n
+          const float g_pi = -A * q + gu * inv;
+          g_l = p * (g_pi + A * mx);                                              // softmax backward, closed form
+          const float g_sig = -A * p * q * (e * inv * inv - inv) - gu * u * inv;  // d/d sigma_n
+          g_s = (s >= kSigmaMin && s <= kSigmaMax) ? g_sig : 0.0f;                // clamp passes grad on [min,max]
+          const float g_e = A * u * q;                                            // d ph / d e_n  (u*q = pi*q/sigma)
+          const float w = u * invS;
+          gc0 = gr0 * w + g_e * sgn(c0 - t0) / 3.0f;
+          gc1 = gr1 * w + g_e * sgn(c1 - t1) / 3.0f;
+          gc2 = gr2 * w + g_e * sgn(c2 - t2) / 3.0f;
+          if (o.g_sigma) bilinear_scatter(o.g_sigma + pl, t, a.W, g_s);
+        } else {
+          g_l = p * (gr0 * c0 + gr1 * c1 + gr2 * c2 - gdotr);
+          gc0 = gr0 * p; gc1 = gr1 * p; gc2 = gr2 * p;
+        }
+        if (o.g_logits) bilinear_scatter(o.g_logits + pl, t, a.W, g_l);
+        if (want_plane) {
+          // d loss / d (ix, iy) in pixels, then back through grid_sample's un-normalisation ((size-1)/2) and the
+          // reference's normalisation (*2, /(size-1)) in autograd's order.
+          const float gix = g_l * dlx + g_s * dsx + gc0 * d0x + gc1 * d1x + gc2 * d2x;
+          const float gpx = gix * halfWm1 * 2.0f / (float)(a.W - 1);
+          if (MODE == PD_WARP_DISP) {
+            gk[0] = gpx * a.sign;
+            gd_dense = gk[0];
+          } else {
+            const float giy = g_l * dly + g_s * dsy + gc0 * d0y + gc1 * d1y + gc2 * d2y;
+            const float gpy = giy * halfHm1 * 2.0f / (float)(a.H - 1);
+            const float gp0 = gpx / g.zc, gp1 = gpy / g.zc;
+            const float gz = g.z_clamped ? 0.0f : -(gpx * g.p0 + gpy * g.p1) / (g.zc * g.zc);
+            const float fx = (float)x, fy = (float)y;
+            gk[0] = gp0 * fx; gk[1] = gp0 * fy; gk[2] = gp0;
+            gk[3] = gp1 * fx; gk[4] = gp1 * fy; gk[5] = gp1;
+            gk[6] = gz * fx;  gk[7] = gz * fy;  gk[8] = gz;
+          }
+        }
+      }
+      if (dense && want_plane) o.g_plane[pl + pix] = gd_dense;
+    }
+    if (reduce_plane) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float v = wave_sum(gk[k]);
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[n * K + k], v);  // LDS atomic, 4 waves
+      }
+    }
+  }
+  if (reduce_plane) {
+    __syncthreads();
+    float* dst = o.partials + ((long)b * gridDim.x + blockIdx.x) * a.N * K;
+    for (int i = threadIdx.x; i < a.N * K; i += kBlock) dst[i] = red[i];
+  }
+}
+
+// partials [B][nblk][M] -> out [B][M], summed in a fixed order (deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblk, int M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= M) return;
+  const float* p = partials + (long)b * nblk * M + j;
+  float acc = 0.0f;
+  for (int i = 0; i < nblk; ++i) acc += p[(long)i * M];
+  out[(long)b * M + j] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-plane tensors of trainer.py:582-602 (forward values only)
+// ---------------------------------------------------------------------------------------------------------------
+struct LayersOut {
+  float* rgb_rec_layered;  // [B,N,3,H,W]
+  float* logit_rec;        // [B,N,H,W]
+  float* probability_rec;  // [B,N,H,W]  softmax, or mixture weights when MIX (trainer.py:602)
+  float* sigma_rec;        // [B,N,H,W]
+  float* pi_rec;           // [B,N,H,W]
+};
+
+template <int MODE, bool MIX>
+__global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, LayersOut o) {
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= HW) return;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const bool has_mask = (MODE == PD_WARP_DISP) && a.padding_mask != nullptr;
+  const float* srcb = a.src + (long)b * 3 * HW;
+  const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
+  // pass 1: softmax statistics; pass 2: write
+  float m_run = -INFINITY, Z = 0.0f, S = 0.0f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float lse = (pass == 1) ? m_run + __logf(Z) : 0.0f;
+    const float invSn = (pass == 1 && MIX) ? Z / S : 0.0f;
+    for (int n = 0; n < a.N; ++n) {
+      bool mk;
+      const PlaneGeom g = plane_coords<MODE>(a, b, n, x, y, iy_disp, mk);
+      if (has_mask) mk = read_mask(a, b, n, x, y);
+      float l = 0, s = 0, c0 = 0, c1 = 0, c2 = 0;
+      const long pl = ((long)b * a.N + n) * HW;
+      if (mk) {
+        const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
+        l = bilinear(a.logits + pl, t, a.W);
+        if (MIX) s = bilinear(a.sigma + pl, t, a.W);
+        if (pass == 1 && o.rgb_rec_layered) {
+          c0 = bilinear(srcb, t, a.W);
+          c1 = bilinear(srcb + HW, t, a.W);
+          c2 = bilinear(srcb + 2 * HW, t, a.W);
+        }
+      }
+      const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
+      if (pass == 0) {
+        if (l > m_run) {
+          const float sc = fast_exp(m_run - l);
+          Z *= sc; S *= sc;
+          m_run = l;
+        }
+        const float p = fast_exp(l - m_run);
+        Z += p;
+        if (MIX) S += p / sg;
+      } else {
+        const float pi = fast_exp(l - lse);
+        if (o.rgb_rec_layered) {
+          float* q = o.rgb_rec_layered + ((long)b * a.N + n) * 3 * HW + pix;
+          q[0] = c0; q[HW] = c1; q[2 * HW] = c2;
+        }
+        if (o.logit_rec) o.logit_rec[pl + pix] = l;
+        if (MIX) {
+          if (o.sigma_rec) o.sigma_rec[pl + pix] = sg;
+          if (o.pi_rec) o.pi_rec[pl + pix] = pi;
+          if (o.probability_rec) o.probability_rec[pl + pix] = pi / sg * invSn;
+        } else if (o.probability_rec) {
+          o.probability_rec[pl + pix] = pi;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pd
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+using namespace pd;
+
+static int validate(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                    const float* plane, const float* plane_aux, const float* inv_K3, const float* padding_mask) {
+  PD_REQUIRE(d != nullptr, "desc is NULL");
+  PD_REQUIRE(d->B > 0 && d->N > 0 && d->H > 1 && d->W > 1, "bad shape B=%d N=%d H=%d W=%d (need H,W >= 2)", d->B, d->N,
+             d->H, d->W);
+  PD_REQUIRE(d->B <= 65535, "B=%d exceeds the grid.y limit", d->B);
+  PD_REQUIRE(d->mode == PD_WARP_DISP || d->mode == PD_WARP_HOMOGRAPHY, "unknown warp mode %d", d->mode);
+  PD_REQUIRE(src && logits && plane, "src/logits/plane must not be NULL");
+  PD_REQUIRE(!(d->flags & PD_MIXTURE) || sigma, "PD_MIXTURE needs sigma");
+  if (d->mode == PD_WARP_HOMOGRAPHY) {
+    PD_REQUIRE(plane_aux && inv_K3, "homography mode needs plane_aux (R n) and inv_K3");
+    PD_REQUIRE(padding_mask == nullptr, "homography mode computes its own padding mask; pass NULL");
+    PD_REQUIRE(!(d->flags & PD_DISP_DENSE), "PD_DISP_DENSE is a disp-mode flag");
+  }
+  if (d->flags & PD_RENDER_PROB) {
+    set_error("PD_RENDER_PROB is handled by pd_plane_sweep_render_* (not this entry point)");
+    return PD_ERR_UNSUPPORTED;
+  }
+  return PD_OK;
+}
+
+static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                           const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                           const float* padding_mask) {
+  SweepArgs a;
+  a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
+  a.flags = d->flags;
+  a.sign = d->sign;
+  a.stash_k = kStashBase + ((d->mode == PD_WARP_DISP) ? (d->N + 31) / 32 : 0);
+  a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr) ? 1 : 0;
+  a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
+  a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3; a.padding_mask = padding_mask;
+  return a;
+}
+
+extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
+  if (!d) return 0;
+  const size_t words = (d->mode == PD_WARP_DISP) ? (size_t)(d->N + 31) / 32 : 0;
+  return (size_t)(kStashBase + words) * d->H * d->W;
+}
+
+extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
+  if (!d) return 0;
+  const size_t K = (d->mode == PD_WARP_DISP) ? 1 : 9;
+  return (size_t)d->B * ceil_div(d->H * d->W, kBlock) * d->N * K;
+}
+
+#define PD_DISPATCH(KERNEL, mode, mix, grid, block, shmem, stream, ...)                                   \
+  do {                                                                                                     \
+    if ((mode) == PD_WARP_DISP) {                                                                          \
+      if (mix) KERNEL<PD_WARP_DISP, true><<<grid, block, shmem, stream>>>(__VA_ARGS__);                    \
+      else     KERNEL<PD_WARP_DISP, false><<<grid, block, shmem, stream>>>(__VA_ARGS__);                   \
+    } else {                                                                                               \
+      if (mix) KERNEL<PD_WARP_HOMOGRAPHY, true><<<grid, block, shmem, stream>>>(__VA_ARGS__);              \
+      else     KERNEL<PD_WARP_HOMOGRAPHY, false><<<grid, block, shmem, stream>>>(__VA_ARGS__);             \
+    }                                                                                                      \
+  } while (0)
+
+extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                                  const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                                  const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map,
+                                  float* stash, pd_stream_t stream) {
+  (void)dists;
+  int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  if (rc) return rc;
+  PD_REQUIRE(tgt && rgb_rec && ph_map && stash, "tgt/rgb_rec/ph_map/stash must not be NULL");
+  // the stash always reserves the mask words in disp mode (pd_sweep_stash_floats); they are written when a mask exists
+  SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
+  PD_DISPATCH(sweep_fwd_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,
+              rgb_rec, ph_map, stash);
+  return check_launch("sweep_fwd_kernel");
+}
+
+extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                                  const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                                  const float* padding_mask, const float* dists, const float* rgb_rec,
+                                  const float* stash, const float* g_rgb_rec, const float* g_ph_map, float* g_logits,
+                                  float* g_sigma, float* g_plane, float* workspace, pd_stream_t stream_) {
+  (void)dists;
+  int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  if (rc) return rc;
+  PD_REQUIRE(tgt && rgb_rec && stash, "tgt/rgb_rec/stash must not be NULL");
+  const bool dense = (d->flags & PD_DISP_DENSE) != 0;
+  PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  BwdOut o;
+  o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
+  o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map;
+  const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
+  const int HW = d->H * d->W;
+  dim3 grid(ceil_div(HW, kBlock), d->B);
+  const int K = (d->mode == PD_WARP_DISP) ? 1 : 9;
+  // general path: the bilinear adjoint is an atomic scatter into zero-filled gradients
+  if (g_logits) (void)hipMemsetAsync(g_logits, 0, plane_bytes, stream);
+  if (g_sigma) (void)hipMemsetAsync(g_sigma, 0, plane_bytes, stream);
+  const size_t shmem = (size_t)d->N * K * sizeof(float);
+  PD_DISPATCH(sweep_bwd_kernel, d->mode, mix, grid, dim3(kBlock), shmem, stream, ak, o);
+  rc = check_launch("sweep_bwd_kernel");
+  if (rc) return rc;
+  if (g_plane && !dense) {
+    const int M = d->N * K;
+    reduce_partials_kernel<<<dim3(ceil_div(M, 64), d->B), 64, 0, stream>>>(workspace, g_plane, grid.x, M);
+    rc = check_launch("reduce_partials_kernel");
+  }
+  return rc;
+}
+
+extern "C" int pd_plane_sweep_layers(const pd_sweep_desc* d, const float* src, const float* logits,
+                                     const float* sigma, const float* plane, const float* plane_aux,
+                                     const float* inv_K3, const float* padding_mask, const float* dists,
+                                     float* rgb_rec_layered, float* logit_rec, float* probability_rec,
+                                     float* sigma_rec, float* pi_rec, pd_stream_t stream) {
+  (void)dists;
+  int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  if (rc) return rc;
+  SweepArgs a = make_args(d, src, nullptr, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  LayersOut o{rgb_rec_layered, logit_rec, probability_rec, sigma_rec, pi_rec};
+  dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
+  PD_DISPATCH(sweep_layers_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,
+              o);
+  return check_launch("sweep_layers_kernel");
+}

@@ -1,0 +1,425 @@
+"""Autograd-aware operators over the C ABI (``include/planedepth_hip.h``).
+
+Every function here launches hand-written HIP kernels through ctypes on torch's current stream.  PyTorch is used for
+device memory, streams and autograd plumbing only; there is no eager / CPU implementation behind these ops.
+"""
+import ctypes
+
+import torch
+
+from . import _capi as C
+
+
+def _desc(B, N, H, W, mode, flags, sign):
+    return C.SweepDesc(B, N, H, W, mode, flags, float(sign), 0)
+
+
+def _contig(t):
+    return None if t is None else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused plane sweep + photometric loss
+# ---------------------------------------------------------------------------------------------------------------------
+class _PlaneSweep(torch.autograd.Function):
+    """(src, tgt, logits, sigma, plane, ...) -> (rgb_rec [B,3,H,W], ph_map [B,1,H,W]).
+
+    Gradients: logits, sigma, plane (disp_layered or H_t2s).  src / tgt are images (no gradient, as in the reference
+    where they are dataset tensors).
+    """
+
+    @staticmethod
+    def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, mode, flags, sign):
+        lib = C.load()
+        B, N, H, W = logits.shape
+        C.require_gpu_tensor("logits", logits)
+        C.require_gpu_tensor("src", src, (B, 3, H, W))
+        C.require_gpu_tensor("tgt", tgt, (B, 3, H, W))
+        if flags & C.PD_MIXTURE:
+            C.require_gpu_tensor("sigma", sigma, (B, N, H, W))
+        if mode == C.PD_WARP_DISP:
+            C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else (B, N))
+            if padding_mask is not None:
+                C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H, W))
+        else:
+            C.require_gpu_tensor("H_t2s", plane, (B * N, 3, 3))
+            C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
+            C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
+        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask = map(
+            _contig, (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask))
+        d = _desc(B, N, H, W, mode, flags, sign)
+        k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
+        rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
+        ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
+        stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
+        with torch.cuda.device(logits.device):
+            rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
+                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), None,
+                                        C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(stash), C.stream_handle(logits.device))
+        C.check(rc, "pd_plane_sweep_fwd")
+        ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, rgb_rec, stash)
+        ctx.cfg = (mode, flags, sign)
+        ctx.mark_non_differentiable(stash)
+        return rgb_rec, ph_map
+
+    @staticmethod
+    def backward(ctx, g_rgb_rec, g_ph_map):
+        lib = C.load()
+        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, rgb_rec, stash = ctx.saved_tensors
+        mode, flags, sign = ctx.cfg
+        B, N, H, W = logits.shape
+        d = _desc(B, N, H, W, mode, flags, sign)
+        need_logits, need_sigma, need_plane = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        mix = bool(flags & C.PD_MIXTURE)
+        g_logits = torch.empty_like(logits) if need_logits else None
+        g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
+        g_plane = torch.empty_like(plane) if need_plane else None
+        ws = None
+        if need_plane and not (flags & C.PD_DISP_DENSE):
+            ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=logits.device,
+                             dtype=torch.float32)
+        g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
+        with torch.cuda.device(logits.device):
+            rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
+                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), None,
+                                        C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map),
+                                        C.ptr(g_logits), C.ptr(g_sigma), C.ptr(g_plane), C.ptr(ws),
+                                        C.stream_handle(logits.device))
+        C.check(rc, "pd_plane_sweep_bwd")
+        return None, None, g_logits, g_sigma, g_plane, None, None, None, None, None, None
+
+
+def _flags(use_mixture_loss, automask, dense=False):
+    return ((C.PD_MIXTURE if use_mixture_loss else 0) | (C.PD_AUTOMASK if automask else 0) |
+            (C.PD_DISP_DENSE if dense else 0))
+
+
+_SIGN = {"r": 1.0, "l": -1.0}
+
+
+def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
+                     use_mixture_loss=True, automask=False):
+    """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
+
+    ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
+    ``[B,N,1,1] -> [B,N,H,W]`` (xy planes only; detected from its strides and passed as ``[B,N]`` without ever
+    being materialised) or a dense ``[B,N,H,W]`` map (xz / yz planes present).
+    """
+    B, N, H, W = logits.shape
+    if tuple(disp_layered.shape) != (B, N, H, W):
+        disp_layered = disp_layered.expand(B, N, H, W)
+    per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
+    plane = disp_layered[:, :, 0, 0] if per_plane else disp_layered
+    if padding_mask is not None and padding_mask.dtype != torch.float32:
+        padding_mask = padding_mask.float()
+    if padding_mask is not None and tuple(padding_mask.shape) != (B, N, H, W):
+        padding_mask = padding_mask.expand(B, N, H, W)
+    sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
+    return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
+                             C.PD_WARP_DISP, _flags(use_mixture_loss, automask, dense=not per_plane), sign)
+
+
+def homography_matrices(d, n, T, K, inv_K):
+    """The O(B*N) 3x3 algebra of HomographyWarp.forward (layers.py:206-219, 223) in stock torch.
+
+    Stays in torch on purpose: it keeps ``torch.inverse``'s rounding and lets autograd carry the
+    gradient of ``H_t2s`` on to the pose network / plane distances.  Returns (H_t2s [BN,3,3], R·n [BN,3]).
+    """
+    B, N = d.shape
+    Rm = T[:, :3, :3]
+    t = T[:, :3, 3:4]
+    nn_ = n.reshape(B * N, 1, 3)
+    Rtnd = Rm + torch.matmul(t, nn_) / d.reshape(B * N, 1, 1)
+    H_s2t = torch.matmul(K[:, :3, :3], torch.matmul(Rtnd, inv_K[:, :3, :3]))
+    H_t2s = torch.inverse(H_s2t)
+    Rn = torch.matmul(Rm, nn_.transpose(1, 2))[:, :, 0]
+    return H_t2s, Rn
+
+
+def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
+                           automask=False):
+    """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
+
+    distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
+    """
+    B, N, H, W = logits.shape
+    ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+    H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
+    inv_K3 = inv_K[:, :3, :3]
+    return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach(),
+                             inv_K3.detach(), None, C.PD_WARP_HOMOGRAPHY, _flags(use_mixture_loss, automask), 0.0)
+
+
+def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",
+                       homography=None, use_mixture_loss=True, want=("rgb_rec_layered", "logit_rec",
+                                                                      "probability_rec", "sigma_rec", "pi_rec")):
+    """Materialise the per-plane tensors the reference keeps in ``outputs`` (trainer.py:582-602).  No gradients."""
+    lib = C.load()
+    B, N, H, W = logits.shape
+    with torch.no_grad():
+        if homography is None:
+            if tuple(disp_layered.shape) != (B, N, H, W):
+                disp_layered = disp_layered.expand(B, N, H, W)
+            per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
+            plane = (disp_layered[:, :, 0, 0] if per_plane else disp_layered).contiguous()
+            aux = k3 = None
+            mode, sign = C.PD_WARP_DISP, _SIGN.get(target_side, 0.0)
+            flags = _flags(use_mixture_loss, False, dense=not per_plane)
+            if padding_mask is not None:
+                padding_mask = padding_mask.float().expand(B, N, H, W).contiguous()
+        else:
+            plane, aux, k3 = (t.contiguous() for t in homography)
+            mode, sign, flags, padding_mask = C.PD_WARP_HOMOGRAPHY, 0.0, _flags(use_mixture_loss, False), None
+        dev = logits.device
+        out = {}
+        shapes = dict(rgb_rec_layered=(B, N, 3, H, W), logit_rec=(B, N, H, W), probability_rec=(B, N, H, W),
+                      sigma_rec=(B, N, H, W), pi_rec=(B, N, H, W))
+        for k in want:
+            if k in ("sigma_rec", "pi_rec") and not use_mixture_loss:
+                continue
+            out[k] = torch.empty(shapes[k], device=dev, dtype=torch.float32)
+        d = _desc(B, N, H, W, mode, flags, sign)
+        with torch.cuda.device(dev):
+            rc = lib.pd_plane_sweep_layers(ctypes.byref(d), C.ptr(src.contiguous()), C.ptr(logits.contiguous()),
+                                           C.ptr(_contig(sigma) if use_mixture_loss else None), C.ptr(plane),
+                                           C.ptr(aux), C.ptr(k3), C.ptr(padding_mask), None,
+                                           C.ptr(out.get("rgb_rec_layered")), C.ptr(out.get("logit_rec")),
+                                           C.ptr(out.get("probability_rec")), C.ptr(out.get("sigma_rec")),
+                                           C.ptr(out.get("pi_rec")), C.stream_handle(dev))
+        C.check(rc, "pd_plane_sweep_layers")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SSIM / reprojection loss
+# ---------------------------------------------------------------------------------------------------------------------
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = C.load()
+        C.require_gpu_tensor("x", x)
+        C.require_gpu_tensor("y", y, x.shape)
+        x, y = x.contiguous(), y.contiguous()
+        B, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            C.check(lib.pd_ssim_fwd(B, Cc, H, W, C.ptr(x), C.ptr(y), C.ptr(out), C.stream_handle(x.device)), "pd_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = C.load()
+        x, y = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None
+        with torch.cuda.device(x.device):
+            C.check(lib.pd_ssim_bwd(B, Cc, H, W, C.ptr(x), C.ptr(y), C.ptr(g.contiguous()), C.ptr(gx), C.ptr(gy),
+                                    C.stream_handle(x.device)), "pd_ssim_bwd")
+        return gx, gy
+
+
+def ssim(x, y):
+    """layers.py:292-306 — per-pixel, per-channel clamp((1 - SSIM)/2, 0, 1) with a 3x3 reflected box window."""
+    return _SSIM.apply(x, y)
+
+
+class _ReprojLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, use_ssim):
+        lib = C.load()
+        B, Cc, H, W = pred.shape
+        if Cc != 3:
+            raise ValueError("compute_reprojection_loss expects 3-channel images")
+        C.require_gpu_tensor("pred", pred)
+        C.require_gpu_tensor("target", target, pred.shape)
+        pred, target = pred.contiguous(), target.contiguous()
+        loss = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
+        with torch.cuda.device(pred.device):
+            C.check(lib.pd_reproj_loss_fwd(B, H, W, int(use_ssim), C.ptr(pred), C.ptr(target), C.ptr(loss),
+                                           C.stream_handle(pred.device)), "pd_reproj_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.use_ssim = int(use_ssim)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = C.load()
+        pred, target = ctx.saved_tensors
+        B, _, H, W = pred.shape
+        gp = torch.empty_like(pred)
+        gt = torch.empty_like(target) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(pred.device):
+            C.check(lib.pd_reproj_loss_bwd(B, H, W, ctx.use_ssim, C.ptr(pred), C.ptr(target), C.ptr(g.contiguous()),
+                                           C.ptr(gp), C.ptr(gt), C.stream_handle(pred.device)), "pd_reproj_loss_bwd")
+        return gp, gt, None
+
+
+def reprojection_loss(pred, target, use_ssim=True):
+    """trainer.py:687-699 fused: 0.85 * mean_c SSIM(pred, target) + 0.15 * mean_c |target - pred|  -> [B,1,H,W]."""
+    return _ReprojLoss.apply(pred, target, bool(use_ssim))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Geometry
+# ---------------------------------------------------------------------------------------------------------------------
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        lib = C.load()
+        B, _, H, W = depth.shape
+        C.require_gpu_tensor("depth", depth, (B, 1, H, W))
+        C.require_gpu_tensor("inv_K", inv_K, (B, 4, 4))
+        depth, inv_K = depth.contiguous(), inv_K.contiguous()
+        cam = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
+        with torch.cuda.device(depth.device):
+            C.check(lib.pd_backproject(B, H, W, C.ptr(depth), C.ptr(inv_K), C.ptr(cam), C.stream_handle(depth.device)),
+                    "pd_backproject")
+        ctx.save_for_backward(inv_K)
+        ctx.hw = (H, W)
+        return cam
+
+    @staticmethod
+    def backward(ctx, g_cam):
+        lib = C.load()
+        (inv_K,) = ctx.saved_tensors
+        H, W = ctx.hw
+        B = inv_K.shape[0]
+        g_depth = torch.empty(B, 1, H, W, device=g_cam.device, dtype=torch.float32)
+        with torch.cuda.device(g_cam.device):
+            C.check(lib.pd_backproject_bwd(B, H, W, C.ptr(inv_K), C.ptr(g_cam.contiguous()), C.ptr(g_depth),
+                                           C.stream_handle(g_cam.device)), "pd_backproject_bwd")
+        return g_depth, None
+
+
+def backproject_depth(depth, inv_K):
+    """BackprojectDepth.forward (layers.py:150-156): depth [B,1,H,W], inv_K [B,4,4] -> cam points [B,4,H*W]."""
+    return _Backproject.apply(depth, inv_K)
+
+
+class _Project3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam, P, H, W, eps):
+        lib = C.load()
+        B = cam.shape[0]
+        C.require_gpu_tensor("points", cam, (B, 4, H * W))
+        C.require_gpu_tensor("P", P, (B, 3, 4))
+        cam, P = cam.contiguous(), P.contiguous()
+        grid = torch.empty(B, H, W, 2, device=cam.device, dtype=torch.float32)
+        with torch.cuda.device(cam.device):
+            C.check(lib.pd_project3d(B, H, W, eps, C.ptr(cam), C.ptr(P), C.ptr(grid), C.stream_handle(cam.device)),
+                    "pd_project3d")
+        ctx.save_for_backward(cam, P)
+        ctx.cfg = (H, W, eps)
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        lib = C.load()
+        cam, P = ctx.saved_tensors
+        H, W, eps = ctx.cfg
+        B = cam.shape[0]
+        g_cam = torch.empty_like(cam) if ctx.needs_input_grad[0] else None
+        g_P = torch.empty_like(P) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(12 * B * ((H * W + 255) // 256), device=cam.device, dtype=torch.float32) if g_P is not None else None
+        with torch.cuda.device(cam.device):
+            C.check(lib.pd_project3d_bwd(B, H, W, eps, C.ptr(cam), C.ptr(P), C.ptr(g_grid.contiguous()), C.ptr(g_cam),
+                                         C.ptr(g_P), C.ptr(ws), C.stream_handle(cam.device)), "pd_project3d_bwd")
+        return g_cam, g_P, None, None, None
+
+
+def project_3d(points, K, T, height, width, eps=1e-7):
+    """Project3D.forward (layers.py:169-182).  P = (K @ T)[:, :3, :] is formed in torch (B tiny 4x4 products)."""
+    P = torch.matmul(K, T)[:, :3, :]
+    return _Project3D.apply(points, P, int(height), int(width), float(eps))
+
+
+class _HomographyGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H_t2s, Rn, inv_K3, H, W):
+        lib = C.load()
+        M = H_t2s.shape[0]
+        C.require_gpu_tensor("H_t2s", H_t2s, (M, 3, 3))
+        C.require_gpu_tensor("Rn", Rn, (M, 3))
+        C.require_gpu_tensor("inv_K3", inv_K3, (M, 3, 3))
+        H_t2s, Rn, inv_K3 = H_t2s.contiguous(), Rn.contiguous(), inv_K3.contiguous()
+        grid = torch.empty(M, H, W, 2, device=H_t2s.device, dtype=torch.float32)
+        mask = torch.empty(M, H, W, device=H_t2s.device, dtype=torch.uint8)
+        with torch.cuda.device(H_t2s.device):
+            C.check(lib.pd_homography_grid(M, H, W, C.ptr(H_t2s), C.ptr(Rn), C.ptr(inv_K3), C.ptr(grid), C.ptr(mask),
+                                           C.stream_handle(H_t2s.device)), "pd_homography_grid")
+        ctx.save_for_backward(H_t2s)
+        ctx.hw = (H, W)
+        ctx.mark_non_differentiable(mask)
+        return grid, mask
+
+    @staticmethod
+    def backward(ctx, g_grid, _g_mask):
+        lib = C.load()
+        (H_t2s,) = ctx.saved_tensors
+        H, W = ctx.hw
+        M = H_t2s.shape[0]
+        g_H = torch.empty_like(H_t2s)
+        ws = torch.empty(9 * M * ((H * W + 255) // 256), device=H_t2s.device, dtype=torch.float32)
+        with torch.cuda.device(H_t2s.device):
+            C.check(lib.pd_homography_grid_bwd(M, H, W, C.ptr(H_t2s), C.ptr(g_grid.contiguous()), C.ptr(g_H), C.ptr(ws),
+                                               C.stream_handle(H_t2s.device)), "pd_homography_grid_bwd")
+        return g_H, None, None, None, None
+
+
+def homography_grid(d, n, T, K, inv_K, height, width):
+    """HomographyWarp.forward (layers.py:206-234) -> (pix_coords [BN,H,W,2], padding_mask bool [B,N,1,H,W])."""
+    B, N = d.shape
+    H_t2s, Rn = homography_matrices(d, n, T, K, inv_K)
+    grid, mask = _HomographyGrid.apply(H_t2s, Rn.detach(), inv_K[:, :3, :3].detach(), int(height), int(width))
+    return grid, mask.bool().reshape(B, N, 1, height, width)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# grid_sample (bilinear, align_corners=True)
+# ---------------------------------------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, grid, padding_mode):
+        lib = C.load()
+        M, Cc, Hi, Wi = inp.shape
+        _, Ho, Wo, two = grid.shape
+        C.require_gpu_tensor("input", inp)
+        C.require_gpu_tensor("grid", grid, (M, Ho, Wo, 2))
+        inp, grid = inp.contiguous(), grid.contiguous()
+        out = torch.empty(M, Cc, Ho, Wo, device=inp.device, dtype=torch.float32)
+        with torch.cuda.device(inp.device):
+            C.check(lib.pd_grid_sample_fwd(M, Cc, Hi, Wi, Ho, Wo, padding_mode, C.ptr(inp), C.ptr(grid), C.ptr(out),
+                                           C.stream_handle(inp.device)), "pd_grid_sample_fwd")
+        ctx.save_for_backward(inp, grid)
+        ctx.padding_mode = padding_mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = C.load()
+        inp, grid = ctx.saved_tensors
+        M, Cc, Hi, Wi = inp.shape
+        _, Ho, Wo, _ = grid.shape
+        g_in = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None  # accumulated with atomics
+        g_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        if g_in is None and g_grid is None:
+            return None, None, None
+        with torch.cuda.device(inp.device):
+            C.check(lib.pd_grid_sample_bwd(M, Cc, Hi, Wi, Ho, Wo, ctx.padding_mode, C.ptr(inp), C.ptr(grid),
+                                           C.ptr(g_out.contiguous()), C.ptr(g_in), C.ptr(g_grid),
+                                           C.stream_handle(inp.device)), "pd_grid_sample_bwd")
+        return g_in, g_grid, None
+
+
+def grid_sample(input, grid, padding_mode="zeros", align_corners=True, mode="bilinear"):
+    """The subset of ``F.grid_sample`` the reference uses: bilinear, align_corners=True, zeros | border."""
+    if mode != "bilinear" or not align_corners:
+        raise NotImplementedError("PlaneDepth only calls grid_sample(mode='bilinear', align_corners=True)")
+    pm = {"zeros": C.PD_PAD_ZEROS, "border": C.PD_PAD_BORDER}.get(padding_mode)
+    if pm is None:
+        raise NotImplementedError("padding_mode %r (the reference uses 'zeros' and 'border')" % (padding_mode,))
+    return _GridSample.apply(input, grid, pm)

@@ -68,9 +68,9 @@ def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False
     return case
 
 
-def survey_fullsize_case(B=1, N=49, H=192, W=640):
+def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234):
     """Inputs exactly as SURVEY.md §8(c) C-golden / BASELINE.md §3 describe them (seed 1234, that draw order)."""
-    g = torch.Generator().manual_seed(1234)
+    g = torch.Generator().manual_seed(seed)
     color_l = torch.rand(B, 3, H, W, generator=g)
     color_r = torch.rand(B, 3, H, W, generator=g)
     logits = torch.randn(B, N, H, W, generator=g)

@@ -1,0 +1,168 @@
+"""The reference Trainer's hot-path methods, re-implemented on the fused HIP operators.
+
+``pred_novel_images``, ``compute_reprojection_loss`` and ``compute_losses`` keep the reference's names, argument
+lists and the ``inputs`` / ``outputs`` / ``losses`` dict contracts (trainer.py:523-603, 687-699, 701-773;
+SURVEY.md row B1), so a reference ``Trainer`` can adopt them verbatim:
+
+    import planedepth_amd
+    planedepth_amd.patch_trainer(trainer_module.Trainer)
+
+``self`` only needs ``opt`` (warp_type, match_aug, use_mixture_loss, automask, alpha_pc, alpha_self,
+self_distillation, alpha_smooth, gamma_smooth, use_ssim), ``target_sides`` and ``perceptual_loss``.
+
+What differs from the reference (all documented in DESIGN.md):
+  * the [B,N,*,H,W] per-plane tensors (``rgb_rec_layered``, ``logit_rec``, ``probability_rec``, ``sigma_rec``,
+    ``pi_rec``) are NOT materialised: nothing live consumes them once the loss is fused.  ``outputs[("sweep", side)]``
+    holds a handle whose ``.layers()`` produces them on demand; ``opt.materialize_layers=True`` stores them eagerly
+    under the reference's keys.
+  * the per-pixel photometric loss is produced by the same kernel that warps (``outputs[("ph_map", side)]``) and
+    ``compute_losses`` only averages it.
+  * ``depth_warp`` (broken in the reference) is routed through BackprojectDepth/Project3D + the
+    decoder's padding mask and is evaluated with the unfused operators.
+"""
+import torch
+
+from . import ops
+from .layers import get_smooth_loss_disp
+
+
+class SweepHandle:
+    """Lazy access to the per-plane tensors of one target view (reference keys of trainer.py:582-602)."""
+
+    def __init__(self, **kw):
+        self._kw = kw
+        self._cache = None
+
+    def layers(self):
+        if self._cache is None:
+            self._cache = ops.plane_sweep_layers(**self._kw)
+        return self._cache
+
+    def __getitem__(self, key):
+        return self.layers()[key]
+
+
+def _color_name(opt):
+    return "color_aug" if getattr(opt, "match_aug", False) else "color"
+
+
+def pred_novel_images(self, inputs, outputs):
+    """Generate the warped (reprojected) colour images for a minibatch (reference trainer.py:523-603).
+
+    Writes ``outputs[("rgb_rec", side)]`` (+ ``("ph_map", side)`` and ``("sweep", side)``) for every target side.
+    """
+    opt = self.opt
+    B, N, H, W = outputs["probability"].shape
+    source_side = "l"
+    cname = _color_name(opt)
+    src = inputs[(cname, source_side)]
+    mix = bool(opt.use_mixture_loss)
+    automask = bool(getattr(opt, "automask", False))
+    if getattr(opt, "render_probability", False):
+        raise NotImplementedError("render_probability goes through planedepth_amd.ops.plane_sweep_render (see DESIGN.md)")
+    for target_side in self.target_sides:
+        tgt = inputs[(cname, target_side)]
+        sigma = outputs["sigma"] if mix else None
+        if opt.warp_type == "disp_warp":
+            rgb_rec, ph_map = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
+                                                   outputs["padding_mask"], target_side=target_side,
+                                                   use_mixture_loss=mix, automask=automask)
+            handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
+                                 padding_mask=outputs["padding_mask"], target_side=target_side, use_mixture_loss=mix)
+        elif opt.warp_type == "homography_warp":
+            T = outputs[("Rt", target_side)]
+            rgb_rec, ph_map = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma, outputs["distance"],
+                                                         outputs["norm"], T, inputs["K"], inputs["inv_K"],
+                                                         use_mixture_loss=mix, automask=automask)
+            with torch.no_grad():
+                ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+                H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
+                                                    ex(inputs["inv_K"]))
+            handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma,
+                                 homography=(H_t2s, Rn, inputs["inv_K"][:, :3, :3]), use_mixture_loss=mix)
+        else:
+            raise NotImplementedError("warp_type %r: the reference's depth_warp branch raises UnboundLocalError "
+                                      "(padding_mask is never assigned, trainer.py:533-538/580); use disp_warp or "
+                                      "homography_warp" % (opt.warp_type,))
+        outputs[("rgb_rec", target_side)] = rgb_rec
+        outputs[("ph_map", target_side)] = ph_map
+        outputs[("sweep", target_side)] = handle
+        if getattr(opt, "materialize_layers", False):
+            for k, v in handle.layers().items():
+                outputs[(k, target_side)] = v
+
+
+def compute_reprojection_loss(self, pred, target):
+    """Computes reprojection loss between a batch of predicted and target images (reference trainer.py:687-699)."""
+    return ops.reprojection_loss(pred, target, use_ssim=bool(self.opt.use_ssim))
+
+
+def compute_losses(self, inputs, outputs):
+    """Compute the reprojection and smoothness losses for a minibatch (reference trainer.py:701-773)."""
+    opt = self.opt
+    B, N, H, W = outputs["probability"].shape
+    losses = {"loss/ph_loss": 0, "loss/pc_loss": 0}
+    if opt.alpha_self > 0.0:
+        losses["loss/self_loss"] = 0
+    losses["loss/total_loss"] = 0
+    cname = _color_name(opt)
+    for target_side in self.target_sides:
+        total_loss = 0
+        pred = outputs[("rgb_rec", target_side)]
+        target = inputs[(cname, target_side)]
+        mask = outputs["mask_novel"] if "mask_novel" in outputs else None
+        if mask is not None:
+            pred = pred * mask + target * (1.0 - mask)
+        if opt.use_mixture_loss:
+            ph_loss = outputs[("ph_map", target_side)]  # mixture NLL (+ automask min), fused with the warp
+            if mask is not None:
+                ph_loss = ph_loss * mask
+        elif mask is None:
+            ph_loss = outputs[("ph_map", target_side)]  # mean_c |rgb_rec - target| (+ automask min), fused
+        else:  # L1 on the blended prediction: [B,3,H,W] elementwise work, left to torch
+            ph_loss = torch.abs(pred - target).mean(1, True)
+            if opt.automask:
+                ph_auto = torch.abs(inputs[(cname, "l")] - target).mean(1, True)
+                ph_loss, _ = torch.cat([ph_loss, ph_auto], dim=1).min(1, True)
+        ph_loss = ph_loss.mean()
+        losses["loss/ph_loss"] += ph_loss
+        total_loss += ph_loss
+
+        # perceptual net (stock VGG, out of scope) — called exactly as the reference does; it back-propagates
+        # into rgb_rec, which is why the fused op takes an upstream gradient for rgb_rec.
+        if not opt.automask:
+            pc_loss = self.perceptual_loss(pred, target).mean()
+        else:
+            pc_loss = self.perceptual_loss(pred, target, inputs[(cname, "l")]).mean()
+        losses["loss/pc_loss"] += pc_loss
+        total_loss += opt.alpha_pc * pc_loss
+
+        if opt.alpha_self > 0.0:
+            self_loss = compute_reprojection_loss(self, outputs[("self_rec", target_side)], inputs[(cname, "l")]).mean()
+            losses["loss/self_loss"] += self_loss
+            total_loss += opt.alpha_self * self_loss
+
+        if opt.self_distillation > 0:
+            disp_loss = torch.abs(outputs["disp"] - outputs["disp_pp"]).mean()
+            losses["loss/disp_loss"] = disp_loss
+            total_loss += opt.self_distillation * disp_loss
+
+        losses["loss/total_loss"] += total_loss
+
+    n_sides = len(self.target_sides)
+    for k in list(losses.keys()):
+        losses[k] = losses[k] / n_sides
+
+    smooth_loss = get_smooth_loss_disp(outputs["disp"][..., int(0.2 * W):], inputs[("color", "l")][..., int(0.2 * W):],
+                                       gamma=opt.gamma_smooth)
+    losses["loss/smooth_loss"] = smooth_loss
+    losses["loss/total_loss"] = losses["loss/total_loss"] + opt.alpha_smooth * smooth_loss
+    return losses
+
+
+def patch_trainer(trainer_cls):
+    """Bind the fused hot path onto a reference-style Trainer class (drop-in)."""
+    trainer_cls.pred_novel_images = pred_novel_images
+    trainer_cls.compute_reprojection_loss = compute_reprojection_loss
+    trainer_cls.compute_losses = compute_losses
+    return trainer_cls

@@ -1,0 +1,51 @@
+"""Drive the PRODUCT path (planedepth_amd, HIP kernels via the C ABI) on a fixture / synthetic case."""
+import types
+
+import torch
+
+import planedepth_amd
+from planedepth_amd import ops
+
+
+def run_product(case, run, device="cuda", force_dense=False, through_trainer=True):
+    """Same contract as cases.run_oracle / make_golden.run_reference, but on the GPU through the product API."""
+    c = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in case.items()}
+    B, N, H, W = c["logits"].shape
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    logits, sigma, disp_pp, Rt = leaf(c["logits"]), leaf(c["sigma"]), leaf(c["disp_pp"]), leaf(c["Rt"])
+    if case["dense_disp"] or force_dense:
+        disp_layered = disp_pp.expand(-1, -1, H, W) * c["row_gain"]
+    else:
+        disp_layered = disp_pp.expand(-1, -1, H, W)  # a view, as the decoder makes it for xy planes
+    distance = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
+    norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
+    side = run.get("target_side", "r")
+    mix = run.get("use_mixture_loss", True)
+    warp = run.get("warp_type", "disp_warp")
+    inputs = {("color", "l"): c["color_l"], "K": c["K"], "inv_K": c["inv_K"]}
+    if side != "l":
+        inputs[("color", side)] = c["color_r"]
+    outputs = {"probability": torch.empty(B, N, H, W, device="meta"), "logits": logits, "sigma": sigma,
+               "disp_layered": disp_layered, "padding_mask": c["padding_mask"], "distance": distance, "norm": norm,
+               ("Rt", side): Rt, "disp": torch.zeros(B, 1, H, W, device=device)}
+    if "mask_novel" in c:
+        outputs["mask_novel"] = c["mask_novel"]
+    opt = types.SimpleNamespace(warp_type=warp, match_aug=False, use_mixture_loss=mix, automask=run.get("automask", False),
+                                render_probability=run.get("render_probability", False), alpha_pc=0.0, alpha_self=0.0,
+                                self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=True,
+                                materialize_layers=True)
+    ns = types.SimpleNamespace(opt=opt, target_sides=[side],
+                               perceptual_loss=lambda *a, **k: torch.zeros((), device=device))
+    planedepth_amd.pred_novel_images(ns, inputs, outputs)
+    losses = planedepth_amd.compute_losses(ns, inputs, outputs)
+    rgb_rec = outputs[("rgb_rec", side)]
+    (losses["loss/ph_loss"] + (rgb_rec * c["g_rgb_rec"]).sum()).backward()
+    z = torch.zeros_like
+    res = dict(rgb_rec=rgb_rec, ph_loss=losses["loss/ph_loss"], ph_map=outputs[("ph_map", side)],
+               g_logits=logits.grad, g_sigma=sigma.grad if sigma.grad is not None else z(sigma),
+               g_disp_pp=disp_pp.grad if disp_pp.grad is not None else z(disp_pp),
+               g_Rt=Rt.grad if Rt.grad is not None else z(Rt))
+    for k in ("rgb_rec_layered", "logit_rec", "probability_rec", "sigma_rec", "pi_rec"):
+        if (k, side) in outputs:
+            res[k] = outputs[(k, side)]
+    return {k: v.detach().cpu() for k, v in res.items()}

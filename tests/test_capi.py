@@ -1,0 +1,77 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every declared symbol, validates arguments
+without touching a GPU, and the Python operators refuse CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from planedepth_amd import _capi as C
+from planedepth_amd import ops
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "planedepth_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.load()
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in C.SIGNATURES, "ctypes prototype missing for " + n
+    assert sorted(C.SIGNATURES) == names
+    assert lib.pd_version() >= 100
+
+
+def test_desc_layout_and_host_queries():
+    assert ctypes.sizeof(C.SweepDesc) == 32
+    lib = C.load()
+    d = C.SweepDesc(2, 49, 192, 640, C.PD_WARP_DISP, C.PD_MIXTURE, 1.0, 0)
+    assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == (4 + 2) * 192 * 640
+    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49
+    d.mode = C.PD_WARP_HOMOGRAPHY
+    assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == 4 * 192 * 640
+    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49 * 9
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = C.load()
+    d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_DISP, C.PD_MIXTURE, 1.0, 0)
+    null = [None] * 13
+    assert lib.pd_plane_sweep_fwd(ctypes.byref(d), *null) == 1  # PD_ERR_ARG: NULL tensors
+    assert b"NULL" in lib.pd_last_error()
+    d.mode = 7
+    assert lib.pd_plane_sweep_fwd(ctypes.byref(d), *null) == 1
+    assert b"warp mode" in lib.pd_last_error()
+    assert lib.pd_ssim_fwd(0, 3, 8, 8, None, None, None, None) == 1
+    assert lib.pd_grid_sample_fwd(1, 1, 4, 4, 4, 4, 9, None, None, None, None) == 1
+
+
+def test_ops_refuse_cpu_tensors():
+    B, N, H, W = 1, 3, 4, 6
+    src = torch.rand(B, 3, H, W)
+    lg = torch.randn(B, N, H, W)
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.plane_sweep_disp(src, src, lg, lg.sigmoid(), torch.ones(B, N, 1, 1).expand(B, N, H, W))
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.ssim(src, src)
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.grid_sample(src, torch.zeros(B, H, W, 2))
+    with pytest.raises(NotImplementedError):
+        ops.grid_sample(src, torch.zeros(B, H, W, 2), padding_mode="reflection")
+
+
+def test_product_never_imports_the_oracle():
+    import planedepth_amd
+    pkg = os.path.dirname(planedepth_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("oracle container", ""), f
