@@ -49,12 +49,16 @@ enum pd_sweep_flags {
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
 
+/* Kernel selection.  The row-shift kernels apply to PD_WARP_DISP with per-plane scalar disparities; the general
+ * kernels handle everything (and are the cross-check for the specialised ones in the tests). */
+enum pd_sweep_impl { PD_IMPL_AUTO = 0, PD_IMPL_GENERAL = 1 };
+
 typedef struct pd_sweep_desc {
   int32_t B, N, H, W;
   int32_t mode;  /* pd_warp_mode */
   int32_t flags; /* OR of pd_sweep_flags */
   float sign;    /* PD_WARP_DISP: +1 for target "r" (x + d), -1 for target "l" (x - d), 0 = grid untouched */
-  int32_t reserved;
+  int32_t impl;  /* pd_sweep_impl: 0 = pick the fastest applicable kernels, 1 = force the general (atomic) kernels */
 } pd_sweep_desc;
 
 int pd_version(void);

@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libplanedepth_hip.so")
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE = 1, 2, 4, 8
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
+PD_IMPL_AUTO, PD_IMPL_GENERAL = 0, 1
 
 
 class SweepDesc(ctypes.Structure):
     """Mirror of ``pd_sweep_desc``."""
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
                 ("mode", ctypes.c_int32), ("flags", ctypes.c_int32), ("sign", ctypes.c_float),
-                ("reserved", ctypes.c_int32)]
+                ("impl", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p

@@ -100,9 +100,24 @@ __device__ __forceinline__ void bilinear_scatter(float* __restrict__ p, const Ta
 
 // Pixel -> normalised [-1,1] -> pixel, with the reference's exact op order (trainer.py:550-552 then grid_sample's
 // un-normalisation).  The round trip is NOT the identity in fp32, so it is reproduced, not skipped.
+// fp contraction is OFF here: fusing (a - 0.5) * 2 into fma(a, 2, -1) or (g + 1) * 0.5 into fma(g, 0.5, 0.5) changes
+// the coordinate by an ulp, which is visible in the weights of taps that are almost out of view.
+__device__ __forceinline__ float normalise(float px, float size_m1) {
+#pragma clang fp contract(off)
+  const float q = px / size_m1;
+  const float h = q - 0.5f;
+  return h * 2.0f;
+}
+
+__device__ __forceinline__ float unnormalise(float g, float size_m1) {
+#pragma clang fp contract(off)
+  const float s = g + 1.0f;
+  const float h = s * 0.5f;
+  return h * size_m1;
+}
+
 __device__ __forceinline__ float normalise_roundtrip(float px, float size_m1) {
-  const float g = (px / size_m1 - 0.5f) * 2.0f;
-  return (g + 1.0f) * 0.5f * size_m1;
+  return unnormalise(normalise(px, size_m1), size_m1);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void project3d_kernel(int H, int W, float e
   const float p1 = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7] * Wh;
   const float z = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11] * Wh + eps;
   float2 o;
-  o.x = ((p0 / z) / (float)(W - 1) - 0.5f) * 2.0f;
-  o.y = ((p1 / z) / (float)(H - 1) - 0.5f) * 2.0f;
+  o.x = normalise(p0 / z, (float)(W - 1));
+  o.y = normalise(p1 / z, (float)(H - 1));
   reinterpret_cast<float2*>(grid)[(long)b * HW + pix] = o;
 }
 
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kBlock) void homography_grid_kernel(int H, int W, c
                        (Ki[6] * fx + Ki[7] * fy + Ki[8]) * rn[2];
   const float zc = (z < 1e-7f) ? 1e-7f : z;
   float2 o;
-  o.x = ((p0 / zc) / (float)(W - 1) - 0.5f) * 2.0f;
-  o.y = ((p1 / zc) / (float)(H - 1) - 0.5f) * 2.0f;
+  o.x = normalise(p0 / zc, (float)(W - 1));
+  o.y = normalise(p1 / zc, (float)(H - 1));
   reinterpret_cast<float2*>(grid)[(long)m * HW + pix] = o;
   if (mask) mask[(long)m * HW + pix] = (facing > 0.0f && z > 1e-7f) ? 1 : 0;
 }

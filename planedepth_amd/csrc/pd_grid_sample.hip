@@ -21,7 +21,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample_fwd_kernel(int C, int Hi, 
   if (pix >= HWo) return;
   const int m = blockIdx.y;
   const float2 g = reinterpret_cast<const float2*>(grid)[(long)m * HWo + pix];
-  float ix = (g.x + 1.0f) * 0.5f * (float)(Wi - 1), iy = (g.y + 1.0f) * 0.5f * (float)(Hi - 1);
+  float ix = unnormalise(g.x, (float)(Wi - 1)), iy = unnormalise(g.y, (float)(Hi - 1));
   if (border) {
     float dm;
     ix = clip_coord(ix, (float)(Wi - 1), dm);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample_bwd_kernel(int C, int Hi, 
   const int m = blockIdx.y;
   const float2 g = reinterpret_cast<const float2*>(grid)[(long)m * HWo + pix];
   float mx = (float)(Wi - 1) / 2, my = (float)(Hi - 1) / 2;
-  float ix = (g.x + 1.0f) * 0.5f * (float)(Wi - 1), iy = (g.y + 1.0f) * 0.5f * (float)(Hi - 1);
+  float ix = unnormalise(g.x, (float)(Wi - 1)), iy = unnormalise(g.y, (float)(Hi - 1));
   if (border) {
     float dmx, dmy;
     ix = clip_coord(ix, (float)(Wi - 1), dmx);

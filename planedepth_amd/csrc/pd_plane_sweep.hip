@@ -13,28 +13,9 @@
 //                         block-reduced plane-parameter gradient partials
 //   reduce_partials_kernel  deterministic second stage for the plane-parameter gradient
 //   sweep_layers_kernel   optional materialisation of the per-plane tensors the reference stores in `outputs`
-#include "pd_common.h"
+#include "pd_sweep.h"
 
 namespace pd {
-
-constexpr int kStashBase = 4;  // lse, S, Mx, flags
-constexpr float kSigmaMin = 0.01f, kSigmaMax = 1.0f, kLogEps = 1e-7f, kZMin = 1e-7f;
-
-struct SweepArgs {
-  int B, N, H, W;
-  int flags;
-  float sign;
-  int stash_k;     // floats per pixel in the stash: kStashBase + ceil(N/32) mask words in disp mode
-  int has_mask;    // disp mode with a padding_mask tensor: mask bits live in the stash words
-  const float* src;
-  const float* tgt;
-  const float* logits;
-  const float* sigma;
-  const float* plane;
-  const float* plane_aux;
-  const float* inv_K3;
-  const float* padding_mask;
-};
 
 // ---------------------------------------------------------------------------------------------------------------
 // Sampling position of target pixel (x,y) on plane n of image b, plus the padding mask.
@@ -110,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
     ea = (fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2)) / 3.0f;
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
 
-  float m_run = -INFINITY, Z = 0.0f, S = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Mx = 0.0f, Ma = 0.0f;
+  FwdAcc acc;
   uint32_t bits = 0;
   for (int n = 0; n < a.N; ++n) {
     bool mk;
@@ -133,70 +114,23 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
       c1 = bilinear(srcb + HW, t, a.W);
       c2 = bilinear(srcb + 2 * HW, t, a.W);
     }
-    // online softmax over planes (trainer.py:593): rescale the running sums when the max moves
-    if (l > m_run) {
-      const float sc = fast_exp(m_run - l);
-      Z *= sc; S *= sc; C0 *= sc; C1 *= sc; C2 *= sc; Mx *= sc; Ma *= sc;
-      m_run = l;
-    }
-    const float p = fast_exp(l - m_run);
-    Z += p;
-    if (MIX) {
-      const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);  // trainer.py:597
-      const float inv = 1.0f / sg;
-      const float u = p * inv;                                 // pi / sigma  (trainer.py:600)
-      S += u;
-      C0 += c0 * u; C1 += c1 * u; C2 += c2 * u;
-      const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;  // trainer.py:729
-      Mx += u * (0.5f * fast_exp(-e * inv));                                      // pi * laplacian(e; sigma)
-      if (automask) Ma += u * (0.5f * fast_exp(-ea * inv));
-    } else {
-      C0 += c0 * p; C1 += c1 * p; C2 += c2 * p;
-    }
+    fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
   }
-  const float invZ = 1.0f / Z;
-  float r0, r1, r2, ph, sel = 0.0f;
+  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
   float* st = stash + (long)b * a.stash_k * HW + pix;
-  if (MIX) {
-    const float invS = 1.0f / S;
-    r0 = C0 * invS; r1 = C1 * invS; r2 = C2 * invS;
-    const float mx = Mx * invZ;
-    ph = -__logf(mx + kLogEps);  // layers.py:466
-    if (automask) {
-      const float pa = -__logf(Ma * invZ + kLogEps);
-      if (pa < ph) { ph = pa; sel = 1.0f; }  // torch.min over cat([ph, ph_auto]) keeps the first on ties
-    }
-    st[HW] = S * invZ;
-    st[2 * HW] = mx;
-  } else {
-    r0 = C0 * invZ; r1 = C1 * invZ; r2 = C2 * invZ;
-    ph = (fabsf(r0 - t0) + fabsf(r1 - t1) + fabsf(r2 - t2)) / 3.0f;  // trainer.py:738
-    if (automask && ea < ph) { ph = ea; sel = 1.0f; }
-    st[HW] = 0.0f;
-    st[2 * HW] = 0.0f;
-  }
-  st[0] = m_run + __logf(Z);
-  st[3 * HW] = sel;
-  rgb_rec[((long)b * 3 + 0) * HW + pix] = r0;
-  rgb_rec[((long)b * 3 + 1) * HW + pix] = r1;
-  rgb_rec[((long)b * 3 + 2) * HW + pix] = r2;
-  ph_map[(long)b * HW + pix] = ph;
+  st[0] = r.lse;
+  st[HW] = r.Sn;
+  st[2 * HW] = r.mx;
+  st[3 * HW] = r.sel;
+  rgb_rec[((long)b * 3 + 0) * HW + pix] = r.r0;
+  rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
+  rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
+  ph_map[(long)b * HW + pix] = r.ph;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward (general: any warp, atomics for the bilinear adjoint)
 // ---------------------------------------------------------------------------------------------------------------
-struct BwdOut {
-  float* g_logits;
-  float* g_sigma;
-  float* g_plane;    // dense disp: written directly; otherwise via partials
-  float* partials;   // [B][nblk][N*K]  (K = 1 disp, 9 homography)
-  const float* rgb_rec;
-  const float* stash;
-  const float* g_rgb_rec;
-  const float* g_ph_map;
-};
-
 template <int MODE, bool MIX>
 __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float red[];  // [N*K] block accumulators of the plane-parameter gradient
@@ -217,35 +151,8 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
   const float* srcb = a.src + (long)b * 3 * HW;
   const int SK = a.stash_k;
 
-  float t0 = 0, t1 = 0, t2 = 0, lse = 0, Sn = 1, mx = 1, gp = 0, gr0 = 0, gr1 = 0, gr2 = 0, r0 = 0, r1 = 0, r2 = 0;
-  if (active) {
-    t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
-    t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
-    t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
-    const float* st = o.stash + (long)b * SK * HW + pix;
-    lse = st[0];
-    Sn = st[HW];
-    mx = st[2 * HW];
-    const float sel = st[3 * HW];
-    gp = (o.g_ph_map && sel == 0.0f) ? o.g_ph_map[(long)b * HW + pix] : 0.0f;
-    r0 = o.rgb_rec[((long)b * 3 + 0) * HW + pix];
-    r1 = o.rgb_rec[((long)b * 3 + 1) * HW + pix];
-    r2 = o.rgb_rec[((long)b * 3 + 2) * HW + pix];
-    if (o.g_rgb_rec) {
-      gr0 = o.g_rgb_rec[((long)b * 3 + 0) * HW + pix];
-      gr1 = o.g_rgb_rec[((long)b * 3 + 1) * HW + pix];
-      gr2 = o.g_rgb_rec[((long)b * 3 + 2) * HW + pix];
-    }
-    if (!MIX) {  // L1 branch: ph = mean_c |rgb_rec - tgt| feeds straight into the rgb_rec gradient
-      gr0 += gp * sgn(r0 - t0) / 3.0f;
-      gr1 += gp * sgn(r1 - t1) / 3.0f;
-      gr2 += gp * sgn(r2 - t2) / 3.0f;
-    }
-  }
+  const PixelCtx c = active ? make_pixel_ctx<MIX>(a, o, b, pix, HW) : zero_pixel_ctx();
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
-  const float A = MIX ? gp / (mx + kLogEps) : 0.0f;   // -d ph / d Mx  (layers.py:466)
-  const float invS = MIX ? 1.0f / Sn : 1.0f;
-  const float gdotr = gr0 * r0 + gr1 * r1 + gr2 * r2;
   const float halfWm1 = (float)(a.W - 1) / 2, halfHm1 = (float)(a.H - 1) / 2;
 
   uint32_t bits = 0;
@@ -269,30 +176,10 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
         const float c0 = bilinear_vg(srcb, t, a.W, d0x, d0y);
         const float c1 = bilinear_vg(srcb + HW, t, a.W, d1x, d1y);
         const float c2 = bilinear_vg(srcb + 2 * HW, t, a.W, d2x, d2y);
-        const float p = fast_exp(l - lse);  // pi_n
-        float g_l, g_s = 0.0f, gc0, gc1, gc2;
-        if (MIX) {
-          const float s = bilinear_vg(a.sigma + pl, t, a.W, dsx, dsy);
-          const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
-          const float inv = 1.0f / sg;
-          const float u = p * inv;
-          const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;
-          const float q = 0.5f * fast_exp(-e * inv) * inv;                        // laplacian(e; sigma)
-          const float gu = (gr0 * c0 + gr1 * c1 + gr2 * c2 - gdotr) * invS;       // d(rgb_rec . g)/d u_n
-          const float g_pi = -A * q + gu * inv;
-          g_l = p * (g_pi + A * mx);                                              // softmax backward, closed form
-          const float g_sig = -A * p * q * (e * inv * inv - inv) - gu * u * inv;  // d/d sigma_n
-          g_s = (s >= kSigmaMin && s <= kSigmaMax) ? g_sig : 0.0f;                // clamp passes grad on [min,max]
-          const float g_e = A * u * q;                                            // d ph / d e_n  (u*q = pi*q/sigma)
-          const float w = u * invS;
-          gc0 = gr0 * w + g_e * sgn(c0 - t0) / 3.0f;
-          gc1 = gr1 * w + g_e * sgn(c1 - t1) / 3.0f;
-          gc2 = gr2 * w + g_e * sgn(c2 - t2) / 3.0f;
-          if (o.g_sigma) bilinear_scatter(o.g_sigma + pl, t, a.W, g_s);
-        } else {
-          g_l = p * (gr0 * c0 + gr1 * c1 + gr2 * c2 - gdotr);
-          gc0 = gr0 * p; gc1 = gr1 * p; gc2 = gr2 * p;
-        }
+        const float s = MIX ? bilinear_vg(a.sigma + pl, t, a.W, dsx, dsy) : 0.0f;
+        const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+        const float g_l = pg.g_l, g_s = pg.g_s, gc0 = pg.gc0, gc1 = pg.gc1, gc2 = pg.gc2;
+        if (MIX && o.g_sigma) bilinear_scatter(o.g_sigma + pl, t, a.W, g_s);
         if (o.g_logits) bilinear_scatter(o.g_logits + pl, t, a.W, g_l);
         if (want_plane) {
           // d loss / d (ix, iy) in pixels, then back through grid_sample's un-normalisation ((size-1)/2) and the
@@ -333,13 +220,12 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
 
 // partials [B][nblk][M] -> out [B][M], summed in a fixed order (deterministic)
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblk, int M) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
-  if (j >= M) return;
+  const int j = blockIdx.x, b = blockIdx.y;  // one wave per output element; lanes stride over the blocks
   const float* p = partials + (long)b * nblk * M + j;
   float acc = 0.0f;
-  for (int i = 0; i < nblk; ++i) acc += p[(long)i * M];
-  out[(long)b * M + j] = acc;
+  for (int i = threadIdx.x; i < nblk; i += kWave) acc += p[(long)i * M];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[(long)b * M + j] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -464,7 +350,9 @@ extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
 extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   if (!d) return 0;
   const size_t K = (d->mode == PD_WARP_DISP) ? 1 : 9;
-  return (size_t)d->B * ceil_div(d->H * d->W, kBlock) * d->N * K;
+  const size_t general = (size_t)d->B * ceil_div(d->H * d->W, kBlock) * d->N * K;
+  const size_t rows = rowshift_applicable(d) ? rowshift_bwd_workspace_floats(d) : 0;
+  return general > rows ? general : rows;
 }
 
 #define PD_DISPATCH(KERNEL, mode, mix, grid, block, shmem, stream, ...)                                   \
@@ -488,6 +376,8 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(tgt && rgb_rec && ph_map && stash, "tgt/rgb_rec/ph_map/stash must not be NULL");
   // the stash always reserves the mask words in disp mode (pd_sweep_stash_floats); they are written when a mask exists
   SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d))
+    return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
   PD_DISPATCH(sweep_fwd_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,
               rgb_rec, ph_map, stash);
@@ -511,6 +401,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map;
+  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) return rowshift_bwd(d, ak, o, stream);
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;
   dim3 grid(ceil_div(HW, kBlock), d->B);
@@ -524,7 +415,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   if (rc) return rc;
   if (g_plane && !dense) {
     const int M = d->N * K;
-    reduce_partials_kernel<<<dim3(ceil_div(M, 64), d->B), 64, 0, stream>>>(workspace, g_plane, grid.x, M);
+    reduce_partials_kernel<<<dim3(M, d->B), kWave, 0, stream>>>(workspace, g_plane, grid.x, M);
     rc = check_launch("reduce_partials_kernel");
   }
   return rc;

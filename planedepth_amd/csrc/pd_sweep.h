@@ -1,0 +1,190 @@
+// Shared definitions of the plane-sweep kernels: argument blocks, per-pixel / per-plane math.
+// The math follows reference trainer.py:580-603 (mask, softmax over planes, sigma clamp, mixture weights, composite)
+// and trainer.py:728-742 + layers.py:454-466 (Laplacian-mixture NLL, automask min); the closed-form backward is
+// derived in DESIGN.md §"Backward".
+#pragma once
+#include "pd_common.h"
+
+namespace pd {
+
+constexpr int kStashBase = 4;  // lse, S, Mx, flags  (then ceil(N/32) mask words in disp mode)
+constexpr float kSigmaMin = 0.01f, kSigmaMax = 1.0f, kLogEps = 1e-7f, kZMin = 1e-7f;
+
+struct SweepArgs {
+  int B, N, H, W;
+  int flags;
+  float sign;
+  int stash_k;   // floats per pixel in the stash: kStashBase + ceil(N/32) mask words in disp mode
+  int has_mask;  // disp mode with a padding_mask tensor: mask bits live in the stash words
+  const float* src;
+  const float* tgt;
+  const float* logits;
+  const float* sigma;
+  const float* plane;
+  const float* plane_aux;
+  const float* inv_K3;
+  const float* padding_mask;
+};
+
+struct BwdOut {
+  float* g_logits;
+  float* g_sigma;
+  float* g_plane;   // dense disp: written directly; otherwise via partials
+  float* partials;  // per-block partial sums of the plane-parameter gradient
+  const float* rgb_rec;
+  const float* stash;
+  const float* g_rgb_rec;
+  const float* g_ph_map;
+};
+
+// ---- forward: online softmax / mixture accumulators of ONE target pixel over the planes ---------------------------
+struct FwdAcc {
+  float m = -INFINITY, Z = 0.0f, S = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Mx = 0.0f, Ma = 0.0f;
+};
+
+// One plane's (masked) samples l, s, c* enter the running sums.  t* = target colour, ea = identity-reprojection error.
+template <bool MIX>
+__device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, float c0, float c1, float c2, float t0,
+                                               float t1, float t2, float ea, bool automask) {
+  if (l > a.m) {  // online softmax (trainer.py:593): rescale the running sums when the max moves
+    const float sc = fast_exp(a.m - l);
+    a.Z *= sc; a.S *= sc; a.C0 *= sc; a.C1 *= sc; a.C2 *= sc; a.Mx *= sc; a.Ma *= sc;
+    a.m = l;
+  }
+  const float p = fast_exp(l - a.m);
+  a.Z += p;
+  if (MIX) {
+    const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);  // trainer.py:597
+    const float inv = 1.0f / sg;
+    const float u = p * inv;                                 // pi / sigma (trainer.py:600)
+    a.S += u;
+    a.C0 += c0 * u; a.C1 += c1 * u; a.C2 += c2 * u;
+    const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;  // trainer.py:729
+    a.Mx += u * (0.5f * fast_exp(-e * inv));                                    // pi * laplacian(e; sigma)
+    if (automask) a.Ma += u * (0.5f * fast_exp(-ea * inv));
+  } else {
+    a.C0 += c0 * p; a.C1 += c1 * p; a.C2 += c2 * p;
+  }
+}
+
+struct FwdResult {
+  float r0, r1, r2, ph;
+  float lse, Sn, mx, sel;  // stash
+};
+
+template <bool MIX>
+__device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float t1, float t2, float ea,
+                                                bool automask) {
+  FwdResult r;
+  const float invZ = 1.0f / a.Z;
+  r.sel = 0.0f;
+  if (MIX) {
+    const float invS = 1.0f / a.S;
+    r.r0 = a.C0 * invS; r.r1 = a.C1 * invS; r.r2 = a.C2 * invS;
+    r.mx = a.Mx * invZ;
+    r.Sn = a.S * invZ;
+    r.ph = -__logf(r.mx + kLogEps);  // layers.py:466
+    if (automask) {
+      const float pa = -__logf(a.Ma * invZ + kLogEps);
+      if (pa < r.ph) { r.ph = pa; r.sel = 1.0f; }  // torch.min over cat([ph, ph_auto]) keeps the first on ties
+    }
+  } else {
+    r.r0 = a.C0 * invZ; r.r1 = a.C1 * invZ; r.r2 = a.C2 * invZ;
+    r.mx = 0.0f;
+    r.Sn = 0.0f;
+    r.ph = (fabsf(r.r0 - t0) + fabsf(r.r1 - t1) + fabsf(r.r2 - t2)) / 3.0f;  // trainer.py:738
+    if (automask && ea < r.ph) { r.ph = ea; r.sel = 1.0f; }
+  }
+  r.lse = a.m + __logf(a.Z);
+  return r;
+}
+
+// ---- backward: per-target-pixel context and per-plane gradients w.r.t. the SAMPLED features -----------------------
+struct PixelCtx {
+  float t0, t1, t2;     // target colour
+  float lse;            // log-sum-exp of the sampled logits
+  float invS, mx, A;    // mixture: 1 / sum(pi/sigma), sum(pi*lap), g_ph / (mx + 1e-7)
+  float gr0, gr1, gr2;  // upstream gradient of rgb_rec (+ the L1 photometric term when !MIX)
+  float gdotr;          // gr . rgb_rec
+};
+
+template <bool MIX>
+__device__ __forceinline__ PixelCtx make_pixel_ctx(const SweepArgs& a, const BwdOut& o, int b, int pix, int HW) {
+  PixelCtx c;
+  c.t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+  c.t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+  c.t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+  const float* st = o.stash + (long)b * a.stash_k * HW + pix;
+  c.lse = st[0];
+  const float Sn = st[HW];
+  c.mx = st[2 * HW];
+  const float sel = st[3 * HW];
+  const float gp = (o.g_ph_map && sel == 0.0f) ? o.g_ph_map[(long)b * HW + pix] : 0.0f;
+  const float r0 = o.rgb_rec[((long)b * 3 + 0) * HW + pix];
+  const float r1 = o.rgb_rec[((long)b * 3 + 1) * HW + pix];
+  const float r2 = o.rgb_rec[((long)b * 3 + 2) * HW + pix];
+  c.gr0 = c.gr1 = c.gr2 = 0.0f;
+  if (o.g_rgb_rec) {
+    c.gr0 = o.g_rgb_rec[((long)b * 3 + 0) * HW + pix];
+    c.gr1 = o.g_rgb_rec[((long)b * 3 + 1) * HW + pix];
+    c.gr2 = o.g_rgb_rec[((long)b * 3 + 2) * HW + pix];
+  }
+  if (!MIX) {  // L1 branch: ph = mean_c |rgb_rec - tgt| feeds straight into the rgb_rec gradient
+    c.gr0 += gp * sgn(r0 - c.t0) / 3.0f;
+    c.gr1 += gp * sgn(r1 - c.t1) / 3.0f;
+    c.gr2 += gp * sgn(r2 - c.t2) / 3.0f;
+  }
+  c.A = MIX ? gp / (c.mx + kLogEps) : 0.0f;  // -d ph / d Mx (layers.py:466)
+  c.invS = MIX ? 1.0f / Sn : 1.0f;
+  c.gdotr = c.gr0 * r0 + c.gr1 * r1 + c.gr2 * r2;
+  return c;
+}
+
+__device__ __forceinline__ PixelCtx zero_pixel_ctx() {
+  PixelCtx c;
+  c.t0 = c.t1 = c.t2 = c.lse = 0.0f;
+  c.invS = 1.0f; c.mx = 1.0f; c.A = 0.0f;
+  c.gr0 = c.gr1 = c.gr2 = c.gdotr = 0.0f;
+  return c;
+}
+
+struct PlaneGrad {
+  float g_l, g_s, gc0, gc1, gc2;  // d loss / d sampled (logit, sigma, r, g, b) of this plane at this target pixel
+};
+
+template <bool MIX>
+__device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, float s, float c0, float c1, float c2) {
+  PlaneGrad g;
+  const float p = fast_exp(l - c.lse);  // pi_n
+  if (MIX) {
+    const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
+    const float inv = 1.0f / sg;
+    const float u = p * inv;
+    const float e = (fabsf(c0 - c.t0) + fabsf(c1 - c.t1) + fabsf(c2 - c.t2)) / 3.0f;
+    const float q = 0.5f * fast_exp(-e * inv) * inv;                                  // laplacian(e; sigma)
+    const float gu = (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr) * c.invS;       // d (g . rgb_rec) / d u_n
+    const float g_pi = -c.A * q + gu * inv;
+    g.g_l = p * (g_pi + c.A * c.mx);                                                  // softmax backward, closed form
+    const float g_sig = -c.A * p * q * (e * inv * inv - inv) - gu * u * inv;          // d / d sigma_n
+    g.g_s = (s >= kSigmaMin && s <= kSigmaMax) ? g_sig : 0.0f;                        // clamp: grad on [min,max]
+    const float g_e = c.A * u * q;                                                    // d ph / d e_n
+    const float w = u * c.invS;
+    g.gc0 = c.gr0 * w + g_e * sgn(c0 - c.t0) / 3.0f;
+    g.gc1 = c.gr1 * w + g_e * sgn(c1 - c.t1) / 3.0f;
+    g.gc2 = c.gr2 * w + g_e * sgn(c2 - c.t2) / 3.0f;
+  } else {
+    g.g_l = p * (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr);
+    g.g_s = 0.0f;
+    g.gc0 = c.gr0 * p; g.gc1 = c.gr1 * p; g.gc2 = c.gr2 * p;
+  }
+  return g;
+}
+
+// Row-shift specialisation (pd_plane_sweep_rowshift.hip): disp mode, per-plane scalar disparities.
+bool rowshift_applicable(const pd_sweep_desc* d);
+int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
+                 hipStream_t stream);
+int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
+size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d);
+
+}  // namespace pd

@@ -10,8 +10,13 @@ import torch
 from . import _capi as C
 
 
+# Kernel selection for the sweep (C.PD_IMPL_AUTO | C.PD_IMPL_GENERAL).  Tests flip it to cross-check the specialised
+# row-shift kernels against the general ones; leave it alone otherwise.
+SWEEP_IMPL = C.PD_IMPL_AUTO
+
+
 def _desc(B, N, H, W, mode, flags, sign):
-    return C.SweepDesc(B, N, H, W, mode, flags, float(sign), 0)
+    return C.SweepDesc(B, N, H, W, mode, flags, float(sign), SWEEP_IMPL)
 
 
 def _contig(t):
@@ -97,6 +102,23 @@ def _flags(use_mixture_loss, automask, dense=False):
 _SIGN = {"r": 1.0, "l": -1.0}
 
 
+def _per_plane_view(disp_layered):
+    """[B,N] view of an H/W-expanded disparity tensor, taken from the tensor it was expanded FROM when possible.
+
+    ``disp_layered[:, :, 0, 0]`` would be correct but makes autograd materialise a zero [B,N,H,W] gradient and then
+    reduce it again (ExpandBackward): ~0.1 ms per step of pure overhead at 8x49x192x640.  When the view's base is the
+    decoder's [B,N,1,1] tensor (networks/depth_decoder.py:153-156) the gradient is handed to that tensor directly.
+    """
+    B, N = disp_layered.shape[:2]
+    base = disp_layered._base
+    if (base is not None and base.dim() == 4 and tuple(base.shape) == (B, N, 1, 1)
+            and base.storage_offset() == disp_layered.storage_offset()
+            and base.stride()[:2] == disp_layered.stride()[:2]
+            and base.requires_grad == disp_layered.requires_grad):
+        return base.reshape(B, N)
+    return disp_layered[:, :, 0, 0]
+
+
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
                      use_mixture_loss=True, automask=False):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
@@ -109,7 +131,7 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     if tuple(disp_layered.shape) != (B, N, H, W):
         disp_layered = disp_layered.expand(B, N, H, W)
     per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
-    plane = disp_layered[:, :, 0, 0] if per_plane else disp_layered
+    plane = _per_plane_view(disp_layered) if per_plane else disp_layered
     if padding_mask is not None and padding_mask.dtype != torch.float32:
         padding_mask = padding_mask.float()
     if padding_mask is not None and tuple(padding_mask.shape) != (B, N, H, W):

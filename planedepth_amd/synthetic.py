@@ -37,13 +37,15 @@ def small_pose(gen, B, rot=0.01, trans=0.05, stereo=False):
 
 
 def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False, special_disp=None,
-               stereo_T=True, with_mask_novel=False, render_probability=False):
+               stereo_T=True, with_mask_novel=False, render_probability=False, sigma_interior=False):
     """Synthetic decoder outputs + dataset inputs in the reference's dict format."""
     g = torch.Generator().manual_seed(seed)
     color_l = torch.rand(B, 3, H, W, generator=g)
     color_r = torch.rand(B, 3, H, W, generator=g)
     logits = torch.randn(B, N, H, W, generator=g)
     sigma = torch.rand(B, N, H, W, generator=g).clamp(0.01, 1.0)
+    if sigma_interior:  # keep sigma strictly inside the clamp range: no knife-edge clamp gradients (DESIGN.md §parity)
+        sigma = 0.011 + 0.978 * sigma
     res = torch.rand(B, N, 1, 1, generator=g) - 0.5
     level = torch.arange(N, dtype=torch.float32)[None, :, None, None] + res
     disp_pp = disp_max * (disp_min / disp_max) ** (level / (N - 1))  # [B,N,1,1], the learnable per-plane disparity
@@ -68,13 +70,15 @@ def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False
     return case
 
 
-def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234):
+def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=False):
     """Inputs exactly as SURVEY.md §8(c) C-golden / BASELINE.md §3 describe them (seed 1234, that draw order)."""
     g = torch.Generator().manual_seed(seed)
     color_l = torch.rand(B, 3, H, W, generator=g)
     color_r = torch.rand(B, 3, H, W, generator=g)
     logits = torch.randn(B, N, H, W, generator=g)
     sigma = torch.rand(B, N, H, W, generator=g).clamp(0.01, 1.0)
+    if sigma_interior:
+        sigma = 0.011 + 0.978 * sigma
     res = torch.rand(B, N, 1, 1, generator=g) - 0.5
     disp_pp = 300.0 * (2.0 / 300.0) ** ((torch.arange(N, dtype=torch.float32)[None, :, None, None] + res) / (N - 1))
     K, inv_K = intrinsics(B, H, W)
