@@ -86,9 +86,8 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
   const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
   const float t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
   const float t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
-  float ea = 0.0f;  // identity-reprojection error mean_c |src - tgt| (trainer.py:732 / 740)
-  if (automask)
-    ea = (fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2)) / 3.0f;
+  float ea = 0.0f;  // 3 x identity-reprojection error: sum_c |src - tgt| (trainer.py:732 / 740)
+  if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
 
   FwdAcc acc;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
   }
   const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
   float* st = stash + (long)b * a.stash_k * HW + pix;
-  st[0] = r.lse;
+  st[0] = r.lse2;
   st[HW] = r.Sn;
   st[2 * HW] = r.mx;
   st[3 * HW] = r.sel;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
   // pass 1: softmax statistics; pass 2: write
   float m_run = -INFINITY, Z = 0.0f, S = 0.0f;
   for (int pass = 0; pass < 2; ++pass) {
-    const float lse = (pass == 1) ? m_run + __logf(Z) : 0.0f;
+    const float lse2 = (pass == 1) ? m_run + log2_fast(Z) : 0.0f;
     const float invSn = (pass == 1 && MIX) ? Z / S : 0.0f;
     for (int n = 0; n < a.N; ++n) {
       bool mk;
@@ -271,17 +270,18 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
         }
       }
       const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
+      const float l2 = l * kLog2e;
       if (pass == 0) {
-        if (l > m_run) {
-          const float sc = fast_exp(m_run - l);
+        if (l2 > m_run) {
+          const float sc = exp2_fast(m_run - l2);
           Z *= sc; S *= sc;
-          m_run = l;
+          m_run = l2;
         }
-        const float p = fast_exp(l - m_run);
+        const float p = exp2_fast(l2 - m_run);
         Z += p;
         if (MIX) S += p / sg;
       } else {
-        const float pi = fast_exp(l - lse);
+        const float pi = exp2_fast(l2 - lse2);
         if (o.rgb_rec_layered) {
           float* q = o.rgb_rec_layered + ((long)b * a.N + n) * 3 * HW + pix;
           q[0] = c0; q[HW] = c1; q[2 * HW] = c2;

@@ -58,10 +58,11 @@ __device__ __forceinline__ RowSel make_row_sel(int y, int H) {
   return r;
 }
 
-struct ColTap {   // horizontal footprint of one target pixel on one plane
-  int x0;
-  float wx0, wx1;
-  bool v0, v1;
+struct ColTap {    // horizontal footprint of one target pixel on one plane
+  int x0;           // floor(ix), clamped to [-2, W] (only meaningful when v0 || v1)
+  unsigned i0, i1;  // x0 and x0+1 if inside the image, else 0: always safe to load
+  float m0, m1;     // torch's weights (x1 - ix), (ix - x0) with out-of-image taps zeroed (padding_mode="zeros")
+  bool v0, v1;      // tap inside the image
 };
 
 // Correctly rounded a / b from the correctly rounded reciprocal of b (Markstein's theorem; b = W-1 is an integer
@@ -90,11 +91,14 @@ __device__ __forceinline__ ColTap make_col_tap(float px, float Wm1, float rcpWm1
     ix = unnormalise(g, Wm1);                               // grid_sample un-normalisation, align_corners=True
   }
   const float xf = floorf(ix);
-  t.wx0 = (xf + 1.0f) - ix;
-  t.wx1 = ix - xf;
-  t.v0 = (xf >= 0.0f) && (xf <= Wm1);
-  t.v1 = (xf + 1.0f >= 0.0f) && (xf + 1.0f <= Wm1);
-  t.x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W);
+  const float wx0 = (xf + 1.0f) - ix, wx1 = ix - xf;
+  t.x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W);            // NaN / huge coordinates end up outside
+  t.v0 = (unsigned)t.x0 < (unsigned)W;
+  t.v1 = (unsigned)(t.x0 + 1) < (unsigned)W;
+  t.i0 = t.v0 ? (unsigned)t.x0 : 0u;
+  t.i1 = t.v1 ? (unsigned)(t.x0 + 1) : 0u;
+  t.m0 = t.v0 ? wx0 : 0.0f;
+  t.m1 = t.v1 ? wx1 : 0.0f;
   return t;
 }
 
@@ -104,33 +108,34 @@ struct Taps {
   float a0, a1, b0, b1;  // row A (x0, x0+1), row B (x0, x0+1)
 };
 
+// Loads are UNCONDITIONAL (clamped indices off a workgroup-uniform row pointer): no exec-mask branches, so the compiler
+// can issue a whole group's loads back to back.  Out-of-image taps are cancelled by the zeroed weights m0/m1.
 template <int NROWS>
-__device__ __forceinline__ Taps<NROWS> load_taps(const float* __restrict__ plane, const RowSel& r, const ColTap& c,
-                                                 int W) {
+__device__ __forceinline__ Taps<NROWS> load_taps(const float* __restrict__ rowA, const float* __restrict__ rowB,
+                                                 const ColTap& c) {
   Taps<NROWS> t;
-  const float* q = plane + (long)r.yA * W + c.x0;
-  t.a0 = c.v0 ? q[0] : 0.0f;
-  t.a1 = c.v1 ? q[1] : 0.0f;
+  t.a0 = rowA[c.i0];
+  t.a1 = rowA[c.i1];
   t.b0 = t.b1 = 0.0f;
   if (NROWS == 2) {
-    const float* p = plane + (long)r.yB * W + c.x0;
-    t.b0 = c.v0 ? p[0] : 0.0f;
-    t.b1 = c.v1 ? p[1] : 0.0f;
+    t.b0 = rowB[c.i0];
+    t.b1 = rowB[c.i1];
   }
   return t;
 }
 
 template <int NROWS>
 __device__ __forceinline__ float tap_value(const Taps<NROWS>& t, const RowSel& r, const ColTap& c) {
-  float v = t.a0 * (c.wx0 * r.wA) + t.a1 * (c.wx1 * r.wA);
-  if (NROWS == 2) v += t.b0 * (c.wx0 * r.wB) + t.b1 * (c.wx1 * r.wB);
+  float v = t.a0 * (c.m0 * r.wA) + t.a1 * (c.m1 * r.wA);
+  if (NROWS == 2) v += t.b0 * (c.m0 * r.wB) + t.b1 * (c.m1 * r.wB);
   return v;
 }
 
+// d value / d ix: (ne - nw) * wy with out-of-image taps reading as zero
 template <int NROWS>
-__device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r) {
-  float d = (t.a1 - t.a0) * r.wA;
-  if (NROWS == 2) d += (t.b1 - t.b0) * r.wB;
+__device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r, const ColTap& c) {
+  float d = ((c.v1 ? t.a1 : 0.0f) - (c.v0 ? t.a0 : 0.0f)) * r.wA;
+  if (NROWS == 2) d += ((c.v1 ? t.b1 : 0.0f) - (c.v0 ? t.b0 : 0.0f)) * r.wB;
   return d;
 }
 
@@ -138,16 +143,14 @@ __device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r) {
 template <int NROWS>
 __device__ __forceinline__ void colour_taps(const float4* __restrict__ lrgb, int W, const RowSel& r, const ColTap& c,
                                             float& c0, float& c1, float& c2) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int i0 = min(max(c.x0, 0), W - 1), i1 = min(max(c.x0 + 1, 0), W - 1);
-  const float4 nw = c.v0 ? lrgb[i0] : z, ne = c.v1 ? lrgb[i1] : z;
-  const float w0 = c.wx0 * r.wA, w1 = c.wx1 * r.wA;
+  const float4 nw = lrgb[c.i0], ne = lrgb[c.i1];
+  const float w0 = c.m0 * r.wA, w1 = c.m1 * r.wA;
   c0 = nw.x * w0 + ne.x * w1;
   c1 = nw.y * w0 + ne.y * w1;
   c2 = nw.z * w0 + ne.z * w1;
   if (NROWS == 2) {
-    const float4 sw = c.v0 ? lrgb[W + i0] : z, se = c.v1 ? lrgb[W + i1] : z;
-    const float u0 = c.wx0 * r.wB, u1 = c.wx1 * r.wB;
+    const float4 sw = lrgb[W + c.i0], se = lrgb[W + c.i1];
+    const float u0 = c.m0 * r.wB, u1 = c.m1 * r.wB;
     c0 += sw.x * u0 + se.x * u1;
     c1 += sw.y * u0 + se.y * u1;
     c2 += sw.z * u0 + se.z * u1;
@@ -158,25 +161,25 @@ template <int NROWS>
 __device__ __forceinline__ void colour_taps_dx(const float4* __restrict__ lrgb, int W, const RowSel& r,
                                                const ColTap& c, float& c0, float& c1, float& c2, float& d0, float& d1,
                                                float& d2) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int i0 = min(max(c.x0, 0), W - 1), i1 = min(max(c.x0 + 1, 0), W - 1);
-  const float4 nw = c.v0 ? lrgb[i0] : z, ne = c.v1 ? lrgb[i1] : z;
-  const float w0 = c.wx0 * r.wA, w1 = c.wx1 * r.wA;
+  const float4 nw = lrgb[c.i0], ne = lrgb[c.i1];
+  const float w0 = c.m0 * r.wA, w1 = c.m1 * r.wA;
+  const float z0 = c.v0 ? r.wA : 0.0f, z1 = c.v1 ? r.wA : 0.0f;
   c0 = nw.x * w0 + ne.x * w1;
   c1 = nw.y * w0 + ne.y * w1;
   c2 = nw.z * w0 + ne.z * w1;
-  d0 = (ne.x - nw.x) * r.wA;
-  d1 = (ne.y - nw.y) * r.wA;
-  d2 = (ne.z - nw.z) * r.wA;
+  d0 = ne.x * z1 - nw.x * z0;
+  d1 = ne.y * z1 - nw.y * z0;
+  d2 = ne.z * z1 - nw.z * z0;
   if (NROWS == 2) {
-    const float4 sw = c.v0 ? lrgb[W + i0] : z, se = c.v1 ? lrgb[W + i1] : z;
-    const float u0 = c.wx0 * r.wB, u1 = c.wx1 * r.wB;
+    const float4 sw = lrgb[W + c.i0], se = lrgb[W + c.i1];
+    const float u0 = c.m0 * r.wB, u1 = c.m1 * r.wB;
+    const float y0 = c.v0 ? r.wB : 0.0f, y1 = c.v1 ? r.wB : 0.0f;
     c0 += sw.x * u0 + se.x * u1;
     c1 += sw.y * u0 + se.y * u1;
     c2 += sw.z * u0 + se.z * u1;
-    d0 += (se.x - sw.x) * r.wB;
-    d1 += (se.y - sw.y) * r.wB;
-    d2 += (se.z - sw.z) * r.wB;
+    d0 += se.x * y1 - sw.x * y0;
+    d1 += se.y * y1 - sw.y * y0;
+    d2 += se.z * y1 - sw.z * y0;
   }
 }
 
@@ -197,47 +200,49 @@ __device__ __forceinline__ void stage_colour_rows(float4* __restrict__ lrgb, con
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MIX, int NROWS, int U>
+// LDS layout shared by both kernels: float4 colour[2*W] | float sdisp[N] (= sign * disparity of each plane) | ...
+template <bool MIX, bool HASMASK, int NROWS, int U>
 __device__ __forceinline__ void fwd_group(const SweepArgs& a, const RowSel& row, const float4* __restrict__ lrgb,
-                                          int b, int n0, int x, int pix, int HW, float Wm1, float rcpWm1, float t0,
-                                          float t1, float t2, float ea, bool automask, FwdAcc& acc, uint32_t& bits,
-                                          float* __restrict__ stash) {
+                                          const float* __restrict__ sdisp, int b, int n0, int x, int pix, int HW,
+                                          float Wm1, float rcpWm1, float t0, float t1, float t2, float ea,
+                                          bool automask, FwdAcc& acc, uint32_t& bits, float* __restrict__ stash) {
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
   float mval[U];
-  const float* dplane = a.plane + (long)b * a.N;
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // issue every global load of the group before the first use
     const int n = n0 + u;
-    const long pl = ((long)b * a.N + n) * HW;
-    ct[u] = make_col_tap((float)x + a.sign * dplane[n], Wm1, rcpWm1, a.W);
-    mval[u] = a.has_mask ? a.padding_mask[pl + pix] : 1.0f;
-    tl[u] = load_taps<NROWS>(a.logits + pl, row, ct[u], a.W);
-    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl, row, ct[u], a.W);
+    const long pl = ((long)b * a.N + n) * HW;               // workgroup-uniform
+    const float* lA = a.logits + pl + (long)row.yA * a.W;   // uniform row pointers: scalar base + 32-bit lane offset
+    const float* lB = a.logits + pl + (long)row.yB * a.W;
+    ct[u] = make_col_tap((float)x + sdisp[n], Wm1, rcpWm1, a.W);
+    mval[u] = HASMASK ? (a.padding_mask + pl)[(unsigned)pix] : 1.0f;
+    tl[u] = load_taps<NROWS>(lA, lB, ct[u]);
+    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl + (long)row.yA * a.W, a.sigma + pl + (long)row.yB * a.W, ct[u]);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
-    const bool mk = mval[u] != 0.0f;
-    if (a.has_mask) {
+    if (HASMASK) {  // rec_features * padding_mask (trainer.py:580): a masked plane samples as all-zero features,
+      const bool mk = mval[u] != 0.0f;  // i.e. every tap weight of the plane is zero
       if (mk) bits |= 1u << (n & 31);
       if ((n & 31) == 31 || n == a.N - 1) {
         stash[((long)b * a.stash_k + kStashBase + (n >> 5)) * HW + pix] = __uint_as_float(bits);
         bits = 0;
       }
+      ct[u].m0 = mk ? ct[u].m0 : 0.0f;
+      ct[u].m1 = mk ? ct[u].m1 : 0.0f;
     }
-    float l = 0.0f, s = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    if (mk) {  // rec_features * padding_mask (trainer.py:580)
-      l = tap_value<NROWS>(tl[u], row, ct[u]);
-      if (MIX) s = tap_value<NROWS>(ts[u], row, ct[u]);
-      colour_taps<NROWS>(lrgb, a.W, row, ct[u], c0, c1, c2);
-    }
+    const float l = tap_value<NROWS>(tl[u], row, ct[u]);
+    const float s = MIX ? tap_value<NROWS>(ts[u], row, ct[u]) : 0.0f;
+    float c0, c1, c2;
+    colour_taps<NROWS>(lrgb, a.W, row, ct[u], c0, c1, c2);
     fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
   }
 }
 
-template <bool MIX, int NROWS>
-__device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb,
+template <bool MIX, bool HASMASK, int NROWS>
+__device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
                                                   float* __restrict__ rgb_rec, float* __restrict__ ph_map,
                                                   float* __restrict__ stash) {
   constexpr int U = (NROWS == 1) ? 4 : 2;
@@ -247,25 +252,27 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
   const float Wm1 = (float)(a.W - 1), rcpWm1 = refined_rcp(Wm1);
   const float* srcb = a.src + (long)b * 3 * HW;
   stage_colour_rows<NROWS>(lrgb, srcb, HW, a.W, row);
+  for (int i = threadIdx.x; i < a.N; i += blockDim.x) sdisp[i] = a.sign * a.plane[(long)b * a.N + i];
   __syncthreads();
   for (int x = threadIdx.x; x < a.W; x += blockDim.x) {
     const int pix = y * a.W + x;
     const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
     const float t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
     const float t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
-    float ea = 0.0f;
-    if (automask)
-      ea = (fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2)) / 3.0f;
+    float ea = 0.0f;  // 3 x identity-reprojection error
+    if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
     FwdAcc acc;
     uint32_t bits = 0;
     int n = 0;
     for (; n + U <= a.N; n += U)
-      fwd_group<MIX, NROWS, U>(a, row, lrgb, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask, acc, bits, stash);
+      fwd_group<MIX, HASMASK, NROWS, U>(a, row, lrgb, sdisp, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask,
+                                         acc, bits, stash);
     for (; n < a.N; ++n)
-      fwd_group<MIX, NROWS, 1>(a, row, lrgb, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask, acc, bits, stash);
+      fwd_group<MIX, HASMASK, NROWS, 1>(a, row, lrgb, sdisp, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask,
+                                         acc, bits, stash);
     const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
     float* st = stash + (long)b * a.stash_k * HW + pix;
-    st[0] = r.lse;
+    st[0] = r.lse2;
     st[HW] = r.Sn;
     st[2 * HW] = r.mx;
     st[3 * HW] = r.sel;
@@ -276,14 +283,15 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
   }
 }
 
-template <bool MIX>
+template <bool MIX, bool HASMASK>
 __global__ __launch_bounds__(kMaxRowThreads) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
                                                                      float* __restrict__ stash) {
   extern __shared__ float4 lds4[];
+  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * a.W);
   const RowSel row = make_row_sel(blockIdx.x, a.H);
-  if (row.nrows == 2) rowshift_fwd_body<MIX, 2>(a, row, lds4, rgb_rec, ph_map, stash);
-  else                rowshift_fwd_body<MIX, 1>(a, row, lds4, rgb_rec, ph_map, stash);
+  if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, 2>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
+  else                rowshift_fwd_body<MIX, HASMASK, 1>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -335,26 +343,24 @@ struct SegCtx {
   bool active;
 };
 
-template <bool MIX, int NROWS, int U>
+template <bool MIX, bool HASMASK, int NROWS, int U>
 __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, const RowSel& row,
-                                          const float4* __restrict__ lrgb, float* __restrict__ red,
-                                          float* __restrict__ bnd, int b, int y, int n0, const SegCtx& sc,
-                                          const PixelCtx& c, int HW, float Wm1, float rcpWm1, float gix_scale,
-                                          bool want_plane, uint32_t& bits) {
+                                          const float4* __restrict__ lrgb, const float* __restrict__ sdisp,
+                                          float* __restrict__ red, float* __restrict__ bnd, int b, int y, int n0,
+                                          const SegCtx& sc, const PixelCtx& c, int HW, float Wm1, float rcpWm1,
+                                          float gix_scale, bool want_plane, uint32_t& bits) {
   const int W = a.W, N = a.N;
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
   float sd[U];
-  const float* dplane = a.plane + (long)b * N;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
     const long pl = ((long)b * N + n) * HW;
-    sd[u] = a.sign * dplane[n];
+    sd[u] = sdisp[n];
     ct[u] = make_col_tap((float)sc.xt + sd[u], Wm1, rcpWm1, W);
-    if (!sc.active) ct[u].v0 = ct[u].v1 = false;
-    tl[u] = load_taps<NROWS>(a.logits + pl, row, ct[u], W);
-    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl, row, ct[u], W);
+    tl[u] = load_taps<NROWS>(a.logits + pl + (long)row.yA * W, a.logits + pl + (long)row.yB * W, ct[u]);
+    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl + (long)row.yA * W, a.sigma + pl + (long)row.yB * W, ct[u]);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -362,43 +368,39 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
     const long pl = ((long)b * N + n) * HW;
     const int k = (int)fminf(fmaxf(floorf(sd[u]), -(float)W), (float)W);  // nominal shift, |k| <= W
     bool mk = sc.active;
-    if (a.has_mask) {
-      if ((n & 31) == 0 && sc.active)
-        bits = __float_as_uint(o.stash[((long)b * a.stash_k + kStashBase + (n >> 5)) * HW + sc.pix]);
+    if (HASMASK) {
+      if ((n & 31) == 0)
+        bits = __float_as_uint((o.stash + ((long)b * a.stash_k + kStashBase + (n >> 5)) * HW)[(unsigned)sc.pix]);
       mk = sc.active && ((bits >> (n & 31)) & 1u);
     }
-    float cl0 = 0.0f, cl1 = 0.0f, cs0 = 0.0f, cs1 = 0.0f, gd = 0.0f;
-    int dl = 0;
-    if (mk) {
-      const ColTap& t = ct[u];
-      float c0, c1, c2, d0x, d1x, d2x;
-      colour_taps_dx<NROWS>(lrgb, W, row, t, c0, c1, c2, d0x, d1x, d2x);
-      const float l = tap_value<NROWS>(tl[u], row, t);
-      const float s = MIX ? tap_value<NROWS>(ts[u], row, t) : 0.0f;
-      const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
-      if (t.v0 || t.v1) dl = t.x0 - sc.xt - k;
-      const float gl = pg.g_l * row.wy_main, gs = pg.g_s * row.wy_main;
-      cl0 = t.v0 ? gl * t.wx0 : 0.0f;
-      cl1 = t.v1 ? gl * t.wx1 : 0.0f;
-      cs0 = t.v0 ? gs * t.wx0 : 0.0f;
-      cs1 = t.v1 ? gs * t.wx1 : 0.0f;
-      if (want_plane) {
-        const float dlx = tap_dx<NROWS>(tl[u], row);
-        const float dsx = MIX ? tap_dx<NROWS>(ts[u], row) : 0.0f;
-        gd = (pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x) * gix_scale;
-      }
+    const ColTap& t = ct[u];
+    float c0, c1, c2, d0x, d1x, d2x;
+    colour_taps_dx<NROWS>(lrgb, W, row, t, c0, c1, c2, d0x, d1x, d2x);
+    float l = tap_value<NROWS>(tl[u], row, t);
+    float s = MIX ? tap_value<NROWS>(ts[u], row, t) : 0.0f;
+    const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    const float live = mk ? row.wy_main : 0.0f;   // padding mask x vertical adjoint weight of the own row
+    const int dl = (mk && (t.v0 || t.v1)) ? t.x0 - sc.xt - k : 0;
+    const float gl = pg.g_l * live, gs = pg.g_s * live;
+    const float cl0 = gl * t.m0, cl1 = gl * t.m1, cs0 = gs * t.m0, cs1 = gs * t.m1;
+    float gd = 0.0f;
+    if (want_plane) {
+      const float dlx = tap_dx<NROWS>(tl[u], row, t);
+      const float dsx = MIX ? tap_dx<NROWS>(ts[u], row, t) : 0.0f;
+      gd = (pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x) * gix_scale;
+      gd = mk ? gd : 0.0f;
     }
     const bool regular = __all(dl == 0);
     int xs = sc.xt + k;                       // the source pixel this slot owns (ring of W slots)
     xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
     Bnd bl, bs;
     const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bl);
-    if (sc.active && o.g_logits) o.g_logits[pl + (long)y * W + xs] = out_l;
+    if (sc.active && o.g_logits) (o.g_logits + pl + (long)y * W)[(unsigned)xs] = out_l;
     float* bp = bnd + ((long)sc.seg * N + n) * 6;
     if (sc.lane == 0) { bp[0] = bl.left; bp[1] = bl.right0; bp[2] = bl.right1; }
     if (MIX) {
       const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bs);
-      if (sc.active && o.g_sigma) o.g_sigma[pl + (long)y * W + xs] = out_s;
+      if (sc.active && o.g_sigma) (o.g_sigma + pl + (long)y * W)[(unsigned)xs] = out_s;
       if (sc.lane == 0) { bp[3] = bs.left; bp[4] = bs.right0; bp[5] = bs.right1; }
     }
     if (want_plane) {
@@ -408,9 +410,9 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
   }
 }
 
-template <bool MIX, int NROWS>
-__device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, float* red,
-                                                  float* bnd, float4* lrgb) {
+template <bool MIX, bool HASMASK, int NROWS>
+__device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
+                                                  float* sdisp, float* red, float* bnd, float4* lrgb) {
   constexpr int U = (NROWS == 1) ? 2 : 1;
   const int y = blockIdx.x, b = blockIdx.y;
   const int HW = a.H * a.W, W = a.W, N = a.N;
@@ -418,7 +420,10 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const int nseg = (W + kWave - 1) / kWave;
   const bool want_plane = (o.g_plane != nullptr);
   const float* srcb = a.src + (long)b * 3 * HW;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) red[i] = 0.0f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    red[i] = 0.0f;
+    sdisp[i] = a.sign * a.plane[(long)b * N + i];
+  }
   stage_colour_rows<NROWS>(lrgb, srcb, HW, W, row);
   __syncthreads();
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
@@ -437,15 +442,16 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     uint32_t bits = 0;
     int n = 0;
     for (; n + U <= N; n += U)
-      bwd_group<MIX, NROWS, U>(a, o, row, lrgb, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale, want_plane, bits);
+      bwd_group<MIX, HASMASK, NROWS, U>(a, o, row, lrgb, sdisp, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
+                                         want_plane, bits);
     for (; n < N; ++n)
-      bwd_group<MIX, NROWS, 1>(a, o, row, lrgb, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale, want_plane, bits);
+      bwd_group<MIX, HASMASK, NROWS, 1>(a, o, row, lrgb, sdisp, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
+                                         want_plane, bits);
   }
   __syncthreads();
   // Deferred segment-boundary contributions: record (seg, n, j) targets global slot g (ring), i.e. source (g+k) mod W.
   const int ntens = MIX ? 2 : 1;
   const int nrec = nseg * N * 3 * ntens;
-  const float* dplane = a.plane + (long)b * N;
   for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
     const int j = i % 3, tns = (i / 3) % ntens, n = (i / (3 * ntens)) % N, seg = i / (3 * ntens * N);
     const float v = bnd[((long)seg * N + n) * 6 + tns * 3 + j];
@@ -455,8 +461,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     const int T0 = seg * kWave, last = min(kWave - 1, W - 1 - T0);
     int g = (j == 0) ? T0 - 1 : T0 + last + j;   // j=1 -> last+1, j=2 -> last+2
     g = ((g % W) + W) % W;
-    const float sd = a.sign * dplane[n];
-    const int k = (int)fminf(fmaxf(floorf(sd), -(float)W), (float)W);
+    const int k = (int)fminf(fmaxf(floorf(sdisp[n]), -(float)W), (float)W);
     int xs = g + k;
     xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
     unsafeAtomicAdd(dst + ((long)b * N + n) * HW + (long)y * W + xs, v);
@@ -467,15 +472,16 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   }
 }
 
-template <bool MIX>
+template <bool MIX, bool HASMASK>
 __global__ __launch_bounds__(kMaxRowThreads) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
-  // LDS: colour rows float4[2*W] | red[N] | bnd[nseg][N][6]  (6 = {left,right0,right1} x {logits, sigma})
-  float* red = reinterpret_cast<float*>(lds4 + 2 * a.W);
+  // LDS: colour rows float4[2*W] | sdisp[N] | red[N] | bnd[nseg][N][6]  (6 = {left,right0,right1} x {logits, sigma})
+  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * a.W);
+  float* red = sdisp + a.N;
   float* bnd = red + a.N;
   const RowSel row = make_row_sel(blockIdx.x, a.H);
-  if (row.nrows == 2) rowshift_bwd_body<MIX, 2>(a, o, row, red, bnd, lds4);
-  else                rowshift_bwd_body<MIX, 1>(a, o, row, red, bnd, lds4);
+  if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, red, bnd, lds4);
+  else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, red, bnd, lds4);
 }
 
 // partials [B][R][M] -> out [B][M]; one wave per (b, j): lanes stride over R, then wave-reduce.  Deterministic.
@@ -514,7 +520,7 @@ static int row_threads(int W) {
 
 bool rowshift_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
-         (size_t)d->W * 32 + ((size_t)d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
+         (size_t)d->W * 32 + ((size_t)2 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
 }
 
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
@@ -525,31 +531,31 @@ static void allow_lds(K kernel, size_t shmem) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 }
 
+#define PD_ROW_DISPATCH(KERNEL, mix, hasmask, grid, block, shmem, stream, ...)                 \
+  do {                                                                                          \
+    if (mix) {                                                                                  \
+      if (hasmask) { allow_lds(KERNEL<true, true>, shmem);  KERNEL<true, true><<<grid, block, shmem, stream>>>(__VA_ARGS__); }   \
+      else         { allow_lds(KERNEL<true, false>, shmem); KERNEL<true, false><<<grid, block, shmem, stream>>>(__VA_ARGS__); }  \
+    } else {                                                                                    \
+      if (hasmask) { allow_lds(KERNEL<false, true>, shmem);  KERNEL<false, true><<<grid, block, shmem, stream>>>(__VA_ARGS__); } \
+      else         { allow_lds(KERNEL<false, false>, shmem); KERNEL<false, false><<<grid, block, shmem, stream>>>(__VA_ARGS__); }\
+    }                                                                                           \
+  } while (0)
+
 int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
                  hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
-  const size_t shmem = (size_t)d->W * 2 * sizeof(float4);
-  if (d->flags & PD_MIXTURE) {
-    allow_lds(rowshift_fwd_kernel<true>, shmem);
-    rowshift_fwd_kernel<true><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash);
-  } else {
-    allow_lds(rowshift_fwd_kernel<false>, shmem);
-    rowshift_fwd_kernel<false><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash);
-  }
+  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + (size_t)d->N * sizeof(float);
+  PD_ROW_DISPATCH(rowshift_fwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a,
+                  rgb_rec, ph_map, stash);
   return check_launch("rowshift_fwd_kernel");
 }
 
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
   const int nseg = ceil_div(d->W, kWave);
-  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + ((size_t)d->N + (size_t)nseg * d->N * 6) * sizeof(float);
-  if (d->flags & PD_MIXTURE) {
-    allow_lds(rowshift_bwd_kernel<true>, shmem);
-    rowshift_bwd_kernel<true><<<grid, block, shmem, stream>>>(a, o);
-  } else {
-    allow_lds(rowshift_bwd_kernel<false>, shmem);
-    rowshift_bwd_kernel<false><<<grid, block, shmem, stream>>>(a, o);
-  }
+  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + ((size_t)2 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
+  PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
   int rc = check_launch("rowshift_bwd_kernel");
   if (rc || !o.g_plane) return rc;
   reduce_rows_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);

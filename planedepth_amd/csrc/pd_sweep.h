@@ -38,30 +38,43 @@ struct BwdOut {
 };
 
 // ---- forward: online softmax / mixture accumulators of ONE target pixel over the planes ---------------------------
+// Everything exponential is evaluated in base 2 (v_exp_f32 / v_log_f32 are base-2 instructions): logits are scaled by
+// log2(e) once, the stash keeps the log-sum-exp in log2 units.  The running reference `m` of the online softmax is only
+// moved when a logit exceeds it by more than kRescaleThr (2^20): exact max-tracking would cost a divergent branch
+// with a rescale of eight accumulators on ~ln(N) planes per pixel, any lane of the wave triggering it.
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+constexpr float kRescaleThr = 20.0f;
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+
 struct FwdAcc {
   float m = -INFINITY, Z = 0.0f, S = 0.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Mx = 0.0f, Ma = 0.0f;
 };
 
-// One plane's (masked) samples l, s, c* enter the running sums.  t* = target colour, ea = identity-reprojection error.
+// One plane's (masked) samples l, s, c* enter the running sums.  t* = target colour, ea3 = 3 x the identity-
+// reprojection error (sum over channels of |src - tgt|).  Mx / Ma omit the Laplacian's constant 1/2 (applied at the end).
 template <bool MIX>
 __device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, float c0, float c1, float c2, float t0,
-                                               float t1, float t2, float ea, bool automask) {
-  if (l > a.m) {  // online softmax (trainer.py:593): rescale the running sums when the max moves
-    const float sc = fast_exp(a.m - l);
+                                               float t1, float t2, float ea3, bool automask) {
+  const float l2 = l * kLog2e;
+  if (l2 - a.m > kRescaleThr) {  // first plane (m = -inf) and rare large jumps only
+    const float sc = exp2_fast(a.m - l2);
     a.Z *= sc; a.S *= sc; a.C0 *= sc; a.C1 *= sc; a.C2 *= sc; a.Mx *= sc; a.Ma *= sc;
-    a.m = l;
+    a.m = l2;
   }
-  const float p = fast_exp(l - a.m);
+  const float p = exp2_fast(l2 - a.m);
   a.Z += p;
   if (MIX) {
     const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);  // trainer.py:597
-    const float inv = 1.0f / sg;
+    const float inv = fast_rcp(sg);
     const float u = p * inv;                                 // pi / sigma (trainer.py:600)
     a.S += u;
     a.C0 += c0 * u; a.C1 += c1 * u; a.C2 += c2 * u;
-    const float e = (fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2)) / 3.0f;  // trainer.py:729
-    a.Mx += u * (0.5f * fast_exp(-e * inv));                                    // pi * laplacian(e; sigma)
-    if (automask) a.Ma += u * (0.5f * fast_exp(-ea * inv));
+    const float e3 = fabsf(c0 - t0) + fabsf(c1 - t1) + fabsf(c2 - t2);  // 3 * mean_c |c - t|  (trainer.py:729)
+    const float k = inv * (-kLog2e / 3.0f);
+    a.Mx += u * exp2_fast(e3 * k);                                      // pi * 2 * laplacian(e; sigma)
+    if (automask) a.Ma += u * exp2_fast(ea3 * k);
   } else {
     a.C0 += c0 * p; a.C1 += c1 * p; a.C2 += c2 * p;
   }
@@ -69,11 +82,11 @@ __device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, floa
 
 struct FwdResult {
   float r0, r1, r2, ph;
-  float lse, Sn, mx, sel;  // stash
+  float lse2, Sn, mx, sel;  // stash: log2-sum-exp2 of the scaled logits, sum(pi/sigma), sum(pi*lap), automask flag
 };
 
 template <bool MIX>
-__device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float t1, float t2, float ea,
+__device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float t1, float t2, float ea3,
                                                 bool automask) {
   FwdResult r;
   const float invZ = 1.0f / a.Z;
@@ -81,11 +94,11 @@ __device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float
   if (MIX) {
     const float invS = 1.0f / a.S;
     r.r0 = a.C0 * invS; r.r1 = a.C1 * invS; r.r2 = a.C2 * invS;
-    r.mx = a.Mx * invZ;
+    r.mx = 0.5f * a.Mx * invZ;
     r.Sn = a.S * invZ;
-    r.ph = -__logf(r.mx + kLogEps);  // layers.py:466
+    r.ph = -kLn2 * log2_fast(r.mx + kLogEps);  // layers.py:466
     if (automask) {
-      const float pa = -__logf(a.Ma * invZ + kLogEps);
+      const float pa = -kLn2 * log2_fast(0.5f * a.Ma * invZ + kLogEps);
       if (pa < r.ph) { r.ph = pa; r.sel = 1.0f; }  // torch.min over cat([ph, ph_auto]) keeps the first on ties
     }
   } else {
@@ -93,16 +106,17 @@ __device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float
     r.mx = 0.0f;
     r.Sn = 0.0f;
     r.ph = (fabsf(r.r0 - t0) + fabsf(r.r1 - t1) + fabsf(r.r2 - t2)) / 3.0f;  // trainer.py:738
+    const float ea = ea3 / 3.0f;
     if (automask && ea < r.ph) { r.ph = ea; r.sel = 1.0f; }
   }
-  r.lse = a.m + __logf(a.Z);
+  r.lse2 = a.m + log2_fast(a.Z);
   return r;
 }
 
 // ---- backward: per-target-pixel context and per-plane gradients w.r.t. the SAMPLED features -----------------------
 struct PixelCtx {
   float t0, t1, t2;     // target colour
-  float lse;            // log-sum-exp of the sampled logits
+  float lse2;           // log2-sum-exp2 of the sampled logits scaled by log2(e)
   float invS, mx, A;    // mixture: 1 / sum(pi/sigma), sum(pi*lap), g_ph / (mx + 1e-7)
   float gr0, gr1, gr2;  // upstream gradient of rgb_rec (+ the L1 photometric term when !MIX)
   float gdotr;          // gr . rgb_rec
@@ -115,7 +129,7 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const SweepArgs& a, const Bwd
   c.t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
   c.t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
   const float* st = o.stash + (long)b * a.stash_k * HW + pix;
-  c.lse = st[0];
+  c.lse2 = st[0];
   const float Sn = st[HW];
   c.mx = st[2 * HW];
   const float sel = st[3 * HW];
@@ -130,9 +144,9 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const SweepArgs& a, const Bwd
     c.gr2 = o.g_rgb_rec[((long)b * 3 + 2) * HW + pix];
   }
   if (!MIX) {  // L1 branch: ph = mean_c |rgb_rec - tgt| feeds straight into the rgb_rec gradient
-    c.gr0 += gp * sgn(r0 - c.t0) / 3.0f;
-    c.gr1 += gp * sgn(r1 - c.t1) / 3.0f;
-    c.gr2 += gp * sgn(r2 - c.t2) / 3.0f;
+    c.gr0 += gp * sgn(r0 - c.t0) * (1.0f / 3.0f);
+    c.gr1 += gp * sgn(r1 - c.t1) * (1.0f / 3.0f);
+    c.gr2 += gp * sgn(r2 - c.t2) * (1.0f / 3.0f);
   }
   c.A = MIX ? gp / (c.mx + kLogEps) : 0.0f;  // -d ph / d Mx (layers.py:466)
   c.invS = MIX ? 1.0f / Sn : 1.0f;
@@ -142,7 +156,7 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const SweepArgs& a, const Bwd
 
 __device__ __forceinline__ PixelCtx zero_pixel_ctx() {
   PixelCtx c;
-  c.t0 = c.t1 = c.t2 = c.lse = 0.0f;
+  c.t0 = c.t1 = c.t2 = c.lse2 = 0.0f;
   c.invS = 1.0f; c.mx = 1.0f; c.A = 0.0f;
   c.gr0 = c.gr1 = c.gr2 = c.gdotr = 0.0f;
   return c;
@@ -155,23 +169,24 @@ struct PlaneGrad {
 template <bool MIX>
 __device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, float s, float c0, float c1, float c2) {
   PlaneGrad g;
-  const float p = fast_exp(l - c.lse);  // pi_n
+  const float p = exp2_fast(l * kLog2e - c.lse2);  // pi_n
   if (MIX) {
     const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
-    const float inv = 1.0f / sg;
+    const float inv = fast_rcp(sg);
     const float u = p * inv;
-    const float e = (fabsf(c0 - c.t0) + fabsf(c1 - c.t1) + fabsf(c2 - c.t2)) / 3.0f;
-    const float q = 0.5f * fast_exp(-e * inv) * inv;                                  // laplacian(e; sigma)
+    const float e3 = fabsf(c0 - c.t0) + fabsf(c1 - c.t1) + fabsf(c2 - c.t2);          // 3 e
+    const float ei = e3 * inv * (1.0f / 3.0f);                                        // e / sigma
+    const float q = 0.5f * exp2_fast(-kLog2e * ei) * inv;                             // laplacian(e; sigma)
     const float gu = (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr) * c.invS;       // d (g . rgb_rec) / d u_n
     const float g_pi = -c.A * q + gu * inv;
     g.g_l = p * (g_pi + c.A * c.mx);                                                  // softmax backward, closed form
-    const float g_sig = -c.A * p * q * (e * inv * inv - inv) - gu * u * inv;          // d / d sigma_n
+    const float g_sig = -c.A * p * q * (ei * inv - inv) - gu * u * inv;               // d / d sigma_n
     g.g_s = (s >= kSigmaMin && s <= kSigmaMax) ? g_sig : 0.0f;                        // clamp: grad on [min,max]
-    const float g_e = c.A * u * q;                                                    // d ph / d e_n
+    const float g_e3 = c.A * u * q * (1.0f / 3.0f);                                   // d ph / d e_n, per channel
     const float w = u * c.invS;
-    g.gc0 = c.gr0 * w + g_e * sgn(c0 - c.t0) / 3.0f;
-    g.gc1 = c.gr1 * w + g_e * sgn(c1 - c.t1) / 3.0f;
-    g.gc2 = c.gr2 * w + g_e * sgn(c2 - c.t2) / 3.0f;
+    g.gc0 = c.gr0 * w + g_e3 * sgn(c0 - c.t0);
+    g.gc1 = c.gr1 * w + g_e3 * sgn(c1 - c.t1);
+    g.gc2 = c.gr2 * w + g_e3 * sgn(c2 - c.t2);
   } else {
     g.g_l = p * (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr);
     g.g_s = 0.0f;
