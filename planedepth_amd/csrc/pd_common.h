@@ -126,6 +126,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- DPP cross-lane helpers (GFX9 family: wave_shr / row_bcast controls exist on gfx950) ---------------------------
+// They are VALU operand modifiers: no LDS traffic, unlike __shfl_* which lowers to ds_bpermute_b32.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_zero(float v) {  // lanes without a source (or masked rows) read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// lane i receives lane i-1 across the whole wave; lane 0 receives 0
+__device__ __forceinline__ float wave_shift_up1(float v) { return dpp_zero<0x138>(v); }
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (use lane 63).
+__device__ __forceinline__ float wave_sum_hi(float v) {
+  v += dpp_zero<0xB1>(v);         // quad_perm:[1,0,3,2]
+  v += dpp_zero<0x4E>(v);         // quad_perm:[2,3,0,1]   -> quad sums
+  v += dpp_zero<0x124>(v);        // row_ror:4
+  v += dpp_zero<0x128>(v);        // row_ror:8             -> row (16-lane) sums in every lane
+  v += dpp_zero<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_zero<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave total
+  return v;
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }

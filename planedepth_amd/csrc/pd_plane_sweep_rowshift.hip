@@ -297,43 +297,40 @@ __global__ __launch_bounds__(kMaxRowThreads) void rowshift_fwd_kernel(SweepArgs 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward: one workgroup per target row; 64-lane segments of the row; gather-form adjoint.
 // ---------------------------------------------------------------------------------------------------------------
-struct Bnd {  // contributions that leave a segment, per (segment, plane, tensor)
-  float left, right0, right1;  // to global slots T0-1, Tend+1, Tend+2 (ring)
-};
-
-// Route lane contributions (c0 -> slot lane+dl, c1 -> slot lane+dl+1) to their slots inside the wave.
-// Returns this lane's slot total; out-of-wave parts go to `bnd`.  `last` = last active lane of the segment.
-__device__ __forceinline__ float route(float c0, float c1, int dl, bool regular, int lane, int last, Bnd& bnd) {
-  float out;
-  if (regular) {
-    const float up = __shfl_up(c1, 1, kWave);
-    out = c0 + ((lane > 0) ? up : 0.0f);
-    bnd.left = 0.0f;
-    bnd.right0 = __shfl(c1, last, kWave);
-    bnd.right1 = 0.0f;
-  } else {
-    out = 0.0f;
+// Segment-boundary records live in LDS, zero-filled at kernel start: bnd[(seg*N + n)*6 + tensor*3 + j] with
+// j = 0: to global slot T0-1, j = 1: to slot Tlast+1, j = 2: to slot Tlast+2 (the row is a ring of W slots).
+//
+// Route lane contributions (c0 -> slot lane+dl, c1 -> slot lane+dl+1) to their slots inside the wave and return this
+// lane's slot total.  `last` = last active lane of the segment; `bp` = this (segment, plane, tensor)'s 3 records.
+__device__ __forceinline__ float route(float c0, float c1, int dl, bool regular, int lane, int last,
+                                       float* __restrict__ bp) {
+  if (regular) {  // every lane's left tap is exactly its own slot: one wave-wide shift
+    if (lane == last) bp[1] = c1;  // leaves the segment on the right
+    return c0 + wave_shift_up1(c1);
+  }
+  float out = 0.0f;
 #pragma unroll
-    for (int r = -2; r <= 1; ++r) {
-      const int srcl = lane + r;
-      const int sl = min(max(srcl, 0), kWave - 1);
-      const float v0 = __shfl(c0, sl, kWave), v1 = __shfl(c1, sl, kWave);
-      const int dd = __shfl(dl, sl, kWave);
-      const bool in = (srcl >= 0) && (srcl <= last);
-      if (in && dd == -r) out += v0;       // c0 of lane+r lands on slot lane+r+dd == lane
-      if (in && dd == -r - 1) out += v1;   // c1 of lane+r lands on slot lane+r+dd+1 == lane
-    }
-    const float c0_first = __shfl(c0, 0, kWave);
-    const int d_first = __shfl(dl, 0, kWave);
-    const float c0_last = __shfl(c0, last, kWave), c1_last = __shfl(c1, last, kWave);
-    const int d_last = __shfl(dl, last, kWave);
-    const int lp = max(last - 1, 0);
-    const float c1_prev = __shfl(c1, lp, kWave);
-    const int d_prev = __shfl(dl, lp, kWave);
-    bnd.left = (d_first == -1) ? c0_first : 0.0f;                      // slot -1
-    bnd.right0 = ((d_last == 1) ? c0_last : 0.0f) + ((d_last == 0) ? c1_last : 0.0f) +
-                 ((last >= 1 && d_prev == 1) ? c1_prev : 0.0f);       // slot last+1
-    bnd.right1 = (d_last == 1) ? c1_last : 0.0f;                       // slot last+2
+  for (int r = -2; r <= 1; ++r) {
+    const int srcl = lane + r;
+    const int sl = min(max(srcl, 0), kWave - 1);
+    const float v0 = __shfl(c0, sl, kWave), v1 = __shfl(c1, sl, kWave);
+    const int dd = __shfl(dl, sl, kWave);
+    const bool in = (srcl >= 0) && (srcl <= last);
+    if (in && dd == -r) out += v0;       // c0 of lane+r lands on slot lane+r+dd == lane
+    if (in && dd == -r - 1) out += v1;   // c1 of lane+r lands on slot lane+r+dd+1 == lane
+  }
+  const float c0_first = __shfl(c0, 0, kWave);
+  const int d_first = __shfl(dl, 0, kWave);
+  const float c0_last = __shfl(c0, last, kWave), c1_last = __shfl(c1, last, kWave);
+  const int d_last = __shfl(dl, last, kWave);
+  const int lp = max(last - 1, 0);
+  const float c1_prev = __shfl(c1, lp, kWave);
+  const int d_prev = __shfl(dl, lp, kWave);
+  if (lane == 0) {
+    bp[0] = (d_first == -1) ? c0_first : 0.0f;                                      // slot -1
+    bp[1] = ((d_last == 1) ? c0_last : 0.0f) + ((d_last == 0) ? c1_last : 0.0f) +
+            ((last >= 1 && d_prev == 1) ? c1_prev : 0.0f);                          // slot last+1
+    bp[2] = (d_last == 1) ? c1_last : 0.0f;                                         // slot last+2
   }
   return out;
 }
@@ -346,19 +343,18 @@ struct SegCtx {
 template <bool MIX, bool HASMASK, int NROWS, int U>
 __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, const RowSel& row,
                                           const float4* __restrict__ lrgb, const float* __restrict__ sdisp,
-                                          float* __restrict__ red, float* __restrict__ bnd, int b, int y, int n0,
+                                          const int* __restrict__ kshift, float* __restrict__ red,
+                                          float* __restrict__ bnd, int b, int y, int n0,
                                           const SegCtx& sc, const PixelCtx& c, int HW, float Wm1, float rcpWm1,
                                           float gix_scale, bool want_plane, uint32_t& bits) {
   const int W = a.W, N = a.N;
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
-  float sd[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
     const long pl = ((long)b * N + n) * HW;
-    sd[u] = sdisp[n];
-    ct[u] = make_col_tap((float)sc.xt + sd[u], Wm1, rcpWm1, W);
+    ct[u] = make_col_tap((float)sc.xt + sdisp[n], Wm1, rcpWm1, W);
     tl[u] = load_taps<NROWS>(a.logits + pl + (long)row.yA * W, a.logits + pl + (long)row.yB * W, ct[u]);
     if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl + (long)row.yA * W, a.sigma + pl + (long)row.yB * W, ct[u]);
   }
@@ -366,7 +362,7 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
     const long pl = ((long)b * N + n) * HW;
-    const int k = (int)fminf(fmaxf(floorf(sd[u]), -(float)W), (float)W);  // nominal shift, |k| <= W
+    const int k = kshift[n];  // nominal shift floor(s*d), |k| <= W
     bool mk = sc.active;
     if (HASMASK) {
       if ((n & 31) == 0)
@@ -393,26 +389,23 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
     const bool regular = __all(dl == 0);
     int xs = sc.xt + k;                       // the source pixel this slot owns (ring of W slots)
     xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
-    Bnd bl, bs;
-    const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bl);
-    if (sc.active && o.g_logits) (o.g_logits + pl + (long)y * W)[(unsigned)xs] = out_l;
     float* bp = bnd + ((long)sc.seg * N + n) * 6;
-    if (sc.lane == 0) { bp[0] = bl.left; bp[1] = bl.right0; bp[2] = bl.right1; }
+    const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bp);
+    if (sc.active && o.g_logits) (o.g_logits + pl + (long)y * W)[(unsigned)xs] = out_l;
     if (MIX) {
-      const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bs);
+      const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
       if (sc.active && o.g_sigma) (o.g_sigma + pl + (long)y * W)[(unsigned)xs] = out_s;
-      if (sc.lane == 0) { bp[3] = bs.left; bp[4] = bs.right0; bp[5] = bs.right1; }
     }
     if (want_plane) {
-      const float v = wave_sum(gd);
-      if (sc.lane == 0) atomicAdd(&red[n], v);
+      const float v = wave_sum_hi(gd);
+      if (sc.lane == kWave - 1) atomicAdd(&red[n], v);
     }
   }
 }
 
 template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
-                                                  float* sdisp, float* red, float* bnd, float4* lrgb) {
+                                                  float* sdisp, int* kshift, float* red, float* bnd, float4* lrgb) {
   constexpr int U = (NROWS == 1) ? 2 : 1;
   const int y = blockIdx.x, b = blockIdx.y;
   const int HW = a.H * a.W, W = a.W, N = a.N;
@@ -422,8 +415,11 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const float* srcb = a.src + (long)b * 3 * HW;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     red[i] = 0.0f;
-    sdisp[i] = a.sign * a.plane[(long)b * N + i];
+    const float sd = a.sign * a.plane[(long)b * N + i];
+    sdisp[i] = sd;
+    kshift[i] = (int)fminf(fmaxf(floorf(sd), -(float)W), (float)W);
   }
+  for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
   stage_colour_rows<NROWS>(lrgb, srcb, HW, W, row);
   __syncthreads();
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
@@ -442,10 +438,10 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     uint32_t bits = 0;
     int n = 0;
     for (; n + U <= N; n += U)
-      bwd_group<MIX, HASMASK, NROWS, U>(a, o, row, lrgb, sdisp, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
+      bwd_group<MIX, HASMASK, NROWS, U>(a, o, row, lrgb, sdisp, kshift, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
                                          want_plane, bits);
     for (; n < N; ++n)
-      bwd_group<MIX, HASMASK, NROWS, 1>(a, o, row, lrgb, sdisp, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
+      bwd_group<MIX, HASMASK, NROWS, 1>(a, o, row, lrgb, sdisp, kshift, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
                                          want_plane, bits);
   }
   __syncthreads();
@@ -461,7 +457,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     const int T0 = seg * kWave, last = min(kWave - 1, W - 1 - T0);
     int g = (j == 0) ? T0 - 1 : T0 + last + j;   // j=1 -> last+1, j=2 -> last+2
     g = ((g % W) + W) % W;
-    const int k = (int)fminf(fmaxf(floorf(sdisp[n]), -(float)W), (float)W);
+    const int k = kshift[n];
     int xs = g + k;
     xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
     unsafeAtomicAdd(dst + ((long)b * N + n) * HW + (long)y * W + xs, v);
@@ -475,13 +471,14 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
 template <bool MIX, bool HASMASK>
 __global__ __launch_bounds__(kMaxRowThreads) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
-  // LDS: colour rows float4[2*W] | sdisp[N] | red[N] | bnd[nseg][N][6]  (6 = {left,right0,right1} x {logits, sigma})
+  // LDS: colour rows float4[2*W] | sdisp[N] | kshift[N] | red[N] | bnd[nseg][N][6]  (6 = 3 records x {logits, sigma})
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * a.W);
-  float* red = sdisp + a.N;
+  int* kshift = reinterpret_cast<int*>(sdisp + a.N);
+  float* red = sdisp + 2 * a.N;
   float* bnd = red + a.N;
   const RowSel row = make_row_sel(blockIdx.x, a.H);
-  if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, red, bnd, lds4);
-  else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, red, bnd, lds4);
+  if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
+  else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }
 
 // partials [B][R][M] -> out [B][M]; one wave per (b, j): lanes stride over R, then wave-reduce.  Deterministic.
@@ -520,7 +517,7 @@ static int row_threads(int W) {
 
 bool rowshift_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
-         (size_t)d->W * 32 + ((size_t)2 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
+         (size_t)d->W * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
 }
 
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
@@ -554,7 +551,7 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
   const int nseg = ceil_div(d->W, kWave);
-  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + ((size_t)2 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
+  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + ((size_t)3 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
   PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
   int rc = check_launch("rowshift_bwd_kernel");
   if (rc || !o.g_plane) return rc;
