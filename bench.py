@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--warp_type", default="disp_warp", choices=["disp_warp", "homography_warp"])
     ap.add_argument("--no_mixture", action="store_true")
     ap.add_argument("--automask", action="store_true")
-    ap.add_argument("--no_padding_mask", action="store_true", help="do not feed the decoder's all-ones padding mask")
+    ap.add_argument("--xz_levels", type=int, default=0,
+                    help="reference option: 0 (BASELINE's '49 planes') lets the path skip the decoder's all-ones padding "
+                         "mask; >0 feeds it as a dense [B,N,H,W] tensor like the decoder with ground planes does")
+    ap.add_argument("--no_padding_mask", action="store_true", help="never pass a padding mask (diagnostics)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
@@ -65,7 +68,8 @@ def build_step(args, c, device):
     Rt = c["Rt"].clone()
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
                                 render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
-                                gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False)
+                                gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
+                                xz_levels=args.xz_levels, yz_levels=0)
     zero = torch.zeros((), device=device)
     ns = types.SimpleNamespace(opt=opt, target_sides=["r"], perceptual_loss=lambda *a, **k: zero)
     inputs = {("color", "l"): c["color_l"], ("color", "r"): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
@@ -114,7 +118,7 @@ def kernel_times(args, c, device, iters):
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
     d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, 0)
     plane = c["disp_pp"][:, :, 0, 0].contiguous()
-    pm = None if args.no_padding_mask else c["padding_mask"]
+    pm = None if (args.no_padding_mask or args.xz_levels == 0) else c["padding_mask"]
     k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
     rgb = torch.empty(B, 3, H, W, device=device)
     ph = torch.empty(B, 1, H, W, device=device)
@@ -237,7 +241,8 @@ def main():
                                   args.height, args.width, args.planes),
                    "global_batch": args.batch * world, "planes": args.planes, "height": args.height,
                    "width": args.width, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
-                   "padding_mask": "decoder's dense all-ones [B,N,H,W]" if not args.no_padding_mask else "none"},
+                   "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
+                   if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask"},
     }
     if rank == 0:
         kt = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))

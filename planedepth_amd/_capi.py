@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (imported first so the process already holds torch's libamdhip64 — one HIP runtime only)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplanedepth_hip.so")
+LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth_hip.so")  # PD_LIB: diagnostics builds
 
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE = 1, 2, 4, 8

@@ -150,5 +150,10 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+// sign(x) in two instructions: scale any normal |x| beyond 1, then clamp to [-1, 1] (v_med3_f32); sign(0) = 0 as in
+// torch's abs backward.  Denormal differences (|x| < 2^-126) give a fraction instead of +-1: below fp32 data noise.
+__device__ __forceinline__ float sgn_fast(float x) {
+  return __builtin_amdgcn_fmed3f(x * 8.5070592e37f /* 2^126 */, -1.0f, 1.0f);
+}
 
 }  // namespace pd

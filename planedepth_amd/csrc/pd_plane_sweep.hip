@@ -13,6 +13,8 @@
 //                         block-reduced plane-parameter gradient partials
 //   reduce_partials_kernel  deterministic second stage for the plane-parameter gradient
 //   sweep_layers_kernel   optional materialisation of the per-plane tensors the reference stores in `outputs`
+#include <stdlib.h>
+
 #include "pd_sweep.h"
 
 namespace pd {

@@ -26,11 +26,46 @@
 // The forward and the per-pixel gradient use both rows exactly; the adjoint applies the (1-eps) weight to the
 // workgroup's own row and drops the eps-weighted term of the neighbouring row (relative size <= 1e-5, an order of
 // magnitude inside the 1e-4 parity budget; measured in tests/test_gpu_parity.py).  The general kernels keep it.
+#include <stdlib.h>
+
 #include "pd_sweep.h"
 
 namespace pd {
 
 constexpr int kMaxRowThreads = 1024;
+
+// Tuning knobs (scripts/gpu_variants.sh builds variants with -D...): plane-group size, one-group-ahead prefetch and
+// the occupancy the register allocator must leave room for (waves per SIMD), per kernel.
+#ifndef PD_VARIANT
+#define PD_VARIANT 0
+#endif
+#ifndef PD_FWD_U
+#define PD_FWD_U 4
+#endif
+#ifndef PD_FWD_PF
+#define PD_FWD_PF 1
+#endif
+#ifndef PD_FWD_OCC
+#define PD_FWD_OCC 4
+#endif
+#ifndef PD_BWD_U
+#define PD_BWD_U 2
+#endif
+#ifndef PD_BWD_PF
+#define PD_BWD_PF 1
+#endif
+#ifndef PD_BWD_OCC
+#define PD_BWD_OCC 4
+#endif
+constexpr int kVariant = PD_VARIANT;
+constexpr int kRowThreadsMax = 512;  // row workgroups use <= 8 waves (row_threads)
+
+// Row handled by workgroup r of an image.  The dispatcher deals consecutive workgroups to the 8 XCDs round-robin; the
+// banded mapping gives each XCD (its own L2) a contiguous band of rows instead of every 8th row.
+__device__ __forceinline__ int block_row(int r, int H) {
+  if ((kVariant & 1) && (H % 8 == 0)) return (r & 7) * (H >> 3) + (r >> 3);
+  return r;
+}
 
 // Vertical footprint of target row y (workgroup-uniform): up to two live source rows with their weights.
 struct RowSel {
@@ -58,11 +93,27 @@ __device__ __forceinline__ RowSel make_row_sel(int y, int H) {
   return r;
 }
 
+// ---- memory access layer ------------------------------------------------------------------------------------------
+// Row-sized buffer resources (SRD in SGPRs, built from workgroup-uniform values only) give three things at once:
+//   * a 32-bit per-lane byte offset instead of 64-bit address arithmetic (the u64 adds were ~15% of all VALU cycles);
+//   * hardware range checking: a tap left of column 0 (offset wraps to >= 2^31) or right of column W-1 reads as 0,
+//     which IS grid_sample's padding_mode="zeros" — no validity compares, selects or clamped indices in the forward;
+//   * loads without exec-mask branches, so a whole group's loads issue back to back.
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+
+__device__ __forceinline__ Rsrc row_rsrc(const float* row, int W) {  // `row` must be wave-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, W * 4, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(Rsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(Rsrc r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
+}
+
 struct ColTap {    // horizontal footprint of one target pixel on one plane
-  int x0;           // floor(ix), clamped to [-2, W] (only meaningful when v0 || v1)
-  unsigned i0, i1;  // x0 and x0+1 if inside the image, else 0: always safe to load
-  float m0, m1;     // torch's weights (x1 - ix), (ix - x0) with out-of-image taps zeroed (padding_mode="zeros")
-  bool v0, v1;      // tap inside the image
+  int x0;          // floor(ix)
+  float w0, w1;    // torch's weights (x1 - ix), (ix - x0)
 };
 
 // Correctly rounded a / b from the correctly rounded reciprocal of b (Markstein's theorem; b = W-1 is an integer
@@ -80,164 +131,267 @@ __device__ __forceinline__ float refined_rcp(float b) {
   return fmaf(e, y, y);
 }
 
-__device__ __forceinline__ ColTap make_col_tap(float px, float Wm1, float rcpWm1, int W) {
+// ix = unnormalise(normalise(px)) of the reference, bit for bit, in 7 operations:
+//   reference:  q = px/(W-1);  g = (q - 0.5)*2;            [trainer.py:550-552]
+//               ix = ((g + 1)/2) * (W-1)                    [grid_sample, align_corners=True]
+//   (g + 1)/2 = fl(2h + 1)/2 with h = fl(q - 0.5); scaling by 2 commutes with rounding, so it equals fl(h + 0.5).
+// |px| <= 2W+2 by construction (the per-plane shift is clamped to +-(W+2) when it is staged), so floor(ix) converts
+// to int without saturating and x0*4 cannot alias into the row.
+__device__ __forceinline__ ColTap make_col_tap(float px, float Wm1, float rcpWm1) {
   ColTap t;
   float ix;
   {
 #pragma clang fp contract(off)
     const float q = div_by(px, Wm1, rcpWm1);
     const float h = q - 0.5f;
-    const float g = h * 2.0f;                               // trainer.py:550-552
-    ix = unnormalise(g, Wm1);                               // grid_sample un-normalisation, align_corners=True
+    const float hh = h + 0.5f;
+    ix = hh * Wm1;
   }
   const float xf = floorf(ix);
-  const float wx0 = (xf + 1.0f) - ix, wx1 = ix - xf;
-  t.x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W);            // NaN / huge coordinates end up outside
-  t.v0 = (unsigned)t.x0 < (unsigned)W;
-  t.v1 = (unsigned)(t.x0 + 1) < (unsigned)W;
-  t.i0 = t.v0 ? (unsigned)t.x0 : 0u;
-  t.i1 = t.v1 ? (unsigned)(t.x0 + 1) : 0u;
-  t.m0 = t.v0 ? wx0 : 0.0f;
-  t.m1 = t.v1 ? wx1 : 0.0f;
+  t.w0 = (xf + 1.0f) - ix;
+  t.w1 = ix - xf;
+  t.x0 = (int)xf;
   return t;
 }
 
-// The (up to) four taps of one scalar plane, loaded up-front.
+// The (up to) four taps of one scalar plane, loaded up-front.  Out-of-image taps come back as 0 from the hardware.
 template <int NROWS>
 struct Taps {
   float a0, a1, b0, b1;  // row A (x0, x0+1), row B (x0, x0+1)
 };
 
-// Loads are UNCONDITIONAL (clamped indices off a workgroup-uniform row pointer): no exec-mask branches, so the compiler
-// can issue a whole group's loads back to back.  Out-of-image taps are cancelled by the zeroed weights m0/m1.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f buf_load2(Rsrc r, unsigned byte_off) {  // 8 bytes at any 4-byte-aligned offset
+  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+
+// Both horizontal taps of a row come from ONE 8-byte load at column x0 (measured on gfx950, scripts/probes/buf_probe:
+// unaligned 8/16-byte buffer loads work, the range check is per dword at the upper end, and an access that STARTS
+// left of the row reads as all-zero).  The only column pair that needs help is x0 = -1, whose second tap (column 0) is
+// inside the image: it is fetched as the first dword of a load at column 0.
+struct TapPos {
+  unsigned off;   // byte offset of the load
+  bool edge;      // x0 == -1
+};
+
+__device__ __forceinline__ TapPos tap_pos(const ColTap& c) {
+  TapPos p;
+  p.edge = (c.x0 == -1);
+  p.off = p.edge ? 0u : ((unsigned)c.x0 << 2);
+  return p;
+}
+
 template <int NROWS>
-__device__ __forceinline__ Taps<NROWS> load_taps(const float* __restrict__ rowA, const float* __restrict__ rowB,
-                                                 const ColTap& c) {
+__device__ __forceinline__ Taps<NROWS> load_taps(Rsrc rowA, Rsrc rowB, const TapPos& p) {
   Taps<NROWS> t;
-  t.a0 = rowA[c.i0];
-  t.a1 = rowA[c.i1];
+  const v2f va = buf_load2(rowA, p.off);
+  t.a0 = va.x; t.a1 = va.y;
   t.b0 = t.b1 = 0.0f;
   if (NROWS == 2) {
-    t.b0 = rowB[c.i0];
-    t.b1 = rowB[c.i1];
+    const v2f vb = buf_load2(rowB, p.off);
+    t.b0 = vb.x; t.b1 = vb.y;
   }
   return t;
 }
 
+// Apply the x0 = -1 fix-up after the data has arrived (kept out of the issue phase so it does not wait on the load).
 template <int NROWS>
-__device__ __forceinline__ float tap_value(const Taps<NROWS>& t, const RowSel& r, const ColTap& c) {
-  float v = t.a0 * (c.m0 * r.wA) + t.a1 * (c.m1 * r.wA);
-  if (NROWS == 2) v += t.b0 * (c.m0 * r.wB) + t.b1 * (c.m1 * r.wB);
+__device__ __forceinline__ void fix_edge(Taps<NROWS>& t, bool edge) {
+  t.a1 = edge ? t.a0 : t.a1;
+  t.a0 = edge ? 0.0f : t.a0;
+  if (NROWS == 2) {
+    t.b1 = edge ? t.b0 : t.b1;
+    t.b0 = edge ? 0.0f : t.b0;
+  }
+}
+
+// w0A/w1A(/w0B/w1B): horizontal weight x vertical weight, computed once per plane and shared by all five channels
+struct TapW {
+  float a0, a1, b0, b1;
+};
+
+template <int NROWS>
+__device__ __forceinline__ TapW tap_weights(const ColTap& c, const RowSel& r, float live) {
+  TapW w;
+  const float w0 = c.w0 * live, w1 = c.w1 * live;  // live = 1, or 0 for a plane the padding mask removes
+  w.a0 = w0 * r.wA;
+  w.a1 = w1 * r.wA;
+  w.b0 = w.b1 = 0.0f;
+  if (NROWS == 2) {
+    w.b0 = w0 * r.wB;
+    w.b1 = w1 * r.wB;
+  }
+  return w;
+}
+
+template <int NROWS>
+__device__ __forceinline__ float tap_value(const Taps<NROWS>& t, const TapW& w) {
+  float v = t.a0 * w.a0 + t.a1 * w.a1;
+  if (NROWS == 2) v += t.b0 * w.b0 + t.b1 * w.b1;
   return v;
 }
 
-// d value / d ix: (ne - nw) * wy with out-of-image taps reading as zero
+// d value / d ix = (ne - nw) * wyA + (se - sw) * wyB   (out-of-image taps already read as zero)
 template <int NROWS>
-__device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r, const ColTap& c) {
-  float d = ((c.v1 ? t.a1 : 0.0f) - (c.v0 ? t.a0 : 0.0f)) * r.wA;
-  if (NROWS == 2) d += ((c.v1 ? t.b1 : 0.0f) - (c.v0 ? t.b0 : 0.0f)) * r.wB;
+__device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r) {
+  float d = (t.a1 - t.a0) * r.wA;
+  if (NROWS == 2) d += (t.b1 - t.b0) * r.wB;
   return d;
 }
 
-// Colour taps from the LDS copy of the source rows: [row][x] float4 (r, g, b, unused)
+// Colour rows in LDS: per live row W+4 float4 (r,g,b,-) with two zero guard cells on each side, so taps at
+// x0 in [-2, W] need no validity handling either.  lds_off = byte offset of tap x0 in row A.
+__device__ __forceinline__ unsigned colour_off(int x0, int W) {
+  const int xc = min(max(x0, -2), W);  // v_med3_i32: far-out shifts land on a guard cell
+  return (unsigned)(xc + 2) << 4;
+}
+
 template <int NROWS>
-__device__ __forceinline__ void colour_taps(const float4* __restrict__ lrgb, int W, const RowSel& r, const ColTap& c,
+__device__ __forceinline__ void colour_taps(const char* __restrict__ lrgb, int W, unsigned off, const TapW& w,
                                             float& c0, float& c1, float& c2) {
-  const float4 nw = lrgb[c.i0], ne = lrgb[c.i1];
-  const float w0 = c.m0 * r.wA, w1 = c.m1 * r.wA;
-  c0 = nw.x * w0 + ne.x * w1;
-  c1 = nw.y * w0 + ne.y * w1;
-  c2 = nw.z * w0 + ne.z * w1;
+  const float4 nw = *reinterpret_cast<const float4*>(lrgb + off);
+  const float4 ne = *reinterpret_cast<const float4*>(lrgb + off + 16);
+  c0 = nw.x * w.a0 + ne.x * w.a1;
+  c1 = nw.y * w.a0 + ne.y * w.a1;
+  c2 = nw.z * w.a0 + ne.z * w.a1;
   if (NROWS == 2) {
-    const float4 sw = lrgb[W + c.i0], se = lrgb[W + c.i1];
-    const float u0 = c.m0 * r.wB, u1 = c.m1 * r.wB;
-    c0 += sw.x * u0 + se.x * u1;
-    c1 += sw.y * u0 + se.y * u1;
-    c2 += sw.z * u0 + se.z * u1;
+    const unsigned rb = (unsigned)(W + 4) << 4;
+    const float4 sw = *reinterpret_cast<const float4*>(lrgb + rb + off);
+    const float4 se = *reinterpret_cast<const float4*>(lrgb + rb + off + 16);
+    c0 += sw.x * w.b0 + se.x * w.b1;
+    c1 += sw.y * w.b0 + se.y * w.b1;
+    c2 += sw.z * w.b0 + se.z * w.b1;
   }
 }
 
 template <int NROWS>
-__device__ __forceinline__ void colour_taps_dx(const float4* __restrict__ lrgb, int W, const RowSel& r,
-                                               const ColTap& c, float& c0, float& c1, float& c2, float& d0, float& d1,
+__device__ __forceinline__ void colour_taps_dx(const char* __restrict__ lrgb, int W, unsigned off, const TapW& w,
+                                               const RowSel& r, float& c0, float& c1, float& c2, float& d0, float& d1,
                                                float& d2) {
-  const float4 nw = lrgb[c.i0], ne = lrgb[c.i1];
-  const float w0 = c.m0 * r.wA, w1 = c.m1 * r.wA;
-  const float z0 = c.v0 ? r.wA : 0.0f, z1 = c.v1 ? r.wA : 0.0f;
-  c0 = nw.x * w0 + ne.x * w1;
-  c1 = nw.y * w0 + ne.y * w1;
-  c2 = nw.z * w0 + ne.z * w1;
-  d0 = ne.x * z1 - nw.x * z0;
-  d1 = ne.y * z1 - nw.y * z0;
-  d2 = ne.z * z1 - nw.z * z0;
+  const float4 nw = *reinterpret_cast<const float4*>(lrgb + off);
+  const float4 ne = *reinterpret_cast<const float4*>(lrgb + off + 16);
+  c0 = nw.x * w.a0 + ne.x * w.a1;
+  c1 = nw.y * w.a0 + ne.y * w.a1;
+  c2 = nw.z * w.a0 + ne.z * w.a1;
+  d0 = (ne.x - nw.x) * r.wA;
+  d1 = (ne.y - nw.y) * r.wA;
+  d2 = (ne.z - nw.z) * r.wA;
   if (NROWS == 2) {
-    const float4 sw = lrgb[W + c.i0], se = lrgb[W + c.i1];
-    const float u0 = c.m0 * r.wB, u1 = c.m1 * r.wB;
-    const float y0 = c.v0 ? r.wB : 0.0f, y1 = c.v1 ? r.wB : 0.0f;
-    c0 += sw.x * u0 + se.x * u1;
-    c1 += sw.y * u0 + se.y * u1;
-    c2 += sw.z * u0 + se.z * u1;
-    d0 += se.x * y1 - sw.x * y0;
-    d1 += se.y * y1 - sw.y * y0;
-    d2 += se.z * y1 - sw.z * y0;
+    const unsigned rb = (unsigned)(W + 4) << 4;
+    const float4 sw = *reinterpret_cast<const float4*>(lrgb + rb + off);
+    const float4 se = *reinterpret_cast<const float4*>(lrgb + rb + off + 16);
+    c0 += sw.x * w.b0 + se.x * w.b1;
+    c1 += sw.y * w.b0 + se.y * w.b1;
+    c2 += sw.z * w.b0 + se.z * w.b1;
+    d0 += (se.x - sw.x) * r.wB;
+    d1 += (se.y - sw.y) * r.wB;
+    d2 += (se.z - sw.z) * r.wB;
   }
 }
 
-// Stage the live source colour rows of image b into LDS as float4.
+// Stage the live source colour rows of image b into LDS as float4 (with zero guard cells), plus the per-plane shifts
+// sdisp[n] = sign * disparity clamped to +-(W+2) (beyond +-(W+1) nothing is in view either way).
 template <int NROWS>
-__device__ __forceinline__ void stage_colour_rows(float4* __restrict__ lrgb, const float* __restrict__ srcb, int HW,
-                                                  int W, const RowSel& r) {
+__device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, const RowSel& r, float4* __restrict__ lrgb,
+                                                    float* __restrict__ sdisp) {
+  const int W = a.W, HW = a.H * a.W, RS = W + 4;
+  const float* srcb = a.src + (long)b * 3 * HW;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
     const float* p = srcb + (long)r.yA * W + x;
-    lrgb[x] = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
+    lrgb[2 + x] = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
     if (NROWS == 2) {
       const float* q = srcb + (long)r.yB * W + x;
-      lrgb[W + x] = make_float4(q[0], q[HW], q[2 * HW], 0.0f);
+      lrgb[RS + 2 + x] = make_float4(q[0], q[HW], q[2 * HW], 0.0f);
     }
+  }
+  if (threadIdx.x < 4) {
+    const int g = (threadIdx.x < 2) ? threadIdx.x : W + threadIdx.x;  // cells 0,1 and W+2,W+3
+    lrgb[g] = z;
+    if (NROWS == 2) lrgb[RS + g] = z;
+  }
+  const float lim = (float)(W + 2);
+  for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
+    const float sd = a.sign * a.plane[(long)b * a.N + i];
+    sdisp[i] = (sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f) ? -lim : lim);  // NaN -> +lim: out of view
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
-// LDS layout shared by both kernels: float4 colour[2*W] | float sdisp[N] (= sign * disparity of each plane) | ...
-template <bool MIX, bool HASMASK, int NROWS, int U>
-__device__ __forceinline__ void fwd_group(const SweepArgs& a, const RowSel& row, const float4* __restrict__ lrgb,
-                                          const float* __restrict__ sdisp, int b, int n0, int x, int pix, int HW,
-                                          float Wm1, float rcpWm1, float t0, float t1, float t2, float ea,
-                                          bool automask, FwdAcc& acc, uint32_t& bits, float* __restrict__ stash) {
+// LDS layout shared by both kernels: float4 colour[2*(W+4)] | float sdisp[N] | ...
+// One group of U planes in flight: sampling positions + raw taps (+ padding-mask values).
+template <int NROWS, int U>
+struct PlaneGroup {
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
   float mval[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {  // issue every global load of the group before the first use
-    const int n = n0 + u;
-    const long pl = ((long)b * a.N + n) * HW;               // workgroup-uniform
-    const float* lA = a.logits + pl + (long)row.yA * a.W;   // uniform row pointers: scalar base + 32-bit lane offset
-    const float* lB = a.logits + pl + (long)row.yB * a.W;
-    ct[u] = make_col_tap((float)x + sdisp[n], Wm1, rcpWm1, a.W);
-    mval[u] = HASMASK ? (a.padding_mask + pl)[(unsigned)pix] : 1.0f;
-    tl[u] = load_taps<NROWS>(lA, lB, ct[u]);
-    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl + (long)row.yA * a.W, a.sigma + pl + (long)row.yB * a.W, ct[u]);
-  }
+};
+
+// Issue every global load of planes n0 .. n0+U-1 (no use of the results here: the caller overlaps the latency with
+// the arithmetic of the previous group — one-group-ahead software prefetch).
+template <bool MIX, bool HASMASK, int NROWS, int U>
+__device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const SweepArgs& a, const RowSel& row,
+                                            const float* __restrict__ sdisp, int b, int y, int n0, int x, int HW,
+                                            float Wm1, float rcpWm1) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
+    const float* pl = a.logits + ((long)b * a.N + n) * HW;  // workgroup-uniform
+    if (kAblate & 8) {  // diagnostics: no coordinate chain
+      g.ct[u].x0 = x + n; g.ct[u].w0 = 0.25f; g.ct[u].w1 = 0.75f;
+    } else {
+      g.ct[u] = make_col_tap((float)x + sdisp[n], Wm1, rcpWm1);
+    }
+    g.mval[u] = 1.0f;
+    if (HASMASK && !(kAblate & 16))
+      g.mval[u] = buf_load(row_rsrc(a.padding_mask + ((long)b * a.N + n) * HW + (long)y * a.W, a.W), (unsigned)x << 2);
+    if (kAblate & 1) {  // diagnostics: no logit / sigma loads
+      g.tl[u].a0 = g.tl[u].a1 = g.tl[u].b0 = g.tl[u].b1 = g.ct[u].w0;
+      g.ts[u] = g.tl[u];
+    } else {
+      const TapPos tp = tap_pos(g.ct[u]);
+      g.tl[u] = load_taps<NROWS>(row_rsrc(pl + (long)row.yA * a.W, a.W), row_rsrc(pl + (long)row.yB * a.W, a.W), tp);
+      if (MIX) {
+        const float* ps = a.sigma + ((long)b * a.N + n) * HW;
+        g.ts[u] = load_taps<NROWS>(row_rsrc(ps + (long)row.yA * a.W, a.W), row_rsrc(ps + (long)row.yB * a.W, a.W), tp);
+      }
+    }
+  }
+}
+
+template <bool MIX, bool HASMASK, int NROWS, int U>
+__device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const SweepArgs& a, const RowSel& row,
+                                            const char* __restrict__ lrgb, int b, int n0, int pix, int HW, float t0,
+                                            float t1, float t2, float ea, bool automask, FwdAcc& acc, uint32_t& bits,
+                                            float* __restrict__ stash) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int n = n0 + u;
+    float live = 1.0f;
     if (HASMASK) {  // rec_features * padding_mask (trainer.py:580): a masked plane samples as all-zero features,
-      const bool mk = mval[u] != 0.0f;  // i.e. every tap weight of the plane is zero
+      const bool mk = g.mval[u] != 0.0f;  // i.e. every tap weight of the plane is zero
       if (mk) bits |= 1u << (n & 31);
       if ((n & 31) == 31 || n == a.N - 1) {
         stash[((long)b * a.stash_k + kStashBase + (n >> 5)) * HW + pix] = __uint_as_float(bits);
         bits = 0;
       }
-      ct[u].m0 = mk ? ct[u].m0 : 0.0f;
-      ct[u].m1 = mk ? ct[u].m1 : 0.0f;
+      live = mk ? 1.0f : 0.0f;
     }
-    const float l = tap_value<NROWS>(tl[u], row, ct[u]);
-    const float s = MIX ? tap_value<NROWS>(ts[u], row, ct[u]) : 0.0f;
+    const TapW w = tap_weights<NROWS>(g.ct[u], row, live);
+    const bool edge = (g.ct[u].x0 == -1);
+    Taps<NROWS> tl = g.tl[u], ts = g.ts[u];
+    fix_edge<NROWS>(tl, edge);
+    if (MIX) fix_edge<NROWS>(ts, edge);
+    const float l = tap_value<NROWS>(tl, w);
+    const float s = MIX ? tap_value<NROWS>(ts, w) : 0.0f;
     float c0, c1, c2;
-    colour_taps<NROWS>(lrgb, a.W, row, ct[u], c0, c1, c2);
-    fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+    if (kAblate & 2) { c0 = w.a0; c1 = w.a1; c2 = l; }  // diagnostics: no colour taps
+    else colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W), w, c0, c1, c2);
+    if (kAblate & 4) { acc.Z += l + s; acc.C0 += c0; acc.C1 += c1; acc.C2 += c2; acc.S = 1.0f; acc.m = 0.0f; }  // no softmax/mixture math
+    else fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
   }
 }
 
@@ -245,15 +399,15 @@ template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
                                                   float* __restrict__ rgb_rec, float* __restrict__ ph_map,
                                                   float* __restrict__ stash) {
-  constexpr int U = (NROWS == 1) ? 4 : 2;
-  const int y = blockIdx.x, b = blockIdx.y;
+  constexpr int U = (NROWS == 1) ? PD_FWD_U : (PD_FWD_U > 1 ? PD_FWD_U / 2 : 1);
+  const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
   const int HW = a.H * a.W;
   const bool automask = a.flags & PD_AUTOMASK;
   const float Wm1 = (float)(a.W - 1), rcpWm1 = refined_rcp(Wm1);
   const float* srcb = a.src + (long)b * 3 * HW;
-  stage_colour_rows<NROWS>(lrgb, srcb, HW, a.W, row);
-  for (int i = threadIdx.x; i < a.N; i += blockDim.x) sdisp[i] = a.sign * a.plane[(long)b * a.N + i];
+  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
   __syncthreads();
+  const char* lbytes = reinterpret_cast<const char*>(lrgb);
   for (int x = threadIdx.x; x < a.W; x += blockDim.x) {
     const int pix = y * a.W + x;
     const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
@@ -263,13 +417,29 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
     if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
     FwdAcc acc;
     uint32_t bits = 0;
-    int n = 0;
-    for (; n + U <= a.N; n += U)
-      fwd_group<MIX, HASMASK, NROWS, U>(a, row, lrgb, sdisp, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask,
-                                         acc, bits, stash);
-    for (; n < a.N; ++n)
-      fwd_group<MIX, HASMASK, NROWS, 1>(a, row, lrgb, sdisp, b, n, x, pix, HW, Wm1, rcpWm1, t0, t1, t2, ea, automask,
-                                         acc, bits, stash);
+    // groups of U planes, loads of group i+1 in flight while group i is reduced (ping-pong register sets A / B)
+    PlaneGroup<NROWS, U> ga, gb;
+    const int nfull = a.N / U;  // full groups
+    int gi = 0;
+    if (!PD_FWD_PF) {
+      for (; gi < nfull; ++gi) {
+        group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, gi * U, x, HW, Wm1, rcpWm1);
+        fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+      }
+    } else if (nfull > 0) group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, 0, x, HW, Wm1, rcpWm1);
+    for (; gi + 2 <= nfull; gi += 2) {
+      group_issue<MIX, HASMASK, NROWS, U>(gb, a, row, sdisp, b, y, (gi + 1) * U, x, HW, Wm1, rcpWm1);
+      fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+      if (gi + 2 < nfull) group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, (gi + 2) * U, x, HW, Wm1, rcpWm1);
+      fwd_compute<MIX, HASMASK, NROWS, U>(gb, a, row, lbytes, b, (gi + 1) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+    }
+    if (gi < nfull)  // odd number of full groups: the last one is already in flight in A
+      fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+    for (int n = nfull * U; n < a.N; ++n) {  // remainder planes
+      PlaneGroup<NROWS, 1> g1;
+      group_issue<MIX, HASMASK, NROWS, 1>(g1, a, row, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
+      fwd_compute<MIX, HASMASK, NROWS, 1>(g1, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+    }
     const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
     float* st = stash + (long)b * a.stash_k * HW + pix;
     st[0] = r.lse2;
@@ -284,12 +454,12 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
 }
 
 template <bool MIX, bool HASMASK>
-__global__ __launch_bounds__(kMaxRowThreads) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+__global__ __launch_bounds__(kRowThreadsMax, PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
                                                                      float* __restrict__ stash) {
   extern __shared__ float4 lds4[];
-  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * a.W);
-  const RowSel row = make_row_sel(blockIdx.x, a.H);
+  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
+  const RowSel row = make_row_sel(block_row(blockIdx.x, a.H), a.H);
   if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, 2>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
   else                rowshift_fwd_body<MIX, HASMASK, 1>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
 }
@@ -341,23 +511,13 @@ struct SegCtx {
 };
 
 template <bool MIX, bool HASMASK, int NROWS, int U>
-__device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, const RowSel& row,
-                                          const float4* __restrict__ lrgb, const float* __restrict__ sdisp,
-                                          const int* __restrict__ kshift, float* __restrict__ red,
-                                          float* __restrict__ bnd, int b, int y, int n0,
-                                          const SegCtx& sc, const PixelCtx& c, int HW, float Wm1, float rcpWm1,
-                                          float gix_scale, bool want_plane, uint32_t& bits) {
+__device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const SweepArgs& a, const BwdOut& o,
+                                            const RowSel& row, const char* __restrict__ lrgb,
+                                            const int* __restrict__ kshift, float* __restrict__ red,
+                                            float* __restrict__ bnd, int b, int y, int n0, const SegCtx& sc,
+                                            const PixelCtx& c, int HW, float gix_scale, bool want_plane,
+                                            uint32_t& bits) {
   const int W = a.W, N = a.N;
-  ColTap ct[U];
-  Taps<NROWS> tl[U], ts[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int n = n0 + u;
-    const long pl = ((long)b * N + n) * HW;
-    ct[u] = make_col_tap((float)sc.xt + sdisp[n], Wm1, rcpWm1, W);
-    tl[u] = load_taps<NROWS>(a.logits + pl + (long)row.yA * W, a.logits + pl + (long)row.yB * W, ct[u]);
-    if (MIX) ts[u] = load_taps<NROWS>(a.sigma + pl + (long)row.yA * W, a.sigma + pl + (long)row.yB * W, ct[u]);
-  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
@@ -369,32 +529,42 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
         bits = __float_as_uint((o.stash + ((long)b * a.stash_k + kStashBase + (n >> 5)) * HW)[(unsigned)sc.pix]);
       mk = sc.active && ((bits >> (n & 31)) & 1u);
     }
-    const ColTap& t = ct[u];
+    const ColTap& t = g.ct[u];
+    // forward values (a masked plane contributes nothing to its own gradient, so its samples need no zeroing here)
+    const TapW w = tap_weights<NROWS>(t, row, 1.0f);
     float c0, c1, c2, d0x, d1x, d2x;
-    colour_taps_dx<NROWS>(lrgb, W, row, t, c0, c1, c2, d0x, d1x, d2x);
-    float l = tap_value<NROWS>(tl[u], row, t);
-    float s = MIX ? tap_value<NROWS>(ts[u], row, t) : 0.0f;
+    colour_taps_dx<NROWS>(lrgb, W, colour_off(t.x0, W), w, row, c0, c1, c2, d0x, d1x, d2x);
+    const bool edge = (t.x0 == -1);
+    Taps<NROWS> tl = g.tl[u], ts = g.ts[u];
+    fix_edge<NROWS>(tl, edge);
+    if (MIX) fix_edge<NROWS>(ts, edge);
+    const float l = tap_value<NROWS>(tl, w);
+    const float s = MIX ? tap_value<NROWS>(ts, w) : 0.0f;
     const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    // adjoint of the horizontal gather: contributions to source x0 (weight w0) and x0+1 (weight w1), if inside
+    const bool v0 = (unsigned)t.x0 < (unsigned)W, v1 = (unsigned)(t.x0 + 1) < (unsigned)W;
     const float live = mk ? row.wy_main : 0.0f;   // padding mask x vertical adjoint weight of the own row
-    const int dl = (mk && (t.v0 || t.v1)) ? t.x0 - sc.xt - k : 0;
-    const float gl = pg.g_l * live, gs = pg.g_s * live;
-    const float cl0 = gl * t.m0, cl1 = gl * t.m1, cs0 = gs * t.m0, cs1 = gs * t.m1;
+    const float m0 = v0 ? t.w0 * live : 0.0f, m1 = v1 ? t.w1 * live : 0.0f;
+    const int dl = (mk && (v0 || v1)) ? t.x0 - sc.xt - k : 0;
+    const float cl0 = pg.g_l * m0, cl1 = pg.g_l * m1, cs0 = pg.g_s * m0, cs1 = pg.g_s * m1;
     float gd = 0.0f;
     if (want_plane) {
-      const float dlx = tap_dx<NROWS>(tl[u], row, t);
-      const float dsx = MIX ? tap_dx<NROWS>(ts[u], row, t) : 0.0f;
+      const float dlx = tap_dx<NROWS>(tl, row);
+      const float dsx = MIX ? tap_dx<NROWS>(ts, row) : 0.0f;
       gd = (pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x) * gix_scale;
       gd = mk ? gd : 0.0f;
     }
     const bool regular = __all(dl == 0);
-    int xs = sc.xt + k;                       // the source pixel this slot owns (ring of W slots)
-    xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
-    float* bp = bnd + ((long)sc.seg * N + n) * 6;
+    // the source pixel this slot owns: (xt + k) mod W (ring of W slots); inactive lanes store out of range (dropped)
+    const unsigned xs4 = (unsigned)(sc.xt + k) << 2, W4 = (unsigned)W << 2;
+    const unsigned xw4 = (xs4 < W4) ? xs4 : xs4 + ((k > 0) ? 0u - W4 : W4);
+    const unsigned xoff = sc.active ? xw4 : 0xFFFFFFF0u;
+    float* bp = bnd + (sc.seg * N + n) * 6;
     const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bp);
-    if (sc.active && o.g_logits) (o.g_logits + pl + (long)y * W)[(unsigned)xs] = out_l;
+    if (o.g_logits) buf_store(row_rsrc(o.g_logits + pl + (long)y * W, W), xoff, out_l);
     if (MIX) {
       const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
-      if (sc.active && o.g_sigma) (o.g_sigma + pl + (long)y * W)[(unsigned)xs] = out_s;
+      if (o.g_sigma) buf_store(row_rsrc(o.g_sigma + pl + (long)y * W, W), xoff, out_s);
     }
     if (want_plane) {
       const float v = wave_sum_hi(gd);
@@ -406,22 +576,22 @@ __device__ __forceinline__ void bwd_group(const SweepArgs& a, const BwdOut& o, c
 template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
                                                   float* sdisp, int* kshift, float* red, float* bnd, float4* lrgb) {
-  constexpr int U = (NROWS == 1) ? 2 : 1;
-  const int y = blockIdx.x, b = blockIdx.y;
+  constexpr int U = PD_BWD_U;
+  const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
   const int HW = a.H * a.W, W = a.W, N = a.N;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1), nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: stays in SGPRs
   const int nseg = (W + kWave - 1) / kWave;
   const bool want_plane = (o.g_plane != nullptr);
-  const float* srcb = a.src + (long)b * 3 * HW;
+  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
+  for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
+  __syncthreads();
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     red[i] = 0.0f;
-    const float sd = a.sign * a.plane[(long)b * N + i];
-    sdisp[i] = sd;
-    kshift[i] = (int)fminf(fmaxf(floorf(sd), -(float)W), (float)W);
+    kshift[i] = (int)fminf(fmaxf(floorf(sdisp[i]), -(float)W), (float)W);
   }
-  for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
-  stage_colour_rows<NROWS>(lrgb, srcb, HW, W, row);
   __syncthreads();
+  const char* lbytes = reinterpret_cast<const char*>(lrgb);
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
   const float gix_scale = (Wm1 / 2) * 2.0f / Wm1 * a.sign;  // d ix / d disp through un-normalise, *2, /(W-1)
 
@@ -436,13 +606,29 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     sc.pix = y * W + (sc.active ? sc.xt : 0);
     const PixelCtx c = sc.active ? make_pixel_ctx<MIX>(a, o, b, sc.pix, HW) : zero_pixel_ctx();
     uint32_t bits = 0;
-    int n = 0;
-    for (; n + U <= N; n += U)
-      bwd_group<MIX, HASMASK, NROWS, U>(a, o, row, lrgb, sdisp, kshift, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
-                                         want_plane, bits);
-    for (; n < N; ++n)
-      bwd_group<MIX, HASMASK, NROWS, 1>(a, o, row, lrgb, sdisp, kshift, red, bnd, b, y, n, sc, c, HW, Wm1, rcpWm1, gix_scale,
-                                         want_plane, bits);
+    // same one-group-ahead prefetch as the forward (the mask comes from the stash bits, not from memory)
+    PlaneGroup<NROWS, U> ga, gb;
+    const int nfull = N / U;
+    int gi = 0;
+    if (!PD_BWD_PF) {
+      for (; gi < nfull; ++gi) {
+        group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, gi * U, sc.xt, HW, Wm1, rcpWm1);
+        bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
+      }
+    } else if (nfull > 0) group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, 0, sc.xt, HW, Wm1, rcpWm1);
+    for (; gi + 2 <= nfull; gi += 2) {
+      group_issue<MIX, false, NROWS, U>(gb, a, row, sdisp, b, y, (gi + 1) * U, sc.xt, HW, Wm1, rcpWm1);
+      bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
+      if (gi + 2 < nfull) group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, (gi + 2) * U, sc.xt, HW, Wm1, rcpWm1);
+      bwd_compute<MIX, HASMASK, NROWS, U>(gb, a, o, row, lbytes, kshift, red, bnd, b, y, (gi + 1) * U, sc, c, HW, gix_scale, want_plane, bits);
+    }
+    if (gi < nfull)
+      bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
+    for (int n = nfull * U; n < N; ++n) {
+      PlaneGroup<NROWS, 1> g1;
+      group_issue<MIX, false, NROWS, 1>(g1, a, row, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
+      bwd_compute<MIX, HASMASK, NROWS, 1>(g1, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, bits);
+    }
   }
   __syncthreads();
   // Deferred segment-boundary contributions: record (seg, n, j) targets global slot g (ring), i.e. source (g+k) mod W.
@@ -469,14 +655,14 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
 }
 
 template <bool MIX, bool HASMASK>
-__global__ __launch_bounds__(kMaxRowThreads) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
+__global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
-  // LDS: colour rows float4[2*W] | sdisp[N] | kshift[N] | red[N] | bnd[nseg][N][6]  (6 = 3 records x {logits, sigma})
-  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * a.W);
+  // LDS: colour rows float4[2*(W+4)] | sdisp[N] | kshift[N] | red[N] | bnd[nseg][N][6] (3 records x {logits, sigma})
+  float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);
   float* red = sdisp + 2 * a.N;
   float* bnd = red + a.N;
-  const RowSel row = make_row_sel(blockIdx.x, a.H);
+  const RowSel row = make_row_sel(block_row(blockIdx.x, a.H), a.H);
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }
@@ -504,20 +690,26 @@ __global__ void div_check_kernel(float Wm1, int count, float lo, float step, int
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-// Waves per row-workgroup: a divisor of the number of 64-lane segments (equal work per wave), at most 8, so that
-// several workgroups fit a CU at the kernels' register footprint (e.g. W=640: 10 segments -> 5 waves x 2 segments).
+// Waves per row-workgroup (each wave walks its share of the row's 64-lane segments).
 static int row_threads(int W) {
   const int nseg = ceil_div(W, kWave);
+  if (const char* e = getenv("PD_ROW_WAVES")) {  // tuning hook
+    const int w = atoi(e);
+    if (w >= 1 && w <= 16) return (w < nseg ? w : nseg) * kWave;
+  }
+  // Measured on MI355X (W=640, 10 segments): 4, 5, 8 and 10 waves per workgroup are within 3% of each other, 1-2
+  // waves are 1.5-2.5x slower (too few waves in flight).  Take the largest divisor of nseg up to 8 for equal work
+  // per wave; awkward (prime) segment counts fall back to 8 waves with a ragged last pass.
   int waves = 1;
   for (int w = 1; w <= 8 && w <= nseg; ++w)
     if (nseg % w == 0) waves = w;
-  if (waves < 4 && nseg > 8) waves = 8;  // awkward segment counts (primes): accept a ragged last pass
+  if (waves < 4 && nseg > 8) waves = 8;
   return waves * kWave;
 }
 
 bool rowshift_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
-         (size_t)d->W * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
+         (size_t)(d->W + 4) * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
 }
 
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
@@ -542,7 +734,7 @@ static void allow_lds(K kernel, size_t shmem) {
 int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
                  hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
-  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + (size_t)d->N * sizeof(float);
+  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + (size_t)d->N * sizeof(float);
   PD_ROW_DISPATCH(rowshift_fwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a,
                   rgb_rec, ph_map, stash);
   return check_launch("rowshift_fwd_kernel");
@@ -551,7 +743,7 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
   const int nseg = ceil_div(d->W, kWave);
-  const size_t shmem = (size_t)d->W * 2 * sizeof(float4) + ((size_t)3 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
+  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)3 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
   PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
   int rc = check_launch("rowshift_bwd_kernel");
   if (rc || !o.g_plane) return rc;

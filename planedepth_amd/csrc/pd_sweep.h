@@ -7,6 +7,12 @@
 
 namespace pd {
 
+// Diagnostics only: -DPD_ABLATE=<bits> builds a library that skips parts of the row-shift kernels (scripts/gpu_ablate.sh).
+#ifndef PD_ABLATE
+#define PD_ABLATE 0
+#endif
+constexpr int kAblate = PD_ABLATE;
+
 constexpr int kStashBase = 4;  // lse, S, Mx, flags  (then ceil(N/32) mask words in disp mode)
 constexpr float kSigmaMin = 0.01f, kSigmaMax = 1.0f, kLogEps = 1e-7f, kZMin = 1e-7f;
 
@@ -181,12 +187,12 @@ __device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, floa
     const float g_pi = -c.A * q + gu * inv;
     g.g_l = p * (g_pi + c.A * c.mx);                                                  // softmax backward, closed form
     const float g_sig = -c.A * p * q * (ei * inv - inv) - gu * u * inv;               // d / d sigma_n
-    g.g_s = (s >= kSigmaMin && s <= kSigmaMax) ? g_sig : 0.0f;                        // clamp: grad on [min,max]
+    g.g_s = (s == sg) ? g_sig : 0.0f;  // clamp passes the gradient exactly where it left s untouched ([min,max])
     const float g_e3 = c.A * u * q * (1.0f / 3.0f);                                   // d ph / d e_n, per channel
     const float w = u * c.invS;
-    g.gc0 = c.gr0 * w + g_e3 * sgn(c0 - c.t0);
-    g.gc1 = c.gr1 * w + g_e3 * sgn(c1 - c.t1);
-    g.gc2 = c.gr2 * w + g_e3 * sgn(c2 - c.t2);
+    g.gc0 = c.gr0 * w + g_e3 * sgn_fast(c0 - c.t0);
+    g.gc1 = c.gr1 * w + g_e3 * sgn_fast(c1 - c.t1);
+    g.gc2 = c.gr2 * w + g_e3 * sgn_fast(c2 - c.t2);
   } else {
     g.g_l = p * (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr);
     g.g_s = 0.0f;

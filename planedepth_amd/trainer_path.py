@@ -60,15 +60,21 @@ def pred_novel_images(self, inputs, outputs):
     automask = bool(getattr(opt, "automask", False))
     if getattr(opt, "render_probability", False):
         raise NotImplementedError("render_probability goes through planedepth_amd.ops.plane_sweep_render (see DESIGN.md)")
+    # With xy planes only the decoder's padding mask is torch.ones_like(disp_layered) (networks/depth_decoder.py:157;
+    # zeros only enter with xz/yz planes, :163-207, :224-247).  Reading N*H*W ones is 1/3 of the forward's HBM traffic,
+    # so when the options say there are no xz/yz planes the mask is not read at all.
+    padding_mask = outputs.get("padding_mask")
+    if getattr(opt, "xz_levels", None) == 0 and getattr(opt, "yz_levels", None) == 0:
+        padding_mask = None
     for target_side in self.target_sides:
         tgt = inputs[(cname, target_side)]
         sigma = outputs["sigma"] if mix else None
         if opt.warp_type == "disp_warp":
             rgb_rec, ph_map = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
-                                                   outputs["padding_mask"], target_side=target_side,
+                                                   padding_mask, target_side=target_side,
                                                    use_mixture_loss=mix, automask=automask)
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
-                                 padding_mask=outputs["padding_mask"], target_side=target_side, use_mixture_loss=mix)
+                                 padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix)
         elif opt.warp_type == "homography_warp":
             T = outputs[("Rt", target_side)]
             rgb_rec, ph_map = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma, outputs["distance"],
