@@ -191,46 +191,28 @@ def cpu_baseline(args, budget_s):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm; used for the timing barrier/reduction only
+    from planedepth_amd import parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    rank, world, local_rank = parallel.init_process_group_from_env("nccl")  # RCCL; timing barrier/reduction only
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import __graft_entry__ as entry
     entry.build()
 
-    c = make_batch(args, device, seed=rank)
+    c = make_batch(args, device, seed=rank)  # every rank draws its own shard: no data-path collective
     step, _ = build_step(args, c, device)
-
-    def sync_all():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         step()
-    sync_all()
+    parallel.barrier(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    parallel.barrier(device)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
 
-    total_images = args.batch * world * args.steps
-    value = total_images / elapsed
+    value = parallel.throughput(args.batch, args.steps, world, elapsed)
     result = {
         "metric": "images/sec (warp+loss fwd+bwd), 192x640x49 planes", "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
