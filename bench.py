@@ -138,7 +138,7 @@ def kernel_times(args, c, device, iters):
         C.check(lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
                                        C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(stash),
                                        C.ptr(c["g_rgb_rec"]), C.ptr(gph), C.ptr(gl), C.ptr(gs if mix else None),
-                                       C.ptr(gp), C.ptr(ws), st), "bwd")
+                                       C.ptr(gp), None, C.ptr(ws), st), "bwd")
 
     out = {}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):

@@ -100,13 +100,14 @@ int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tg
  * outputs (each may be NULL to skip it)
  *   g_logits, g_sigma  [B,N,H,W]  — fully overwritten
  *   g_plane            same shape as `plane` (disp: [B,N] or dense [B,N,H,W]; homography: [B*N,3,3]) — overwritten
+ *   g_dists            [B,N-1,H,W] gradient of `dists` (PD_RENDER_PROB only) — overwritten
  *   workspace          pd_sweep_bwd_workspace_floats(d) floats of scratch (only needed when g_plane != NULL)
  */
 int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                        const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                        const float* padding_mask, const float* dists, const float* rgb_rec, const float* stash,
                        const float* g_rgb_rec, const float* g_ph_map, float* g_logits, float* g_sigma, float* g_plane,
-                       float* workspace, pd_stream_t stream);
+                       float* g_dists, float* workspace, pd_stream_t stream);
 
 /*
  * The per-plane tensors the reference stores in `outputs` and the fused path never needs (trainer.py:582-602):

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
   if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
 
+  const bool render = a.flags & PD_RENDER_PROB;
   FwdAcc acc;
+  RenderState rs;
   uint32_t bits = 0;
   for (int n = 0; n < a.N; ++n) {
     bool mk;
@@ -115,9 +117,16 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
       c1 = bilinear(srcb + HW, t, a.W);
       c2 = bilinear(srcb + 2 * HW, t, a.W);
     }
-    fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+    if (render) {
+      const bool last = (n == a.N - 1);
+      const float dist = last ? 0.0f : a.dists[((long)b * (a.N - 1) + n) * HW + pix];
+      const float p = render_prob(rs, render_alpha(l, dist, last));
+      mixture_accumulate<MIX>(acc, p, s, c0, c1, c2, t0, t1, t2, ea, automask);
+    } else {
+      fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+    }
   }
-  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
+  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask, !render);
   float* st = stash + (long)b * a.stash_k * HW + pix;
   st[0] = r.lse2;
   st[HW] = r.Sn;
@@ -156,6 +165,9 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
   const float halfWm1 = (float)(a.W - 1) / 2, halfHm1 = (float)(a.H - 1) / 2;
 
+  const bool render = a.flags & PD_RENDER_PROB;
+  const float Rtot = MIX ? -c.A * c.mx : c.gdotr;  // sum_k p_k dL/dp_k, known in closed form
+  float T = 1.0f, prefix = 0.0f;
   uint32_t bits = 0;
   for (int n = 0; n < a.N; ++n) {
     float gk[K];
@@ -178,7 +190,23 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
         const float c1 = bilinear_vg(srcb + HW, t, a.W, d1x, d1y);
         const float c2 = bilinear_vg(srcb + 2 * HW, t, a.W, d2x, d2y);
         const float s = MIX ? bilinear_vg(a.sigma + pl, t, a.W, dsx, dsy) : 0.0f;
-        const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+        PlaneGrad pg;
+        if (render) {  // alpha compositing: d prob_k / d alpha_n for k >= n through the transmittance (trainer.py:584-591)
+          const bool last = (n == a.N - 1);
+          const float dist = last ? 0.0f : a.dists[((long)b * (a.N - 1) + n) * HW + pix];
+          const float alpha = render_alpha(l, dist, last);
+          const float pn = alpha * T;
+          pg = plane_grad_p<MIX>(c, pn, s, c0, c1, c2);
+          prefix += pg.g_l * pn;
+          const float keep = 1.0f - alpha + 1e-10f;
+          const float g_alpha = pg.g_l * T - (Rtot - prefix) / keep;
+          const float da = (1.0f - alpha);  // d alpha / d (relu(l) * dist)
+          pg.g_l = (!last && l > 0.0f) ? g_alpha * dist * da : 0.0f;
+          if (o.g_dists && !last) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = g_alpha * fmaxf(l, 0.0f) * da;
+          T *= keep;
+        } else {
+          pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+        }
         const float g_l = pg.g_l, g_s = pg.g_s, gc0 = pg.gc0, gc1 = pg.gc1, gc2 = pg.gc2;
         if (MIX && o.g_sigma) bilinear_scatter(o.g_sigma + pl, t, a.W, g_s);
         if (o.g_logits) bilinear_scatter(o.g_logits + pl, t, a.W, g_l);
@@ -202,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
           }
         }
       }
+      if (render && !mk && o.g_dists && n < a.N - 1) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = 0.0f;
       if (dense && want_plane) o.g_plane[pl + pix] = gd_dense;
     }
     if (reduce_plane) {
@@ -251,6 +280,9 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
   const float* srcb = a.src + (long)b * 3 * HW;
   const float iy_disp = (MODE == PD_WARP_DISP) ? normalise_roundtrip((float)y, (float)(a.H - 1)) : 0.0f;
   // pass 1: softmax statistics; pass 2: write
+  const bool render = a.flags & PD_RENDER_PROB;
+  RenderState rs;
+  float Srender = 0.0f;
   float m_run = -INFINITY, Z = 0.0f, S = 0.0f;
   for (int pass = 0; pass < 2; ++pass) {
     const float lse2 = (pass == 1) ? m_run + log2_fast(Z) : 0.0f;
@@ -273,6 +305,26 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
       }
       const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
       const float l2 = l * kLog2e;
+      if (render) {  // alpha compositing needs no normaliser: a single (second) pass
+        if (pass == 0) continue;
+        const bool last = (n == a.N - 1);
+        const float dist = last ? 0.0f : a.dists[((long)b * (a.N - 1) + n) * HW + pix];
+        const float pr = render_prob(rs, render_alpha(l, dist, last));
+        if (o.rgb_rec_layered) {
+          float* q = o.rgb_rec_layered + ((long)b * a.N + n) * 3 * HW + pix;
+          q[0] = c0; q[HW] = c1; q[2 * HW] = c2;
+        }
+        if (o.logit_rec) o.logit_rec[pl + pix] = l;
+        if (MIX) {
+          if (o.sigma_rec) o.sigma_rec[pl + pix] = sg;
+          if (o.pi_rec) o.pi_rec[pl + pix] = pr;
+          if (o.probability_rec) o.probability_rec[pl + pix] = pr / sg;  // normalised by the caller-side sum below
+        } else if (o.probability_rec) {
+          o.probability_rec[pl + pix] = pr;
+        }
+        Srender += pr / sg;
+        continue;
+      }
       if (pass == 0) {
         if (l2 > m_run) {
           const float sc = exp2_fast(m_run - l2);
@@ -299,6 +351,10 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
       }
     }
   }
+  if (render && MIX && o.probability_rec) {  // weights_rec = (pi/sigma) / sum(pi/sigma)  (trainer.py:600-602)
+    const float inv = 1.0f / Srender;
+    for (int n = 0; n < a.N; ++n) o.probability_rec[((long)b * a.N + n) * HW + pix] *= inv;
+  }
 }
 
 }  // namespace pd
@@ -322,16 +378,12 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
     PD_REQUIRE(padding_mask == nullptr, "homography mode computes its own padding mask; pass NULL");
     PD_REQUIRE(!(d->flags & PD_DISP_DENSE), "PD_DISP_DENSE is a disp-mode flag");
   }
-  if (d->flags & PD_RENDER_PROB) {
-    set_error("PD_RENDER_PROB is handled by pd_plane_sweep_render_* (not this entry point)");
-    return PD_ERR_UNSUPPORTED;
-  }
   return PD_OK;
 }
 
 static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                            const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
-                           const float* padding_mask) {
+                           const float* padding_mask, const float* dists = nullptr) {
   SweepArgs a;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
   a.flags = d->flags;
@@ -340,6 +392,7 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr) ? 1 : 0;
   a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
   a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3; a.padding_mask = padding_mask;
+  a.dists = dists;
   return a;
 }
 
@@ -372,12 +425,12 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
                                   const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                                   const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map,
                                   float* stash, pd_stream_t stream) {
-  (void)dists;
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && ph_map && stash, "tgt/rgb_rec/ph_map/stash must not be NULL");
+  PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   // the stash always reserves the mask words in disp mode (pd_sweep_stash_floats); they are written when a mask exists
-  SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d))
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
@@ -390,18 +443,20 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
                                   const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                                   const float* padding_mask, const float* dists, const float* rgb_rec,
                                   const float* stash, const float* g_rgb_rec, const float* g_ph_map, float* g_logits,
-                                  float* g_sigma, float* g_plane, float* workspace, pd_stream_t stream_) {
-  (void)dists;
+                                  float* g_sigma, float* g_plane, float* g_dists, float* workspace,
+                                  pd_stream_t stream_) {
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && stash, "tgt/rgb_rec/stash must not be NULL");
+  PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   const bool dense = (d->flags & PD_DISP_DENSE) != 0;
   PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;
-  SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
+  o.g_dists = (d->flags & PD_RENDER_PROB) ? g_dists : nullptr;
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map;
   if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) return rowshift_bwd(d, ak, o, stream);
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
@@ -428,10 +483,10 @@ extern "C" int pd_plane_sweep_layers(const pd_sweep_desc* d, const float* src, c
                                      const float* inv_K3, const float* padding_mask, const float* dists,
                                      float* rgb_rec_layered, float* logit_rec, float* probability_rec,
                                      float* sigma_rec, float* pi_rec, pd_stream_t stream) {
-  (void)dists;
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
-  SweepArgs a = make_args(d, src, nullptr, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
+  PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
+  SweepArgs a = make_args(d, src, nullptr, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   LayersOut o{rgb_rec_layered, logit_rec, probability_rec, sigma_rec, pi_rec};
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
   PD_DISPATCH(sweep_layers_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,

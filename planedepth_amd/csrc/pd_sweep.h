@@ -30,12 +30,14 @@ struct SweepArgs {
   const float* plane_aux;
   const float* inv_K3;
   const float* padding_mask;
+  const float* dists;  // PD_RENDER_PROB: [B,N-1,H,W] inter-plane distances at the TARGET pixel (trainer.py:587)
 };
 
 struct BwdOut {
   float* g_logits;
   float* g_sigma;
   float* g_plane;   // dense disp: written directly; otherwise via partials
+  float* g_dists;   // PD_RENDER_PROB only (may be NULL)
   float* partials;  // per-block partial sums of the plane-parameter gradient
   const float* rgb_rec;
   const float* stash;
@@ -60,16 +62,21 @@ struct FwdAcc {
 
 // One plane's (masked) samples l, s, c* enter the running sums.  t* = target colour, ea3 = 3 x the identity-
 // reprojection error (sum over channels of |src - tgt|).  Mx / Ma omit the Laplacian's constant 1/2 (applied at the end).
-template <bool MIX>
-__device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, float c0, float c1, float c2, float t0,
-                                               float t1, float t2, float ea3, bool automask) {
+// Unnormalised softmax weight of a plane (and the lazy rescale of everything accumulated so far).
+__device__ __forceinline__ float softmax_weight(FwdAcc& a, float l) {
   const float l2 = l * kLog2e;
   if (l2 - a.m > kRescaleThr) {  // first plane (m = -inf) and rare large jumps only
     const float sc = exp2_fast(a.m - l2);
     a.Z *= sc; a.S *= sc; a.C0 *= sc; a.C1 *= sc; a.C2 *= sc; a.Mx *= sc; a.Ma *= sc;
     a.m = l2;
   }
-  const float p = exp2_fast(l2 - a.m);
+  return exp2_fast(l2 - a.m);
+}
+
+// Accumulate one plane with (unnormalised) probability p.
+template <bool MIX>
+__device__ __forceinline__ void mixture_accumulate(FwdAcc& a, float p, float s, float c0, float c1, float c2, float t0,
+                                                   float t1, float t2, float ea3, bool automask) {
   a.Z += p;
   if (MIX) {
     const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);  // trainer.py:597
@@ -86,6 +93,27 @@ __device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, floa
   }
 }
 
+template <bool MIX>
+__device__ __forceinline__ void fwd_accumulate(FwdAcc& a, float l, float s, float c0, float c1, float c2, float t0,
+                                               float t1, float t2, float ea3, bool automask) {
+  const float p = softmax_weight(a, l);
+  mixture_accumulate<MIX>(a, p, s, c0, c1, c2, t0, t1, t2, ea3, automask);
+}
+
+// --render_probability (trainer.py:584-591): alpha compositing front to back instead of a softmax.
+//   alpha_n = 1 - exp(-relu(l_n) * dists_n) (n < N-1), alpha_{N-1} = 1;  prob_n = alpha_n * prod_{m<n}(1 - alpha_m + 1e-10)
+struct RenderState {
+  float T = 1.0f;  // transmittance in front of the current plane
+};
+__device__ __forceinline__ float render_alpha(float l, float dist, bool last) {
+  return last ? 1.0f : 1.0f - exp2_fast(-kLog2e * fmaxf(l, 0.0f) * dist);
+}
+__device__ __forceinline__ float render_prob(RenderState& r, float alpha) {
+  const float p = alpha * r.T;
+  r.T *= (1.0f - alpha + 1e-10f);
+  return p;
+}
+
 struct FwdResult {
   float r0, r1, r2, ph;
   float lse2, Sn, mx, sel;  // stash: log2-sum-exp2 of the scaled logits, sum(pi/sigma), sum(pi*lap), automask flag
@@ -93,9 +121,9 @@ struct FwdResult {
 
 template <bool MIX>
 __device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float t1, float t2, float ea3,
-                                                bool automask) {
+                                                bool automask, bool normalise = true) {
   FwdResult r;
-  const float invZ = 1.0f / a.Z;
+  const float invZ = normalise ? 1.0f / a.Z : 1.0f;  // render_probability: the weights are used as they are
   r.sel = 0.0f;
   if (MIX) {
     const float invS = 1.0f / a.S;
@@ -115,7 +143,7 @@ __device__ __forceinline__ FwdResult fwd_finish(const FwdAcc& a, float t0, float
     const float ea = ea3 / 3.0f;
     if (automask && ea < r.ph) { r.ph = ea; r.sel = 1.0f; }
   }
-  r.lse2 = a.m + log2_fast(a.Z);
+  r.lse2 = normalise ? a.m + log2_fast(a.Z) : 0.0f;
   return r;
 }
 
@@ -172,10 +200,11 @@ struct PlaneGrad {
   float g_l, g_s, gc0, gc1, gc2;  // d loss / d sampled (logit, sigma, r, g, b) of this plane at this target pixel
 };
 
+// Gradients given the plane's probability p (softmax: pi_n; render: alpha_n T_n).  g.g_l holds d loss / d p here;
+// the caller turns it into the logit gradient.
 template <bool MIX>
-__device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, float s, float c0, float c1, float c2) {
+__device__ __forceinline__ PlaneGrad plane_grad_p(const PixelCtx& c, float p, float s, float c0, float c1, float c2) {
   PlaneGrad g;
-  const float p = exp2_fast(l * kLog2e - c.lse2);  // pi_n
   if (MIX) {
     const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
     const float inv = fast_rcp(sg);
@@ -184,8 +213,7 @@ __device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, floa
     const float ei = e3 * inv * (1.0f / 3.0f);                                        // e / sigma
     const float q = 0.5f * exp2_fast(-kLog2e * ei) * inv;                             // laplacian(e; sigma)
     const float gu = (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr) * c.invS;       // d (g . rgb_rec) / d u_n
-    const float g_pi = -c.A * q + gu * inv;
-    g.g_l = p * (g_pi + c.A * c.mx);                                                  // softmax backward, closed form
+    g.g_l = -c.A * q + gu * inv;                                                      // d loss / d p
     const float g_sig = -c.A * p * q * (ei * inv - inv) - gu * u * inv;               // d / d sigma_n
     g.g_s = (s == sg) ? g_sig : 0.0f;  // clamp passes the gradient exactly where it left s untouched ([min,max])
     const float g_e3 = c.A * u * q * (1.0f / 3.0f);                                   // d ph / d e_n, per channel
@@ -194,10 +222,20 @@ __device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, floa
     g.gc1 = c.gr1 * w + g_e3 * sgn_fast(c1 - c.t1);
     g.gc2 = c.gr2 * w + g_e3 * sgn_fast(c2 - c.t2);
   } else {
-    g.g_l = p * (c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2 - c.gdotr);
+    g.g_l = c.gr0 * c0 + c.gr1 * c1 + c.gr2 * c2;
     g.g_s = 0.0f;
     g.gc0 = c.gr0 * p; g.gc1 = c.gr1 * p; g.gc2 = c.gr2 * p;
   }
+  return g;
+}
+
+// Softmax over planes: sum_k pi_k (d loss / d pi_k) = -A*mx (mixture) or g.rgb_rec (L1), so the softmax backward is
+// g_l = pi_n (g_pi_n - that constant) in one pass.
+template <bool MIX>
+__device__ __forceinline__ PlaneGrad plane_grad(const PixelCtx& c, float l, float s, float c0, float c1, float c2) {
+  const float p = exp2_fast(l * kLog2e - c.lse2);  // pi_n
+  PlaneGrad g = plane_grad_p<MIX>(c, p, s, c0, c1, c2);
+  g.g_l = p * (g.g_l - (MIX ? -c.A * c.mx : c.gdotr));
   return g;
 }
 

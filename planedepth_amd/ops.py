@@ -34,7 +34,7 @@ class _PlaneSweep(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, mode, flags, sign):
+    def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign):
         lib = C.load()
         B, N, H, W = logits.shape
         C.require_gpu_tensor("logits", logits)
@@ -50,8 +50,12 @@ class _PlaneSweep(torch.autograd.Function):
             C.require_gpu_tensor("H_t2s", plane, (B * N, 3, 3))
             C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
             C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
-        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask = map(
-            _contig, (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask))
+        if flags & C.PD_RENDER_PROB:
+            C.require_gpu_tensor("dists", dists, (B, N - 1, H, W))
+        else:
+            dists = None
+        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists = map(
+            _contig, (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists))
         d = _desc(B, N, H, W, mode, flags, sign)
         k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
         rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
@@ -59,10 +63,10 @@ class _PlaneSweep(torch.autograd.Function):
         stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
         with torch.cuda.device(logits.device):
             rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
-                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), None,
+                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                         C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(stash), C.stream_handle(logits.device))
         C.check(rc, "pd_plane_sweep_fwd")
-        ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, rgb_rec, stash)
+        ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
         ctx.cfg = (mode, flags, sign)
         ctx.mark_non_differentiable(stash)
         return rgb_rec, ph_map
@@ -70,7 +74,7 @@ class _PlaneSweep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb_rec, g_ph_map):
         lib = C.load()
-        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, rgb_rec, stash = ctx.saved_tensors
+        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = ctx.saved_tensors
         mode, flags, sign = ctx.cfg
         B, N, H, W = logits.shape
         d = _desc(B, N, H, W, mode, flags, sign)
@@ -79,6 +83,7 @@ class _PlaneSweep(torch.autograd.Function):
         g_logits = torch.empty_like(logits) if need_logits else None
         g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
         g_plane = torch.empty_like(plane) if need_plane else None
+        g_dists = torch.empty_like(dists) if (dists is not None and ctx.needs_input_grad[8]) else None
         ws = None
         if need_plane and not (flags & C.PD_DISP_DENSE):
             ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=logits.device,
@@ -86,17 +91,17 @@ class _PlaneSweep(torch.autograd.Function):
         g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
         with torch.cuda.device(logits.device):
             rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
-                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), None,
+                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                         C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map),
-                                        C.ptr(g_logits), C.ptr(g_sigma), C.ptr(g_plane), C.ptr(ws),
+                                        C.ptr(g_logits), C.ptr(g_sigma), C.ptr(g_plane), C.ptr(g_dists), C.ptr(ws),
                                         C.stream_handle(logits.device))
         C.check(rc, "pd_plane_sweep_bwd")
-        return None, None, g_logits, g_sigma, g_plane, None, None, None, None, None, None
+        return None, None, g_logits, g_sigma, g_plane, None, None, None, g_dists, None, None, None
 
 
-def _flags(use_mixture_loss, automask, dense=False):
+def _flags(use_mixture_loss, automask, dense=False, render=False):
     return ((C.PD_MIXTURE if use_mixture_loss else 0) | (C.PD_AUTOMASK if automask else 0) |
-            (C.PD_DISP_DENSE if dense else 0))
+            (C.PD_DISP_DENSE if dense else 0) | (C.PD_RENDER_PROB if render else 0))
 
 
 _SIGN = {"r": 1.0, "l": -1.0}
@@ -120,7 +125,7 @@ def _per_plane_view(disp_layered):
 
 
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
-                     use_mixture_loss=True, automask=False):
+                     use_mixture_loss=True, automask=False, render_probability=False, dists=None):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
 
     ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
@@ -138,7 +143,8 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
         padding_mask = padding_mask.expand(B, N, H, W)
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
     return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
-                             C.PD_WARP_DISP, _flags(use_mixture_loss, automask, dense=not per_plane), sign)
+                             dists if render_probability else None, C.PD_WARP_DISP,
+                             _flags(use_mixture_loss, automask, dense=not per_plane, render=render_probability), sign)
 
 
 def homography_matrices(d, n, T, K, inv_K):
@@ -159,7 +165,7 @@ def homography_matrices(d, n, T, K, inv_K):
 
 
 def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
-                           automask=False):
+                           automask=False, render_probability=False, dists=None):
     """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
 
     distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
@@ -169,12 +175,13 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
     inv_K3 = inv_K[:, :3, :3]
     return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach(),
-                             inv_K3.detach(), None, C.PD_WARP_HOMOGRAPHY, _flags(use_mixture_loss, automask), 0.0)
+                             inv_K3.detach(), None, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
+                             _flags(use_mixture_loss, automask, render=render_probability), 0.0)
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",
-                       homography=None, use_mixture_loss=True, want=("rgb_rec_layered", "logit_rec",
-                                                                      "probability_rec", "sigma_rec", "pi_rec")):
+                       homography=None, use_mixture_loss=True, render_probability=False, dists=None,
+                       want=("rgb_rec_layered", "logit_rec", "probability_rec", "sigma_rec", "pi_rec")):
     """Materialise the per-plane tensors the reference keeps in ``outputs`` (trainer.py:582-602).  No gradients."""
     lib = C.load()
     B, N, H, W = logits.shape
@@ -186,12 +193,13 @@ def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=No
             plane = (disp_layered[:, :, 0, 0] if per_plane else disp_layered).contiguous()
             aux = k3 = None
             mode, sign = C.PD_WARP_DISP, _SIGN.get(target_side, 0.0)
-            flags = _flags(use_mixture_loss, False, dense=not per_plane)
+            flags = _flags(use_mixture_loss, False, dense=not per_plane, render=render_probability)
             if padding_mask is not None:
                 padding_mask = padding_mask.float().expand(B, N, H, W).contiguous()
         else:
             plane, aux, k3 = (t.contiguous() for t in homography)
-            mode, sign, flags, padding_mask = C.PD_WARP_HOMOGRAPHY, 0.0, _flags(use_mixture_loss, False), None
+            mode, sign, padding_mask = C.PD_WARP_HOMOGRAPHY, 0.0, None
+            flags = _flags(use_mixture_loss, False, render=render_probability)
         dev = logits.device
         out = {}
         shapes = dict(rgb_rec_layered=(B, N, 3, H, W), logit_rec=(B, N, H, W), probability_rec=(B, N, H, W),
@@ -204,7 +212,8 @@ def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=No
         with torch.cuda.device(dev):
             rc = lib.pd_plane_sweep_layers(ctypes.byref(d), C.ptr(src.contiguous()), C.ptr(logits.contiguous()),
                                            C.ptr(_contig(sigma) if use_mixture_loss else None), C.ptr(plane),
-                                           C.ptr(aux), C.ptr(k3), C.ptr(padding_mask), None,
+                                           C.ptr(aux), C.ptr(k3), C.ptr(padding_mask),
+                                           C.ptr(dists.contiguous() if render_probability else None),
                                            C.ptr(out.get("rgb_rec_layered")), C.ptr(out.get("logit_rec")),
                                            C.ptr(out.get("probability_rec")), C.ptr(out.get("sigma_rec")),
                                            C.ptr(out.get("pi_rec")), C.stream_handle(dev))

@@ -58,8 +58,8 @@ def pred_novel_images(self, inputs, outputs):
     src = inputs[(cname, source_side)]
     mix = bool(opt.use_mixture_loss)
     automask = bool(getattr(opt, "automask", False))
-    if getattr(opt, "render_probability", False):
-        raise NotImplementedError("render_probability goes through planedepth_amd.ops.plane_sweep_render (see DESIGN.md)")
+    render = bool(getattr(opt, "render_probability", False))
+    dists = outputs["dists"] if render else None  # trainer.py:585-587: the decoder's inter-plane distances
     # With xy planes only the decoder's padding mask is torch.ones_like(disp_layered) (networks/depth_decoder.py:157;
     # zeros only enter with xz/yz planes, :163-207, :224-247).  Reading N*H*W ones is 1/3 of the forward's HBM traffic,
     # so when the options say there are no xz/yz planes the mask is not read at all.
@@ -72,20 +72,24 @@ def pred_novel_images(self, inputs, outputs):
         if opt.warp_type == "disp_warp":
             rgb_rec, ph_map = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
                                                    padding_mask, target_side=target_side,
-                                                   use_mixture_loss=mix, automask=automask)
+                                                   use_mixture_loss=mix, automask=automask,
+                                                   render_probability=render, dists=dists)
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
-                                 padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix)
+                                 padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix,
+                                 render_probability=render, dists=dists)
         elif opt.warp_type == "homography_warp":
             T = outputs[("Rt", target_side)]
             rgb_rec, ph_map = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma, outputs["distance"],
                                                          outputs["norm"], T, inputs["K"], inputs["inv_K"],
-                                                         use_mixture_loss=mix, automask=automask)
+                                                         use_mixture_loss=mix, automask=automask,
+                                                         render_probability=render, dists=dists)
             with torch.no_grad():
                 ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
                 H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
                                                     ex(inputs["inv_K"]))
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma,
-                                 homography=(H_t2s, Rn, inputs["inv_K"][:, :3, :3]), use_mixture_loss=mix)
+                                 homography=(H_t2s, Rn, inputs["inv_K"][:, :3, :3]), use_mixture_loss=mix,
+                                 render_probability=render, dists=dists)
         else:
             raise NotImplementedError("warp_type %r: the reference's depth_warp branch raises UnboundLocalError "
                                       "(padding_mask is never assigned, trainer.py:533-538/580); use disp_warp or "

@@ -31,6 +31,7 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
     distance = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
     norm = torch.tensor([0.0, 0.0, 1.0], dtype=dtype)[None, None].expand(B, N, -1)
     mix = run.get("use_mixture_loss", True)
+    dists = c["dists"].clone().requires_grad_(True) if run.get("render_probability", False) else None
     # the reference reads the target from inputs[("color", side)]; for side "l" that IS the source image
     tgt = c["color_l"] if run.get("target_side", "r") == "l" else c["color_r"]
     r = orc.warp_and_loss(c["color_l"], tgt, logits, sigma if mix else None,
@@ -38,7 +39,7 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
                           disp_layered=disp_layered, padding_mask=c["padding_mask"], distance=distance, norm=norm,
                           T=Rt, K=c["K"], inv_K=c["inv_K"], use_mixture_loss=mix, automask=run.get("automask", False),
                           mask_novel=c.get("mask_novel"), render_probability=run.get("render_probability", False),
-                          dists=c.get("dists"), sampler=sampler)
+                          dists=dists, sampler=sampler)
     (r["ph_loss"] + (r["rgb_rec"] * c["g_rgb_rec"]).sum()).backward()
     z = torch.zeros_like
     res = dict(rgb_rec=r["rgb_rec"], ph_loss=r["ph_loss"], ph_map=r["ph_map"],
@@ -47,6 +48,8 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
                g_logits=logits.grad, g_sigma=sigma.grad if sigma.grad is not None else z(sigma),
                g_disp_pp=disp_pp.grad if disp_pp.grad is not None else z(disp_pp),
                g_Rt=Rt.grad if Rt.grad is not None else z(Rt))
+    if dists is not None:
+        res["g_dists"] = dists.grad if dists.grad is not None else z(dists)
     if mix:
         res["sigma_rec"] = r["sweep"]["sigma_rec"]
         res["pi_rec"] = r["sweep"]["pi_rec"]

@@ -30,6 +30,10 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
                ("Rt", side): Rt, "disp": torch.zeros(B, 1, H, W, device=device)}
     if "mask_novel" in c:
         outputs["mask_novel"] = c["mask_novel"]
+    dists = None
+    if run.get("render_probability", False):
+        dists = c["dists"].clone().requires_grad_(True)
+        outputs["dists"] = dists
     opt = types.SimpleNamespace(warp_type=warp, match_aug=False, use_mixture_loss=mix, automask=run.get("automask", False),
                                 render_probability=run.get("render_probability", False), alpha_pc=0.0, alpha_self=0.0,
                                 self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=True,
@@ -45,6 +49,8 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
                g_logits=logits.grad, g_sigma=sigma.grad if sigma.grad is not None else z(sigma),
                g_disp_pp=disp_pp.grad if disp_pp.grad is not None else z(disp_pp),
                g_Rt=Rt.grad if Rt.grad is not None else z(Rt))
+    if dists is not None:
+        res["g_dists"] = dists.grad if dists.grad is not None else z(dists)
     for k in ("rgb_rec_layered", "logit_rec", "probability_rec", "sigma_rec", "pi_rec"):
         if (k, side) in outputs:
             res[k] = outputs[(k, side)]

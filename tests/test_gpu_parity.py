@@ -14,7 +14,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-NOT_YET = {"disp_mix_render"}  # render_probability: separate entry point
+NOT_YET = set()
 # Ill-conditioned quantities (the oracle itself disagrees fp32 vs fp64 by O(1) on them — see DESIGN.md "knife edges"):
 #  * stereo homography: every sample row sits exactly on an integer y, where d(bilinear)/dy is discontinuous, so the
 #    y-rows of g_Rt depend on the last ulp of iy.
@@ -59,6 +59,12 @@ def test_dense_disparity_path_matches_per_plane_path(name):
      dict(warp_type="homography_warp", use_mixture_loss=False, automask=True)),
     (205, dict(B=3, N=5, H=17, W=66, disp_min=0.5, disp_max=20.0), dict(use_mixture_loss=False, target_side="l")),
     (206, dict(B=1, N=70, H=16, W=64, disp_min=0.5, disp_max=30.0, n_xz=20), dict()),  # > 64 planes: 3 mask words
+    (207, dict(B=2, N=8, H=17, W=66, disp_min=0.5, disp_max=20.0, render_probability=True),
+     dict(render_probability=True, automask=True)),
+    (208, dict(B=1, N=6, H=17, W=66, disp_min=0.5, disp_max=20.0, render_probability=True, n_xz=2),
+     dict(render_probability=True, use_mixture_loss=False)),
+    (209, dict(B=1, N=6, H=24, W=80, disp_min=0.5, disp_max=20.0, render_probability=True, stereo_T=False),
+     dict(render_probability=True, warp_type="homography_warp")),
 ])
 def test_random_cases_vs_oracle(seed, kw, run):
     """Ragged sizes (W not a multiple of 64, odd H), many planes, against the oracle (fp32, the reference's arithmetic).
@@ -105,7 +111,7 @@ def test_homography_kernel_with_pinned_matrices(mix, automask):
                     Hm.to(dev).requires_grad_(True))
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if automask else 0)
     rgb, ph = ops._PlaneSweep.apply(case["color_l"].to(dev), case["color_r"].to(dev), lgd, sgd if mix else None, Hd,
-                                    Rn64.float().reshape(B * N, 3).to(dev), case["inv_K"][:, :3, :3].to(dev), None, C.PD_WARP_HOMOGRAPHY,
+                                    Rn64.float().reshape(B * N, 3).to(dev), case["inv_K"][:, :3, :3].to(dev), None, None, C.PD_WARP_HOMOGRAPHY,
                                     flags, 0.0)
     (ph.mean() + (rgb * case["g_rgb_rec"].to(dev)).sum()).backward()
     assert rel_err(rgb.detach().cpu(), r["rgb_rec"].detach().float()) < TOL
