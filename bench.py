@@ -53,7 +53,8 @@ def parse():
 def make_batch(args, device, seed):
     from planedepth_amd.synthetic import survey_fullsize_case
     torch.manual_seed(seed)
-    c = survey_fullsize_case(B=args.batch, N=args.planes, H=args.height, W=args.width, seed=1234 + seed)
+    c = survey_fullsize_case(B=args.batch, N=args.planes + args.xz_levels, H=args.height, W=args.width,
+                             seed=1234 + seed, n_xz=args.xz_levels)
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in c.items()}
 
 
@@ -84,8 +85,11 @@ def build_step(args, c, device):
 
     def step():
         logits.grad = sigma.grad = disp_pp.grad = None
+        disp_layered = disp_pp.expand(-1, -1, H, W)
+        if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182)
+            disp_layered = disp_layered * c["row_gain"]
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
-                   "disp_layered": disp_pp.expand(-1, -1, H, W), "padding_mask": pm_arg,
+                   "disp_layered": disp_layered, "padding_mask": pm_arg,
                    "distance": 0.1 * 0.58 * W / disp_pp[:, :, 0, 0], "norm": norm, ("Rt", "r"): Rt}
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
@@ -100,7 +104,7 @@ def build_step(args, c, device):
 def algorithmic_bytes(args):
     """per image per target side, fp32.  mixture: fwd (2N+9) HW 4, bwd (4N+9) HW 4."""
     HW = args.height * args.width
-    N = args.planes
+    N = args.planes + args.xz_levels
     k = 2 if not args.no_mixture else 1
     fwd = (k * N + 9) * HW * 4
     bwd = (2 * k * N + 9) * HW * 4
@@ -113,8 +117,8 @@ def kernel_times(args, c, device, iters):
     lib = C.load()
     B, N, H, W = c["logits"].shape
     mix = not args.no_mixture
-    if args.warp_type != "disp_warp":
-        return None
+    if args.warp_type != "disp_warp" or args.xz_levels:
+        return None  # direct-launch timing is wired for the headline configuration only
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
     d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, 0)
     plane = c["disp_pp"][:, :, 0, 0].contiguous()
@@ -220,9 +224,9 @@ def main():
         "config": {"workload": "BASELINE configs[1]: %s, stereo target r, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
                                % (args.warp_type, "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
-                                  args.height, args.width, args.planes),
-                   "global_batch": args.batch * world, "planes": args.planes, "height": args.height,
-                   "width": args.width, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+                                  args.height, args.width, args.planes + args.xz_levels),
+                   "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
+                   "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
                    "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
                    if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask"},
     }

@@ -44,7 +44,9 @@ enum pd_sweep_flags {
   PD_MIXTURE = 1,     /* opt.use_mixture_loss: sigma channel, Laplacian-mixture NLL (trainer.py:594-602, 728-730) */
   PD_AUTOMASK = 2,    /* opt.automask: min with the identity-reprojection loss (trainer.py:731-734, 739-741)      */
   PD_RENDER_PROB = 4, /* opt.render_probability: alpha compositing instead of softmax (trainer.py:584-591)        */
-  PD_DISP_DENSE = 8   /* disp mode: `plane` is a dense [B,N,H,W] map (xz/yz planes) instead of [B,N] scalars      */
+  PD_DISP_DENSE = 8,  /* disp mode: `plane` is a dense [B,N,H,W] map (xz/yz planes) instead of [B,N] scalars      */
+  PD_DISP_ROWS = 16   /* disp mode: `plane` is [B,N,H], one disparity per plane and ROW (xy + xz planes: the decoder's
+                         map is constant along x, depth_decoder.py:153-181).  Only where pd_sweep_uses_rowshift() */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
@@ -64,6 +66,9 @@ typedef struct pd_sweep_desc {
 int pd_version(void);
 const char* pd_last_error(void);
 
+/* 1 if this descriptor is served by the row-shift kernels (PD_WARP_DISP, scalar or per-row disparities), else 0. */
+int pd_sweep_uses_rowshift(const pd_sweep_desc* d);
+
 /* Floats per image the forward pass stashes for the backward pass (softmax statistics + mask bits). */
 size_t pd_sweep_stash_floats(const pd_sweep_desc* d);
 /* Floats of scratch pd_plane_sweep_bwd needs for its per-block partial reductions of the plane-parameter gradient. */
@@ -75,7 +80,8 @@ size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d);
  *
  *   src, tgt      [B,3,H,W]  source colour (inputs[(color,"l")]) and target colour
  *   logits        [B,N,H,W]  outputs["logits"];  sigma [B,N,H,W] outputs["sigma"] (NULL unless PD_MIXTURE)
- *   plane         PD_WARP_DISP:       outputs["disp_layered"] as [B,N] (or [B,N,H,W] with PD_DISP_DENSE)
+ *   plane         PD_WARP_DISP:       outputs["disp_layered"] as [B,N] ([B,N,H,W] with PD_DISP_DENSE, [B,N,H] with
+ *                                     PD_DISP_ROWS)
  *                 PD_WARP_HOMOGRAPHY: H_t2s [B*N,3,3] (layers.py:219)
  *   plane_aux     PD_WARP_HOMOGRAPHY: R·n [B*N,3] (layers.py:223); else NULL
  *   inv_K3        PD_WARP_HOMOGRAPHY: inv_K[:, :3, :3] as [B,3,3]; else NULL

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth_hip.so")  # PD_LIB: diagnostics builds
 
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
-PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE = 1, 2, 4, 8
+PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS = 1, 2, 4, 8, 16
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_IMPL_AUTO, PD_IMPL_GENERAL = 0, 1
 
@@ -33,6 +33,7 @@ _D = ctypes.POINTER(SweepDesc)
 SIGNATURES = {
     "pd_version": (_I, []),
     "pd_last_error": (ctypes.c_char_p, []),
+    "pd_sweep_uses_rowshift": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
     "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),
     "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 13),

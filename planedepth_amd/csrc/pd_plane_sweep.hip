@@ -376,7 +376,12 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
   if (d->mode == PD_WARP_HOMOGRAPHY) {
     PD_REQUIRE(plane_aux && inv_K3, "homography mode needs plane_aux (R n) and inv_K3");
     PD_REQUIRE(padding_mask == nullptr, "homography mode computes its own padding mask; pass NULL");
-    PD_REQUIRE(!(d->flags & PD_DISP_DENSE), "PD_DISP_DENSE is a disp-mode flag");
+    PD_REQUIRE(!(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)), "PD_DISP_DENSE / PD_DISP_ROWS are disp-mode flags");
+  }
+  PD_REQUIRE(!((d->flags & PD_DISP_DENSE) && (d->flags & PD_DISP_ROWS)), "PD_DISP_DENSE and PD_DISP_ROWS exclude each other");
+  if ((d->flags & PD_DISP_ROWS) && !pd_sweep_uses_rowshift(d)) {
+    set_error("PD_DISP_ROWS is served by the row-shift kernels only (pd_sweep_uses_rowshift); pass a dense map instead");
+    return PD_ERR_UNSUPPORTED;
   }
   return PD_OK;
 }
@@ -394,6 +399,12 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3; a.padding_mask = padding_mask;
   a.dists = dists;
   return a;
+}
+
+int pd_sweep_uses_rowshift(const pd_sweep_desc* d);
+
+extern "C" int pd_sweep_uses_rowshift(const pd_sweep_desc* d) {
+  return (d && d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) ? 1 : 0;
 }
 
 extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
@@ -449,7 +460,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && stash, "tgt/rgb_rec/stash must not be NULL");
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
-  const bool dense = (d->flags & PD_DISP_DENSE) != 0;
+  const bool dense = (d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)) != 0;
   PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;

@@ -312,8 +312,10 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
     if (NROWS == 2) lrgb[RS + g] = z;
   }
   const float lim = (float)(W + 2);
+  const int yrow = block_row(blockIdx.x, a.H);
   for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
-    const float sd = a.sign * a.plane[(long)b * a.N + i];
+    const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
+    const float sd = a.sign * a.plane[di];
     sdisp[i] = (sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f) ? -lim : lim);  // NaN -> +lim: out of view
   }
 }
@@ -649,8 +651,12 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     unsafeAtomicAdd(dst + ((long)b * N + n) * HW + (long)y * W + xs, v);
   }
   if (want_plane) {
-    float* dstp = o.partials + ((long)b * a.H + y) * N;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) dstp[i] = red[i];
+    if (a.flags & PD_DISP_ROWS) {  // one disparity per (plane, row): this workgroup owns the whole sum
+      for (int i = threadIdx.x; i < N; i += blockDim.x) o.g_plane[((long)b * N + i) * a.H + y] = red[i];
+    } else {
+      float* dstp = o.partials + ((long)b * a.H + y) * N;
+      for (int i = threadIdx.x; i < N; i += blockDim.x) dstp[i] = red[i];
+    }
   }
 }
 
@@ -746,7 +752,7 @@ int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hi
   const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)3 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
   PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
   int rc = check_launch("rowshift_bwd_kernel");
-  if (rc || !o.g_plane) return rc;
+  if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
   reduce_rows_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);
   return check_launch("reduce_rows_kernel");
 }

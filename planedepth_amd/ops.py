@@ -13,6 +13,7 @@ from . import _capi as C
 # Kernel selection for the sweep (C.PD_IMPL_AUTO | C.PD_IMPL_GENERAL).  Tests flip it to cross-check the specialised
 # row-shift kernels against the general ones; leave it alone otherwise.
 SWEEP_IMPL = C.PD_IMPL_AUTO
+LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 
 
 def _desc(B, N, H, W, mode, flags, sign):
@@ -35,6 +36,8 @@ class _PlaneSweep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign):
+        global LAST_SWEEP_FLAGS
+        LAST_SWEEP_FLAGS = flags
         lib = C.load()
         B, N, H, W = logits.shape
         C.require_gpu_tensor("logits", logits)
@@ -43,7 +46,8 @@ class _PlaneSweep(torch.autograd.Function):
         if flags & C.PD_MIXTURE:
             C.require_gpu_tensor("sigma", sigma, (B, N, H, W))
         if mode == C.PD_WARP_DISP:
-            C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else (B, N))
+            C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else
+                                 ((B, N, H) if flags & C.PD_DISP_ROWS else (B, N)))
             if padding_mask is not None:
                 C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H, W))
         else:
@@ -85,7 +89,7 @@ class _PlaneSweep(torch.autograd.Function):
         g_plane = torch.empty_like(plane) if need_plane else None
         g_dists = torch.empty_like(dists) if (dists is not None and ctx.needs_input_grad[8]) else None
         ws = None
-        if need_plane and not (flags & C.PD_DISP_DENSE):
+        if need_plane and not (flags & (C.PD_DISP_DENSE | C.PD_DISP_ROWS)):
             ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=logits.device,
                              dtype=torch.float32)
         g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
@@ -99,9 +103,9 @@ class _PlaneSweep(torch.autograd.Function):
         return None, None, g_logits, g_sigma, g_plane, None, None, None, g_dists, None, None, None
 
 
-def _flags(use_mixture_loss, automask, dense=False, render=False):
+def _flags(use_mixture_loss, automask, dense=False, render=False, rows=False):
     return ((C.PD_MIXTURE if use_mixture_loss else 0) | (C.PD_AUTOMASK if automask else 0) |
-            (C.PD_DISP_DENSE if dense else 0) | (C.PD_RENDER_PROB if render else 0))
+            (C.PD_DISP_DENSE if dense else 0) | (C.PD_RENDER_PROB if render else 0) | (C.PD_DISP_ROWS if rows else 0))
 
 
 _SIGN = {"r": 1.0, "l": -1.0}
@@ -125,18 +129,29 @@ def _per_plane_view(disp_layered):
 
 
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
-                     use_mixture_loss=True, automask=False, render_probability=False, dists=None):
+                     use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
 
     ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
     ``[B,N,1,1] -> [B,N,H,W]`` (xy planes only; detected from its strides and passed as ``[B,N]`` without ever
-    being materialised) or a dense ``[B,N,H,W]`` map (xz / yz planes present).
+    being materialised) or a dense ``[B,N,H,W]`` map (xz / yz planes present).  ``row_uniform=True`` promises that a
+    dense map is constant along x (true for xy and xz planes: networks/depth_decoder.py:153-181 build them from the
+    y-grid only; false once yz planes exist): its first column is then used as ``[B,N,H]`` per-row disparities, which
+    keeps the row-shift kernels applicable.
     """
     B, N, H, W = logits.shape
     if tuple(disp_layered.shape) != (B, N, H, W):
         disp_layered = disp_layered.expand(B, N, H, W)
     per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
-    plane = _per_plane_view(disp_layered) if per_plane else disp_layered
+    rows = False
+    if per_plane:
+        plane = _per_plane_view(disp_layered)
+    elif row_uniform and not render_probability:
+        probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS, 1.0, SWEEP_IMPL)
+        rows = bool(C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)))
+        plane = disp_layered[..., 0] if rows else disp_layered
+    else:
+        plane = disp_layered
     if padding_mask is not None and padding_mask.dtype != torch.float32:
         padding_mask = padding_mask.float()
     if padding_mask is not None and tuple(padding_mask.shape) != (B, N, H, W):
@@ -144,7 +159,8 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
     return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
                              dists if render_probability else None, C.PD_WARP_DISP,
-                             _flags(use_mixture_loss, automask, dense=not per_plane, render=render_probability), sign)
+                             _flags(use_mixture_loss, automask, dense=not (per_plane or rows), render=render_probability,
+                                    rows=rows), sign)
 
 
 def homography_matrices(d, n, T, K, inv_K):
@@ -190,7 +206,7 @@ def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=No
             if tuple(disp_layered.shape) != (B, N, H, W):
                 disp_layered = disp_layered.expand(B, N, H, W)
             per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
-            plane = (disp_layered[:, :, 0, 0] if per_plane else disp_layered).contiguous()
+            plane = (disp_layered[:, :, 0, 0] if per_plane else disp_layered).contiguous()  # layers: general kernels
             aux = k3 = None
             mode, sign = C.PD_WARP_DISP, _SIGN.get(target_side, 0.0)
             flags = _flags(use_mixture_loss, False, dense=not per_plane, render=render_probability)

@@ -70,7 +70,7 @@ def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False
     return case
 
 
-def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=False):
+def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=False, n_xz=0):
     """Inputs exactly as SURVEY.md §8(c) C-golden / BASELINE.md §3 describe them (seed 1234, that draw order)."""
     g = torch.Generator().manual_seed(seed)
     color_l = torch.rand(B, 3, H, W, generator=g)
@@ -85,6 +85,11 @@ def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=Fals
     Rt = torch.eye(4)[None].repeat(B, 1, 1)
     Rt[:, 0, 3] = -0.1
     g2 = torch.Generator().manual_seed(4321)
+    row_gain, padding_mask = torch.ones(1, N, H, 1), torch.ones(B, N, H, W)
+    if n_xz:  # the last n_xz planes act as ground (xz) planes: disparity grows with the row, masked above the horizon
+        ycoord = torch.linspace(-1, 1, H)[None, None, :, None]
+        row_gain[:, N - n_xz:] = (0.4 + 0.6 * ycoord.clamp_min(0.0)).expand(1, n_xz, H, 1)
+        padding_mask[:, N - n_xz:] = (ycoord >= 1e-7).float().expand(B, n_xz, H, W)
     return dict(color_l=color_l, color_r=color_r, logits=logits, sigma=sigma, disp_pp=disp_pp,
-                row_gain=torch.ones(1, N, H, 1), padding_mask=torch.ones(B, N, H, W), K=K, inv_K=inv_K, Rt=Rt,
-                g_rgb_rec=torch.randn(B, 3, H, W, generator=g2) * 1e-5, dense_disp=False)
+                row_gain=row_gain, padding_mask=padding_mask, K=K, inv_K=inv_K, Rt=Rt,
+                g_rgb_rec=torch.randn(B, 3, H, W, generator=g2) * 1e-5, dense_disp=bool(n_xz))

@@ -66,6 +66,8 @@ def pred_novel_images(self, inputs, outputs):
     padding_mask = outputs.get("padding_mask")
     if getattr(opt, "xz_levels", None) == 0 and getattr(opt, "yz_levels", None) == 0:
         padding_mask = None
+    # xy and xz planes have disparities that are constant along x (depth_decoder.py:153-181); yz planes do not (:221-236)
+    row_uniform = getattr(opt, "yz_levels", None) == 0
     for target_side in self.target_sides:
         tgt = inputs[(cname, target_side)]
         sigma = outputs["sigma"] if mix else None
@@ -73,7 +75,7 @@ def pred_novel_images(self, inputs, outputs):
             rgb_rec, ph_map = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
                                                    padding_mask, target_side=target_side,
                                                    use_mixture_loss=mix, automask=automask,
-                                                   render_probability=render, dists=dists)
+                                                   render_probability=render, dists=dists, row_uniform=row_uniform)
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
                                  padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix,
                                  render_probability=render, dists=dists)

@@ -7,7 +7,7 @@ import planedepth_amd
 from planedepth_amd import ops
 
 
-def run_product(case, run, device="cuda", force_dense=False, through_trainer=True):
+def run_product(case, run, device="cuda", force_dense=False, through_trainer=True, opt_extra=None):
     """Same contract as cases.run_oracle / make_golden.run_reference, but on the GPU through the product API."""
     c = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in case.items()}
     B, N, H, W = c["logits"].shape
@@ -37,7 +37,7 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
     opt = types.SimpleNamespace(warp_type=warp, match_aug=False, use_mixture_loss=mix, automask=run.get("automask", False),
                                 render_probability=run.get("render_probability", False), alpha_pc=0.0, alpha_self=0.0,
                                 self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=True,
-                                materialize_layers=True)
+                                materialize_layers=True, **(opt_extra or {}))
     ns = types.SimpleNamespace(opt=opt, target_sides=[side],
                                perceptual_loss=lambda *a, **k: torch.zeros((), device=device))
     planedepth_amd.pred_novel_images(ns, inputs, outputs)

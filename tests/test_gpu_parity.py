@@ -157,6 +157,19 @@ def test_rowshift_kernels_vs_general_kernels_and_oracle(W, side, disps):
         assert rel_err(fast[k], slow[k]) < 3e-5, (k, rel_err(fast[k], slow[k]))
 
 
+@pytest.mark.parametrize("name", ["disp_mix_xz", "disp_mix_r", "disp_mix_automask", "disp_mix_integer_d"])
+def test_per_row_disparities_use_the_rowshift_kernels(name):
+    """opt.yz_levels == 0 promises row-uniform disparity maps: dense maps (xz planes, horizon mask) then go through the
+    row-shift kernels as [B,N,H] per-row disparities; same golden vectors, incl. the gradient w.r.t. the plane levels."""
+    from gpu_cases import run_product
+    case, want, run = load_fixture(name)
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    got = run_product(case, run, force_dense=True, opt_extra=dict(yz_levels=0, xz_levels=3))
+    assert ops.LAST_SWEEP_FLAGS & C.PD_DISP_ROWS
+    _compare(got, want, tag=name + "/rows")
+
+
 def test_fast_division_is_exact():
     """The row-shift kernels divide by (W-1) with a refined reciprocal + one correction step; the sampling position
     must not move by a single ulp relative to the reference's IEEE division, so compare bit patterns exhaustively over
