@@ -158,6 +158,21 @@ def kernel_times(args, c, device, iters):
     return out
 
 
+def measured_traffic(args, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if they were taken on this
+    exact workload; None otherwise (bench.py cannot run the profiler around itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        same = (w["batch"] == args.batch and w["planes"] == args.planes and w["height"] == args.height and
+                w["width"] == args.width and w["mixture"] == (not args.no_mixture) and args.xz_levels == 0 and
+                not args.automask and args.warp_type == "disp_warp")
+        return int(t[kernel]) if same else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, budget_s):
     """The oracle (port of the reference's op-by-op PyTorch path) on the host cores: B=1 sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -237,9 +252,10 @@ def main():
             dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
             per_launch = (bwd_b if dom == "bwd" else fwd_b) * args.batch
             ach = per_launch / (kt[dom] * 1e-3) / 1e9
+            traffic = measured_traffic(args, "pd_plane_sweep_" + dom)
             result["roofline"] = {"bound": "hbm", "kernel": "pd_plane_sweep_" + dom, "achieved": round(ach, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                  "traffic": None, "algorithmic_bytes_per_launch": per_launch,
+                                  "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
                                   "avg_launch_ms": round(kt[dom], 4)}
             result["kernels"] = {
                 "fwd_ms": round(kt["fwd"], 4), "bwd_ms": round(kt["bwd"], 4),
