@@ -45,6 +45,7 @@ def parse():
                     help="reference option: 0 (BASELINE's '49 planes') lets the path skip the decoder's all-ones padding "
                          "mask; >0 feeds it as a dense [B,N,H,W] tensor like the decoder with ground planes does")
     ap.add_argument("--no_padding_mask", action="store_true", help="never pass a padding mask (diagnostics)")
+    ap.add_argument("--no_plane_grad", action="store_true", help="diagnostics: disparities do not require grad")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
@@ -65,7 +66,7 @@ def build_step(args, c, device):
     mix = not args.no_mixture
     logits = c["logits"].clone().requires_grad_(True)
     sigma = c["sigma"].clone().requires_grad_(True)
-    disp_pp = c["disp_pp"].clone().requires_grad_(True)  # per-plane disparities incl. the learnt residual
+    disp_pp = c["disp_pp"].clone().requires_grad_(not args.no_plane_grad)  # per-plane disparities incl. the learnt residual
     Rt = c["Rt"].clone()
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
                                 render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
@@ -142,7 +143,7 @@ def kernel_times(args, c, device, iters):
         C.check(lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
                                        C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(stash),
                                        C.ptr(c["g_rgb_rec"]), C.ptr(gph), C.ptr(gl), C.ptr(gs if mix else None),
-                                       C.ptr(gp), None, C.ptr(ws), st), "bwd")
+                                       C.ptr(None if args.no_plane_grad else gp), None, C.ptr(ws), st), "bwd")
 
     out = {}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):

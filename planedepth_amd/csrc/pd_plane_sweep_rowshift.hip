@@ -46,16 +46,19 @@ constexpr int kMaxRowThreads = 1024;
 #define PD_FWD_PF 1
 #endif
 #ifndef PD_FWD_OCC
-#define PD_FWD_OCC 4
+#define PD_FWD_OCC 3
 #endif
 #ifndef PD_BWD_U
 #define PD_BWD_U 2
+#endif
+#ifndef PD_PF_DEPTH
+#define PD_PF_DEPTH 2  // groups in the software pipeline (2: one group ahead, colour taps prefetched too; 3: two ahead)
 #endif
 #ifndef PD_BWD_PF
 #define PD_BWD_PF 1
 #endif
 #ifndef PD_BWD_OCC
-#define PD_BWD_OCC 4
+#define PD_BWD_OCC 3
 #endif
 constexpr int kVariant = PD_VARIANT;
 constexpr int kRowThreadsMax = 512;  // row workgroups use <= 8 waves (row_threads)
@@ -247,6 +250,51 @@ __device__ __forceinline__ unsigned colour_off(int x0, int W) {
   return (unsigned)(xc + 2) << 4;
 }
 
+// Raw colour taps of one plane (read from LDS in the issue phase, so their latency overlaps like the global loads')
+template <int NROWS>
+struct ColourTaps {
+  float4 nw, ne, sw, se;
+};
+
+template <int NROWS>
+__device__ __forceinline__ ColourTaps<NROWS> load_colour_taps(const char* __restrict__ lrgb, int W, unsigned off) {
+  ColourTaps<NROWS> c;
+  c.nw = *reinterpret_cast<const float4*>(lrgb + off);
+  c.ne = *reinterpret_cast<const float4*>(lrgb + off + 16);
+  if (NROWS == 2) {
+    const unsigned rb = (unsigned)(W + 4) << 4;
+    c.sw = *reinterpret_cast<const float4*>(lrgb + rb + off);
+    c.se = *reinterpret_cast<const float4*>(lrgb + rb + off + 16);
+  }
+  return c;
+}
+
+template <int NROWS>
+__device__ __forceinline__ void colour_values(const ColourTaps<NROWS>& t, const TapW& w, float& c0, float& c1,
+                                              float& c2) {
+  c0 = t.nw.x * w.a0 + t.ne.x * w.a1;
+  c1 = t.nw.y * w.a0 + t.ne.y * w.a1;
+  c2 = t.nw.z * w.a0 + t.ne.z * w.a1;
+  if (NROWS == 2) {
+    c0 += t.sw.x * w.b0 + t.se.x * w.b1;
+    c1 += t.sw.y * w.b0 + t.se.y * w.b1;
+    c2 += t.sw.z * w.b0 + t.se.z * w.b1;
+  }
+}
+
+template <int NROWS>
+__device__ __forceinline__ void colour_dx(const ColourTaps<NROWS>& t, const RowSel& r, float& d0, float& d1,
+                                          float& d2) {
+  d0 = (t.ne.x - t.nw.x) * r.wA;
+  d1 = (t.ne.y - t.nw.y) * r.wA;
+  d2 = (t.ne.z - t.nw.z) * r.wA;
+  if (NROWS == 2) {
+    d0 += (t.se.x - t.sw.x) * r.wB;
+    d1 += (t.se.y - t.sw.y) * r.wB;
+    d2 += (t.se.z - t.sw.z) * r.wB;
+  }
+}
+
 template <int NROWS>
 __device__ __forceinline__ void colour_taps(const char* __restrict__ lrgb, int W, unsigned off, const TapW& w,
                                             float& c0, float& c1, float& c2) {
@@ -329,6 +377,9 @@ template <int NROWS, int U>
 struct PlaneGroup {
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
+#if PD_PF_DEPTH == 2
+  ColourTaps<NROWS> tc[U];  // LDS colour taps ride along with the global loads (their latency overlaps too)
+#endif
   float mval[U];
 };
 
@@ -336,17 +387,20 @@ struct PlaneGroup {
 // the arithmetic of the previous group — one-group-ahead software prefetch).
 template <bool MIX, bool HASMASK, int NROWS, int U>
 __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const SweepArgs& a, const RowSel& row,
-                                            const float* __restrict__ sdisp, int b, int y, int n0, int x, int HW,
-                                            float Wm1, float rcpWm1) {
+                                            const char* __restrict__ lrgb, const float* __restrict__ sdisp, int b,
+                                            int y, int n0, int x, int HW, float Wm1, float rcpWm1) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
     const float* pl = a.logits + ((long)b * a.N + n) * HW;  // workgroup-uniform
-    if (kAblate & 8) {  // diagnostics: no coordinate chain
-      g.ct[u].x0 = x + n; g.ct[u].w0 = 0.25f; g.ct[u].w1 = 0.75f;
+    if (kAblate & 8) {  // diagnostics: no coordinate chain (integer shift, constant weights)
+      g.ct[u].x0 = x + (int)sdisp[n]; g.ct[u].w0 = 0.25f; g.ct[u].w1 = 0.75f;
     } else {
       g.ct[u] = make_col_tap((float)x + sdisp[n], Wm1, rcpWm1);
     }
+#if PD_PF_DEPTH == 2
+    if (!(kAblate & 2)) g.tc[u] = load_colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W));
+#endif
     g.mval[u] = 1.0f;
     if (HASMASK && !(kAblate & 16))
       g.mval[u] = buf_load(row_rsrc(a.padding_mask + ((long)b * a.N + n) * HW + (long)y * a.W, a.W), (unsigned)x << 2);
@@ -369,6 +423,14 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
                                             const char* __restrict__ lrgb, int b, int n0, int pix, int HW, float t0,
                                             float t1, float t2, float ea, bool automask, FwdAcc& acc, uint32_t& bits,
                                             float* __restrict__ stash) {
+#if PD_PF_DEPTH == 2
+  const ColourTaps<NROWS>* tc = g.tc;
+#else
+  ColourTaps<NROWS> tc[U];  // all LDS reads of the group first, then the arithmetic
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (!(kAblate & 2)) tc[u] = load_colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W));
+#endif
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
@@ -391,8 +453,8 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
     const float s = MIX ? tap_value<NROWS>(ts, w) : 0.0f;
     float c0, c1, c2;
     if (kAblate & 2) { c0 = w.a0; c1 = w.a1; c2 = l; }  // diagnostics: no colour taps
-    else colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W), w, c0, c1, c2);
-    if (kAblate & 4) { acc.Z += l + s; acc.C0 += c0; acc.C1 += c1; acc.C2 += c2; acc.S = 1.0f; acc.m = 0.0f; }  // no softmax/mixture math
+    else colour_values<NROWS>(tc[u], w, c0, c1, c2);
+    if (kAblate & 4) { acc.Z += l; acc.S += s; acc.C0 += c0; acc.C1 += c1; acc.C2 += c2; acc.m = 0.0f; }  // no softmax/mixture math
     else fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
   }
 }
@@ -419,28 +481,44 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
     if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
     FwdAcc acc;
     uint32_t bits = 0;
-    // groups of U planes, loads of group i+1 in flight while group i is reduced (ping-pong register sets A / B)
-    PlaneGroup<NROWS, U> ga, gb;
+    // Groups of U planes through a software pipeline: while group i is reduced the loads of group i+1 (PD_PF_DEPTH 2;
+    // measured best) or of groups i+1 and i+2 (PD_PF_DEPTH 3; no faster, more registers) are in flight.
+    PlaneGroup<NROWS, U> g0, g1, g2;
     const int nfull = a.N / U;  // full groups
+#define PD_FISSUE(G, I) group_issue<MIX, HASMASK, NROWS, U>(G, a, row, lbytes, sdisp, b, y, (I) * U, x, HW, Wm1, rcpWm1)
+#define PD_FCOMP(G, I) fwd_compute<MIX, HASMASK, NROWS, U>(G, a, row, lbytes, b, (I) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash)
     int gi = 0;
-    if (!PD_FWD_PF) {
-      for (; gi < nfull; ++gi) {
-        group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, gi * U, x, HW, Wm1, rcpWm1);
-        fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+    if (PD_FWD_PF && PD_PF_DEPTH == 2) {
+      if (nfull > 0) PD_FISSUE(g0, 0);
+      for (; gi + 2 <= nfull; gi += 2) {
+        PD_FISSUE(g1, gi + 1);
+        PD_FCOMP(g0, gi);
+        if (gi + 2 < nfull) PD_FISSUE(g0, gi + 2);
+        PD_FCOMP(g1, gi + 1);
       }
-    } else if (nfull > 0) group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, 0, x, HW, Wm1, rcpWm1);
-    for (; gi + 2 <= nfull; gi += 2) {
-      group_issue<MIX, HASMASK, NROWS, U>(gb, a, row, sdisp, b, y, (gi + 1) * U, x, HW, Wm1, rcpWm1);
-      fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
-      if (gi + 2 < nfull) group_issue<MIX, HASMASK, NROWS, U>(ga, a, row, sdisp, b, y, (gi + 2) * U, x, HW, Wm1, rcpWm1);
-      fwd_compute<MIX, HASMASK, NROWS, U>(gb, a, row, lbytes, b, (gi + 1) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+      if (gi < nfull) PD_FCOMP(g0, gi);
+    } else if (PD_FWD_PF) {
+      if (nfull > 0) PD_FISSUE(g0, 0);
+      if (nfull > 1) PD_FISSUE(g1, 1);
+      for (; gi + 3 <= nfull; gi += 3) {
+        PD_FISSUE(g2, gi + 2);
+        PD_FCOMP(g0, gi);
+        if (gi + 3 < nfull) PD_FISSUE(g0, gi + 3);
+        PD_FCOMP(g1, gi + 1);
+        if (gi + 4 < nfull) PD_FISSUE(g1, gi + 4);
+        PD_FCOMP(g2, gi + 2);
+      }
+      if (gi < nfull) PD_FCOMP(g0, gi);
+      if (gi + 1 < nfull) PD_FCOMP(g1, gi + 1);
+    } else {
+      for (; gi < nfull; ++gi) { PD_FISSUE(g0, gi); PD_FCOMP(g0, gi); }
     }
-    if (gi < nfull)  // odd number of full groups: the last one is already in flight in A
-      fwd_compute<MIX, HASMASK, NROWS, U>(ga, a, row, lbytes, b, gi * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+#undef PD_FISSUE
+#undef PD_FCOMP
     for (int n = nfull * U; n < a.N; ++n) {  // remainder planes
-      PlaneGroup<NROWS, 1> g1;
-      group_issue<MIX, HASMASK, NROWS, 1>(g1, a, row, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
-      fwd_compute<MIX, HASMASK, NROWS, 1>(g1, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+      PlaneGroup<NROWS, 1> gr;
+      group_issue<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
+      fwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
     }
     const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
     float* st = stash + (long)b * a.stash_k * HW + pix;
@@ -520,6 +598,13 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
                                             const PixelCtx& c, int HW, float gix_scale, bool want_plane,
                                             uint32_t& bits) {
   const int W = a.W, N = a.N;
+#if PD_PF_DEPTH == 2
+  const ColourTaps<NROWS>* tc = g.tc;
+#else
+  ColourTaps<NROWS> tc[U];  // all LDS reads of the group first, then the arithmetic
+#pragma unroll
+  for (int u = 0; u < U; ++u) tc[u] = load_colour_taps<NROWS>(lrgb, W, colour_off(g.ct[u].x0, W));
+#endif
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
@@ -535,7 +620,8 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     // forward values (a masked plane contributes nothing to its own gradient, so its samples need no zeroing here)
     const TapW w = tap_weights<NROWS>(t, row, 1.0f);
     float c0, c1, c2, d0x, d1x, d2x;
-    colour_taps_dx<NROWS>(lrgb, W, colour_off(t.x0, W), w, row, c0, c1, c2, d0x, d1x, d2x);
+    colour_values<NROWS>(tc[u], w, c0, c1, c2);
+    colour_dx<NROWS>(tc[u], row, d0x, d1x, d2x);
     const bool edge = (t.x0 == -1);
     Taps<NROWS> tl = g.tl[u], ts = g.ts[u];
     fix_edge<NROWS>(tl, edge);
@@ -608,28 +694,43 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     sc.pix = y * W + (sc.active ? sc.xt : 0);
     const PixelCtx c = sc.active ? make_pixel_ctx<MIX>(a, o, b, sc.pix, HW) : zero_pixel_ctx();
     uint32_t bits = 0;
-    // same one-group-ahead prefetch as the forward (the mask comes from the stash bits, not from memory)
-    PlaneGroup<NROWS, U> ga, gb;
+    // same 3-deep software pipeline as the forward (the mask comes from the stash bits, not from memory)
+    PlaneGroup<NROWS, U> g0, g1, g2;
     const int nfull = N / U;
+#define PD_BISSUE(G, I) group_issue<MIX, false, NROWS, U>(G, a, row, lbytes, sdisp, b, y, (I) * U, sc.xt, HW, Wm1, rcpWm1)
+#define PD_BCOMP(G, I) bwd_compute<MIX, HASMASK, NROWS, U>(G, a, o, row, lbytes, kshift, red, bnd, b, y, (I) * U, sc, c, HW, gix_scale, want_plane, bits)
     int gi = 0;
-    if (!PD_BWD_PF) {
-      for (; gi < nfull; ++gi) {
-        group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, gi * U, sc.xt, HW, Wm1, rcpWm1);
-        bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
+    if (PD_BWD_PF && PD_PF_DEPTH == 2) {
+      if (nfull > 0) PD_BISSUE(g0, 0);
+      for (; gi + 2 <= nfull; gi += 2) {
+        PD_BISSUE(g1, gi + 1);
+        PD_BCOMP(g0, gi);
+        if (gi + 2 < nfull) PD_BISSUE(g0, gi + 2);
+        PD_BCOMP(g1, gi + 1);
       }
-    } else if (nfull > 0) group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, 0, sc.xt, HW, Wm1, rcpWm1);
-    for (; gi + 2 <= nfull; gi += 2) {
-      group_issue<MIX, false, NROWS, U>(gb, a, row, sdisp, b, y, (gi + 1) * U, sc.xt, HW, Wm1, rcpWm1);
-      bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
-      if (gi + 2 < nfull) group_issue<MIX, false, NROWS, U>(ga, a, row, sdisp, b, y, (gi + 2) * U, sc.xt, HW, Wm1, rcpWm1);
-      bwd_compute<MIX, HASMASK, NROWS, U>(gb, a, o, row, lbytes, kshift, red, bnd, b, y, (gi + 1) * U, sc, c, HW, gix_scale, want_plane, bits);
+      if (gi < nfull) PD_BCOMP(g0, gi);
+    } else if (PD_BWD_PF) {
+      if (nfull > 0) PD_BISSUE(g0, 0);
+      if (nfull > 1) PD_BISSUE(g1, 1);
+      for (; gi + 3 <= nfull; gi += 3) {
+        PD_BISSUE(g2, gi + 2);
+        PD_BCOMP(g0, gi);
+        if (gi + 3 < nfull) PD_BISSUE(g0, gi + 3);
+        PD_BCOMP(g1, gi + 1);
+        if (gi + 4 < nfull) PD_BISSUE(g1, gi + 4);
+        PD_BCOMP(g2, gi + 2);
+      }
+      if (gi < nfull) PD_BCOMP(g0, gi);
+      if (gi + 1 < nfull) PD_BCOMP(g1, gi + 1);
+    } else {
+      for (; gi < nfull; ++gi) { PD_BISSUE(g0, gi); PD_BCOMP(g0, gi); }
     }
-    if (gi < nfull)
-      bwd_compute<MIX, HASMASK, NROWS, U>(ga, a, o, row, lbytes, kshift, red, bnd, b, y, gi * U, sc, c, HW, gix_scale, want_plane, bits);
+#undef PD_BISSUE
+#undef PD_BCOMP
     for (int n = nfull * U; n < N; ++n) {
-      PlaneGroup<NROWS, 1> g1;
-      group_issue<MIX, false, NROWS, 1>(g1, a, row, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
-      bwd_compute<MIX, HASMASK, NROWS, 1>(g1, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, bits);
+      PlaneGroup<NROWS, 1> gr;
+      group_issue<MIX, false, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
+      bwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, bits);
     }
   }
   __syncthreads();
@@ -706,10 +807,10 @@ static int row_threads(int W) {
   // Measured on MI355X (W=640, 10 segments): 4, 5, 8 and 10 waves per workgroup are within 3% of each other, 1-2
   // waves are 1.5-2.5x slower (too few waves in flight).  Take the largest divisor of nseg up to 8 for equal work
   // per wave; awkward (prime) segment counts fall back to 8 waves with a ragged last pass.
-  int waves = 1;
-  for (int w = 1; w <= 8 && w <= nseg; ++w)
-    if (nseg % w == 0) waves = w;
-  if (waves < 4 && nseg > 8) waves = 8;
+  // PMC (scripts/gpu_occ.sh): 5-wave workgroups kept 1.7-1.8 waves resident per SIMD, 4- and 8-wave ones 2.3-3.3
+  // (the dispatcher deals a workgroup's waves to the SIMDs round-robin, so multiples of 4 pack; odd counts strand
+  // slots) and ran 8-18% faster despite the uneven split of the 10 segments.
+  const int waves = nseg >= 4 ? 4 : nseg;
   return waves * kWave;
 }
 
