@@ -26,6 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+with open(os.path.join(ROOT, "BASELINE.json")) as _f:
+    METRIC = json.load(_f)["metric"]  # "images/sec (warp+loss fwd+bwd), 192x640x49 planes, 1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 
 
@@ -214,8 +216,10 @@ def main():
     from planedepth_amd import parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    rank, world, local_rank = parallel.init_process_group_from_env("nccl")  # RCCL; timing barrier/reduction only
-    device = torch.device("cuda", local_rank)
+    # RCCL ("nccl"); used for the timing barrier / max reduction only.  PD_BENCH_BACKEND=gloo + PD_BENCH_SHARE_GPU=1 is
+    # a functional check of the multi-process flow on a one-GPU box (all ranks on cuda:0).
+    rank, world, local_rank = parallel.init_process_group_from_env(os.environ.get("PD_BENCH_BACKEND", "nccl"))
+    device = torch.device("cuda", 0 if os.environ.get("PD_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
     import __graft_entry__ as entry
     entry.build()
@@ -234,7 +238,7 @@ def main():
 
     value = parallel.throughput(args.batch, args.steps, world, elapsed)
     result = {
-        "metric": "images/sec (warp+loss fwd+bwd), 192x640x49 planes", "value": round(value, 2), "unit": "images/sec",
+        "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %s, stereo target r, %s loss, batch %d/GPU, %dx%d, %d planes, "

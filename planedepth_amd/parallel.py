@@ -60,11 +60,16 @@ def barrier(device=None):
             torch.cuda.synchronize(device)
 
 
+def _comm_device(device):
+    """NCCL/RCCL reduces device tensors, gloo host tensors."""
+    return device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+
+
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (the slowest rank defines the step time)."""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -73,7 +78,7 @@ def global_mean(local_mean, device=None):
     """Mean over ranks of per-rank means (equal shard sizes) — reporting only; gradients never need it."""
     if not dist.is_initialized():
         return float(local_mean)
-    t = torch.tensor([float(local_mean)], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([float(local_mean)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item()) / dist.get_world_size()
 
