@@ -28,7 +28,7 @@
 // magnitude inside the 1e-4 parity budget; measured in tests/test_gpu_parity.py).  The general kernels keep it.
 #include <stdlib.h>
 
-#include "pd_sweep.h"
+#include "pd_rowgeom.h"
 
 namespace pd {
 
@@ -70,32 +70,6 @@ __device__ __forceinline__ int block_row(int r, int H) {
   return r;
 }
 
-// Vertical footprint of target row y (workgroup-uniform): up to two live source rows with their weights.
-struct RowSel {
-  int nrows;      // 0, 1 or 2 live rows
-  int yA, yB;     // source rows (yB only if nrows == 2)
-  float wA, wB;   // their bilinear weights
-  float wy_main;  // weight of the workgroup's own row y (vertical adjoint)
-};
-
-__device__ __forceinline__ RowSel make_row_sel(int y, int H) {
-  RowSel r;
-  const float iy = normalise_roundtrip((float)y, (float)(H - 1));
-  const float yf = floorf(iy);
-  const float wy0 = (yf + 1.0f) - iy, wy1 = iy - yf;
-  const int y0 = (int)yf;
-  const bool use0 = (yf >= 0.0f) && (yf <= (float)(H - 1)) && (wy0 != 0.0f);
-  const bool use1 = (yf + 1.0f >= 0.0f) && (yf + 1.0f <= (float)(H - 1)) && (wy1 != 0.0f);
-  r.nrows = (int)use0 + (int)use1;
-  r.yA = use0 ? y0 : y0 + 1;
-  r.wA = use0 ? wy0 : (use1 ? wy1 : 0.0f);
-  r.yB = y0 + 1;
-  r.wB = wy1;
-  if (r.nrows == 0) r.yA = min(max(y0, 0), H - 1);
-  r.wy_main = (y0 == y) ? wy0 : ((y0 + 1 == y) ? wy1 : 0.0f);
-  return r;
-}
-
 // ---- memory access layer ------------------------------------------------------------------------------------------
 // Row-sized buffer resources (SRD in SGPRs, built from workgroup-uniform values only) give three things at once:
 //   * a 32-bit per-lane byte offset instead of 64-bit address arithmetic (the u64 adds were ~15% of all VALU cycles);
@@ -112,49 +86,6 @@ __device__ __forceinline__ float buf_load(Rsrc r, unsigned byte_off) {
 }
 __device__ __forceinline__ void buf_store(Rsrc r, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
-}
-
-struct ColTap {    // horizontal footprint of one target pixel on one plane
-  int x0;          // floor(ix)
-  float w0, w1;    // torch's weights (x1 - ix), (ix - x0)
-};
-
-// Correctly rounded a / b from the correctly rounded reciprocal of b (Markstein's theorem; b = W-1 is an integer
-// <= 2^24 and a is far from the over/underflow range, so no special cases arise).  Verified bit-for-bit against
-// IEEE division over the whole coordinate range by tests/test_gpu_parity.py::test_fast_division_is_exact.
-__device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
-  const float q0 = a * rcp_b;
-  const float r = fmaf(-q0, b, a);
-  return fmaf(r, rcp_b, q0);
-}
-
-__device__ __forceinline__ float refined_rcp(float b) {
-  float y = __builtin_amdgcn_rcpf(b);
-  const float e = fmaf(-b, y, 1.0f);
-  return fmaf(e, y, y);
-}
-
-// ix = unnormalise(normalise(px)) of the reference, bit for bit, in 7 operations:
-//   reference:  q = px/(W-1);  g = (q - 0.5)*2;            [trainer.py:550-552]
-//               ix = ((g + 1)/2) * (W-1)                    [grid_sample, align_corners=True]
-//   (g + 1)/2 = fl(2h + 1)/2 with h = fl(q - 0.5); scaling by 2 commutes with rounding, so it equals fl(h + 0.5).
-// |px| <= 2W+2 by construction (the per-plane shift is clamped to +-(W+2) when it is staged), so floor(ix) converts
-// to int without saturating and x0*4 cannot alias into the row.
-__device__ __forceinline__ ColTap make_col_tap(float px, float Wm1, float rcpWm1) {
-  ColTap t;
-  float ix;
-  {
-#pragma clang fp contract(off)
-    const float q = div_by(px, Wm1, rcpWm1);
-    const float h = q - 0.5f;
-    const float hh = h + 0.5f;
-    ix = hh * Wm1;
-  }
-  const float xf = floorf(ix);
-  t.w0 = (xf + 1.0f) - ix;
-  t.w1 = ix - xf;
-  t.x0 = (int)xf;
-  return t;
 }
 
 // The (up to) four taps of one scalar plane, loaded up-front.  Out-of-image taps come back as 0 from the hardware.
