@@ -142,6 +142,17 @@ int pd_reproj_loss_bwd(int B, int H, int W, int use_ssim, const float* pred, con
                        float* g_pred, float* g_target, pd_stream_t stream);
 
 /*
+ * multimodal_loss (layers.py:465-466) on materialised tensors:
+ *   out[b,0,p] = -log( sum_n pi * dist(error; sigma) + 1e-7 ),  dist = laplacian (layers.py:454) if `laplacian` else
+ *   gaussian (layers.py:451).  error, sigma, pi [B,N,H,W] -> out [B,1,H,W].  bwd: any of g_error/g_sigma/g_pi may be NULL.
+ */
+int pd_mixture_nll_fwd(int B, int N, int H, int W, int laplacian, const float* error, const float* sigma,
+                       const float* pi, float* out, pd_stream_t stream);
+int pd_mixture_nll_bwd(int B, int N, int H, int W, int laplacian, const float* error, const float* sigma,
+                       const float* pi, const float* g_out, float* g_error, float* g_sigma, float* g_pi,
+                       pd_stream_t stream);
+
+/*
  * Geometry modules.
  *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
  *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]

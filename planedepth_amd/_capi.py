@@ -43,6 +43,8 @@ SIGNATURES = {
     "pd_ssim_bwd": (_I, [_I] * 4 + [_P] * 6),
     "pd_reproj_loss_fwd": (_I, [_I] * 4 + [_P] * 4),
     "pd_reproj_loss_bwd": (_I, [_I] * 4 + [_P] * 6),
+    "pd_mixture_nll_fwd": (_I, [_I] * 5 + [_P] * 5),
+    "pd_mixture_nll_bwd": (_I, [_I] * 5 + [_P] * 8),
     "pd_backproject": (_I, [_I] * 3 + [_P] * 4),
     "pd_backproject_bwd": (_I, [_I] * 3 + [_P] * 4),
     "pd_project3d": (_I, [_I] * 3 + [_F] + [_P] * 4),

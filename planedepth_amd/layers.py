@@ -121,7 +121,8 @@ def bimodal_loss(error0, error1, sigma0, sigma1, w0, w1, dist="gaussian"):
 
 
 def multimodal_loss(error, sigma, pi, dist="gaussian"):
-    return -torch.log(torch.sum(pi * distribution(error, sigma, dist), dim=1, keepdim=True) + 1e-7)
+    """-log(sum_n pi * distribution(error, sigma) + 1e-7) over the plane axis (reference layers.py:465-466) — HIP kernel."""
+    return ops.multimodal_loss(error, sigma, pi, dist)
 
 
 def get_smooth_loss_disp(disp, img, gamma=1):

@@ -310,6 +310,45 @@ def reprojection_loss(pred, target, use_ssim=True):
     return _ReprojLoss.apply(pred, target, bool(use_ssim))
 
 
+class _MixtureNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, error, sigma, pi, laplacian):
+        lib = C.load()
+        C.require_gpu_tensor("error", error)
+        B, N, H, W = error.shape
+        error, sigma, pi = (t.expand(B, N, H, W).contiguous() for t in (error, sigma, pi))
+        C.require_gpu_tensor("sigma", sigma)
+        C.require_gpu_tensor("pi", pi)
+        out = torch.empty(B, 1, H, W, device=error.device, dtype=torch.float32)
+        with torch.cuda.device(error.device):
+            C.check(lib.pd_mixture_nll_fwd(B, N, H, W, int(laplacian), C.ptr(error), C.ptr(sigma), C.ptr(pi), C.ptr(out),
+                                           C.stream_handle(error.device)), "pd_mixture_nll_fwd")
+        ctx.save_for_backward(error, sigma, pi)
+        ctx.lap = int(laplacian)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = C.load()
+        error, sigma, pi = ctx.saved_tensors
+        B, N, H, W = error.shape
+        ge = torch.empty_like(error) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(sigma) if ctx.needs_input_grad[1] else None
+        gp = torch.empty_like(pi) if ctx.needs_input_grad[2] else None
+        if ge is None and gs is None and gp is None:
+            return None, None, None, None
+        with torch.cuda.device(error.device):
+            C.check(lib.pd_mixture_nll_bwd(B, N, H, W, ctx.lap, C.ptr(error), C.ptr(sigma), C.ptr(pi),
+                                           C.ptr(g.contiguous()), C.ptr(ge), C.ptr(gs), C.ptr(gp),
+                                           C.stream_handle(error.device)), "pd_mixture_nll_bwd")
+        return ge, gs, gp, None
+
+
+def multimodal_loss(error, sigma, pi, dist="gaussian"):
+    """layers.py:465-466 on materialised [B,N,H,W] tensors -> [B,1,H,W] (one kernel each way instead of ~10 passes)."""
+    return _MixtureNLL.apply(error, sigma, pi, dist != "gaussian")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Geometry
 # ---------------------------------------------------------------------------------------------------------------------

@@ -290,6 +290,16 @@ def test_modules_vs_reference_golden():
     ns.opt.use_ssim = False
     assert rel_err(pa.compute_reprojection_loss(ns, z["ssim_x"], z["ssim_y"]).cpu(), z["reproj_l1"].cpu()) < TOL
     assert rel_err(pa.multimodal_loss(z["mm_err"], z["mm_sigma"], z["mm_pi"], dist="lap").cpu(), z["mm_lap"].cpu()) < TOL
+    assert rel_err(pa.multimodal_loss(z["mm_err"], z["mm_sigma"], z["mm_pi"]).cpu(), z["mm_gauss"].cpu()) < TOL
+    from oracle import planedepth_oracle as orc
+    for dist in ("lap", "gaussian"):  # backward of the standalone mixture NLL against autograd through the oracle
+        e64, s64, p64 = (z[k].cpu().double().requires_grad_(True) for k in ("mm_err", "mm_sigma", "mm_pi"))
+        gw = torch.rand(z["mm_err"].shape[0], 1, *z["mm_err"].shape[2:], dtype=torch.float64)
+        (orc.multimodal_loss(e64, s64, p64, dist) * gw).sum().backward()
+        eg, sg, pg = (z[k].clone().requires_grad_(True) for k in ("mm_err", "mm_sigma", "mm_pi"))
+        (pa.multimodal_loss(eg, sg, pg, dist=dist) * gw.float().cuda()).sum().backward()
+        assert rel_err(eg.grad.cpu(), e64.grad.float()) < TOL and rel_err(sg.grad.cpu(), s64.grad.float()) < TOL
+        assert rel_err(pg.grad.cpu(), p64.grad.float()) < TOL
     assert rel_err(ops.grid_sample(z["ssim_x"], z["pj_grid"], padding_mode="border").cpu(), z["gs_border"].cpu()) < TOL
     assert rel_err(ops.grid_sample(z["ssim_x"], z["pj_grid"], padding_mode="zeros").cpu(), z["gs_zeros"].cpu()) < TOL
 
