@@ -81,6 +81,13 @@ typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc row_rsrc(const float* row, int W) {  // `row` must be wave-uniform
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, W * 4, 0x00020000);
 }
+// Same, for an address the compiler is known to keep in VGPRs (it then wraps every access in a waterfall loop): state
+// the uniformity explicitly.  Not the default: where the address already lives in SGPRs this costs extra moves.
+__device__ __forceinline__ Rsrc row_rsrc_uniform(const float* row, int W) {
+  const uint64_t p = reinterpret_cast<uint64_t>(row);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, W * 4, 0x00020000);
+}
 __device__ __forceinline__ float buf_load(Rsrc r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
@@ -334,7 +341,7 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
 #endif
     g.mval[u] = 1.0f;
     if (HASMASK && !(kAblate & 16))
-      g.mval[u] = buf_load(row_rsrc(a.padding_mask + ((long)b * a.N + n) * HW + (long)y * a.W, a.W), (unsigned)x << 2);
+      g.mval[u] = buf_load(row_rsrc_uniform(a.padding_mask + ((long)b * a.N + n) * HW + (long)y * a.W, a.W), (unsigned)x << 2);
     if (kAblate & 1) {  // diagnostics: no logit / sigma loads
       g.tl[u].a0 = g.tl[u].a1 = g.tl[u].b0 = g.tl[u].b1 = g.ct[u].w0;
       g.ts[u] = g.tl[u];
@@ -390,34 +397,137 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
   }
 }
 
-template <bool MIX, bool HASMASK, int NROWS>
+// Work split inside a row workgroup.  Whole 64-pixel segments are dealt to the waves round-robin (wave w takes
+// segments w, w+nwaves, ...: the waves of a workgroup then stream through ADJACENT parts of every plane row at the
+// same time, which the memory system rewards — giving each wave a contiguous slice of the row instead measured 20%
+// slower).  The r = nseg % nwaves segments left after the full rounds (W = 640: 10 segments over 4 waves leave 2) are
+// not given to r of the waves (3,3,2,2 segments measured 10% slower per pixel than W = 512 or 768) but cut along the
+// PLANE axis: their r*cps chunks of G planes are sliced evenly over all the waves.  A slice is shorter than a
+// segment, so it touches at most two of the left-over segments.
+struct RowWork {
+  int full;          // rounds of whole segments
+  int r;             // left-over segments
+  int cps;           // plane chunks per segment
+  int cb, ce;        // this wave's chunk slice of the left-over segments
+};
+__device__ __forceinline__ void slice_of(int r, int cps, int w, int nwaves, int& cb, int& ce) {
+  cb = r * cps * w / nwaves;
+  ce = r * cps * (w + 1) / nwaves;
+}
+__device__ __forceinline__ RowWork row_work(int nseg, int N, int G, int wave, int nwaves) {
+  RowWork k;
+  k.full = nseg / nwaves;
+  k.r = nseg - k.full * nwaves;
+  k.cps = (N + G - 1) / G;
+  slice_of(k.r, k.cps, wave, nwaves, k.cb, k.ce);
+  k.cb = __builtin_amdgcn_readfirstlane(k.cb);
+  k.ce = __builtin_amdgcn_readfirstlane(k.ce);
+  return k;
+}
+// Work item `it` of this wave: segment and plane range; piece = 0/1 for a slice piece of a left-over segment, else -1.
+__device__ __forceinline__ bool work_item(const RowWork& k, int it, int wave, int nwaves, int N, int G, int& seg,
+                                          int& n_lo, int& n_hi, int& piece) {
+  if (it < k.full) {
+    seg = it * nwaves + wave; n_lo = 0; n_hi = N; piece = -1;
+    return true;
+  }
+  piece = it - k.full;
+  const int j = k.cb / k.cps + piece;  // left-over segment index
+  if (piece > 1 || j * k.cps >= k.ce) return false;
+  // everything here derives from the wave index: say so (readfirstlane), or the plane-row descriptors built from n_lo
+  // are treated as divergent and every buffer load gets a waterfall loop
+  seg = __builtin_amdgcn_readfirstlane(k.full * nwaves + j);
+  n_lo = __builtin_amdgcn_readfirstlane(max(k.cb - j * k.cps, 0) * G);
+  n_hi = __builtin_amdgcn_readfirstlane(min((min(k.ce, (j + 1) * k.cps) - j * k.cps) * G, N));
+  return true;
+}
+
+// Merge the partial sums of two plane ranges of the same pixel (split online softmax: common reference = the larger).
+__device__ __forceinline__ FwdAcc merge_acc(const FwdAcc& a, const FwdAcc& b) {
+  FwdAcc r;
+  r.m = fmaxf(a.m, b.m);
+  const float sa = exp2_fast(a.m - r.m), sb = exp2_fast(b.m - r.m);
+  r.Z = a.Z * sa + b.Z * sb;
+  r.S = a.S * sa + b.S * sb;
+  r.C0 = a.C0 * sa + b.C0 * sb;
+  r.C1 = a.C1 * sa + b.C1 * sb;
+  r.C2 = a.C2 * sa + b.C2 * sb;
+  r.Mx = a.Mx * sa + b.Mx * sb;
+  r.Ma = a.Ma * sa + b.Ma * sb;
+  return r;
+}
+__device__ __forceinline__ void park_acc(float* __restrict__ slot, int lane, const FwdAcc& a) {  // slot: [8][64]
+  slot[0 * kWave + lane] = a.m;  slot[1 * kWave + lane] = a.Z;  slot[2 * kWave + lane] = a.S;
+  slot[3 * kWave + lane] = a.C0; slot[4 * kWave + lane] = a.C1; slot[5 * kWave + lane] = a.C2;
+  slot[6 * kWave + lane] = a.Mx; slot[7 * kWave + lane] = a.Ma;
+}
+__device__ __forceinline__ FwdAcc fetch_acc(const float* __restrict__ slot, int lane) {
+  FwdAcc a;
+  a.m = slot[0 * kWave + lane];  a.Z = slot[1 * kWave + lane];  a.S = slot[2 * kWave + lane];
+  a.C0 = slot[3 * kWave + lane]; a.C1 = slot[4 * kWave + lane]; a.C2 = slot[5 * kWave + lane];
+  a.Mx = slot[6 * kWave + lane]; a.Ma = slot[7 * kWave + lane];
+  return a;
+}
+
+template <bool MIX>
+__device__ __forceinline__ void fwd_store(const SweepArgs& a, const FwdAcc& acc, int b, int pix, int HW, float t0,
+                                          float t1, float t2, float ea, bool automask, float* __restrict__ rgb_rec,
+                                          float* __restrict__ ph_map, float* __restrict__ stash) {
+  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
+  float* st = stash + (long)b * a.stash_k * HW + pix;
+  st[0] = r.lse2;
+  st[HW] = r.Sn;
+  st[2 * HW] = r.mx;
+  st[3 * HW] = r.sel;
+  rgb_rec[((long)b * 3 + 0) * HW + pix] = r.r0;
+  rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
+  rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
+  ph_map[(long)b * HW + pix] = r.ph;
+}
+
+template <bool MIX, bool HASMASK, bool AUTO, int NROWS>
 __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
-                                                  float* __restrict__ rgb_rec, float* __restrict__ ph_map,
-                                                  float* __restrict__ stash) {
+                                                  float* parts, float* __restrict__ rgb_rec,
+                                                  float* __restrict__ ph_map, float* __restrict__ stash) {
   constexpr int U = (NROWS == 1) ? PD_FWD_U : (PD_FWD_U > 1 ? PD_FWD_U / 2 : 1);
+  constexpr int G = HASMASK ? 32 : U;  // chunk of the work split (mask words of the stash are written whole)
+  static_assert(32 % U == 0, "plane groups must tile the 32-plane mask words");
   const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
-  const int HW = a.H * a.W;
-  const bool automask = a.flags & PD_AUTOMASK;
+  const int HW = a.H * a.W, N = a.N;
+  // mixture kernels are specialised on the automask flag (it costs an exponential per plane); L1 reads it at run time
+  const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
   const float Wm1 = (float)(a.W - 1), rcpWm1 = refined_rcp(Wm1);
   const float* srcb = a.src + (long)b * 3 * HW;
   stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
   __syncthreads();
   const char* lbytes = reinterpret_cast<const char*>(lrgb);
-  for (int x = threadIdx.x; x < a.W; x += blockDim.x) {
-    const int pix = y * a.W + x;
-    const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
-    const float t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
-    const float t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
-    float ea = 0.0f;  // 3 x identity-reprojection error
+  const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (a.W + kWave - 1) / kWave;
+  const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  auto target_pixel = [&](int pix, float& t0, float& t1, float& t2, float& ea) {
+    t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+    t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+    t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+    ea = 0.0f;  // 3 x identity-reprojection error
     if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
+  };
+  for (int it = 0;; ++it) {
+    int seg, n_lo, n_hi, piece;
+    if (!work_item(rw, it, wave, nwaves, N, G, seg, n_lo, n_hi, piece)) break;
+    const int x = seg * kWave + lane;
+    if (x < a.W) {
+    const int pix = y * a.W + x;
+    float t0, t1, t2, ea;
+    target_pixel(pix, t0, t1, t2, ea);
     FwdAcc acc;
     uint32_t bits = 0;
     // Groups of U planes through a software pipeline: while group i is reduced the loads of group i+1 (PD_PF_DEPTH 2;
     // measured best) or of groups i+1 and i+2 (PD_PF_DEPTH 3; no faster, more registers) are in flight.
     PlaneGroup<NROWS, U> g0, g1, g2;
-    const int nfull = a.N / U;  // full groups
-#define PD_FISSUE(G, I) group_issue<MIX, HASMASK, NROWS, U>(G, a, row, lbytes, sdisp, b, y, (I) * U, x, HW, Wm1, rcpWm1)
-#define PD_FCOMP(G, I) fwd_compute<MIX, HASMASK, NROWS, U>(G, a, row, lbytes, b, (I) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash)
+    const int nfull = (n_hi - n_lo) / U;  // full groups
+#define PD_FISSUE(GR, I) group_issue<MIX, HASMASK, NROWS, U>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, x, HW, Wm1, rcpWm1)
+#define PD_FCOMP(GR, I) fwd_compute<MIX, HASMASK, NROWS, U>(GR, a, row, lbytes, b, n_lo + (I) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash)
     int gi = 0;
     if (PD_FWD_PF && PD_PF_DEPTH == 2) {
       if (nfull > 0) PD_FISSUE(g0, 0);
@@ -446,33 +556,47 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
     }
 #undef PD_FISSUE
 #undef PD_FCOMP
-    for (int n = nfull * U; n < a.N; ++n) {  // remainder planes
+    for (int n = n_lo + nfull * U; n < n_hi; ++n) {  // remainder planes (only at the end of the plane axis)
       PlaneGroup<NROWS, 1> gr;
       group_issue<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
       fwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
     }
-    const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
-    float* st = stash + (long)b * a.stash_k * HW + pix;
-    st[0] = r.lse2;
-    st[HW] = r.Sn;
-    st[2 * HW] = r.mx;
-    st[3 * HW] = r.sel;
-    rgb_rec[((long)b * 3 + 0) * HW + pix] = r.r0;
-    rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
-    rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
-    ph_map[(long)b * HW + pix] = r.ph;
+    if (piece < 0) fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
+    else park_acc(parts + ((wave * 2 + piece) * 8) * kWave, lane, acc);
+    }
+  }
+  if (rw.r == 0) return;  // workgroup-uniform
+  __syncthreads();
+  if (wave < rw.r) {  // wave j merges the pieces of left-over segment j (in plane order) and finishes its pixels
+    const int j = wave, x = (rw.full * nwaves + j) * kWave + lane;
+    if (x < a.W) {
+      FwdAcc acc;
+      acc.m = -3.0e38f;  // finite: merging the empty sum must not produce inf - inf
+      for (int w2 = 0; w2 < nwaves; ++w2) {
+        int cb2, ce2;
+        slice_of(rw.r, rw.cps, w2, nwaves, cb2, ce2);
+        if (cb2 < (j + 1) * rw.cps && ce2 > j * rw.cps && ce2 > cb2)
+          acc = merge_acc(acc, fetch_acc(parts + ((w2 * 2 + (cb2 < j * rw.cps ? 1 : 0)) * 8) * kWave, lane));
+      }
+      const int pix = y * a.W + x;
+      float t0, t1, t2, ea;
+      target_pixel(pix, t0, t1, t2, ea);
+      fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
+    }
   }
 }
 
-template <bool MIX, bool HASMASK>
+template <bool MIX, bool HASMASK, bool AUTO>
 __global__ __launch_bounds__(kRowThreadsMax, PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
                                                                      float* __restrict__ stash) {
   extern __shared__ float4 lds4[];
+  // LDS: colour rows float4[2*(W+4)] | sdisp[N] | parked partial sums [nwaves][2][8][64]
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
+  float* parts = sdisp + a.N;
   const RowSel row = make_row_sel(block_row(blockIdx.x, a.H), a.H);
-  if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, 2>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
-  else                rowshift_fwd_body<MIX, HASMASK, 1>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
+  if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  else                rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -585,6 +709,7 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
       const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
       if (o.g_sigma) buf_store(row_rsrc(o.g_sigma + pl + (long)y * W, W), xoff, out_s);
     }
+    // (per-lane LDS partials, one ds_add_f32 per plane, measured 12% slower than the DPP reduction + one atomic)
     if (want_plane) {
       const float v = wave_sum_hi(gd);
       if (sc.lane == kWave - 1) atomicAdd(&red[n], v);
@@ -598,7 +723,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   constexpr int U = PD_BWD_U;
   const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
   const int HW = a.H * a.W, W = a.W, N = a.N;
-  const int lane = threadIdx.x & (kWave - 1), nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: stays in SGPRs
   const int nseg = (W + kWave - 1) / kWave;
   const bool want_plane = (o.g_plane != nullptr);
@@ -614,7 +739,14 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
   const float gix_scale = (Wm1 / 2) * 2.0f / Wm1 * a.sign;  // d ix / d disp through un-normalise, *2, /(W-1)
 
-  for (int seg = wave; seg < nseg; seg += nwaves) {
+  // balanced split of the row's (segment, plane chunk) list over the waves, as in the forward; the per-plane gradient
+  // is closed-form given the pixel's stash, so a segment split between two waves needs no merge at all
+  constexpr int G = HASMASK ? 32 : U;  // mask words are fetched whole
+  static_assert(32 % U == 0, "plane groups must tile the 32-plane mask words");
+  const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  for (int it = 0;; ++it) {
+    int seg, n_lo, n_hi, piece;
+    if (!work_item(rw, it, wave, nwaves, N, G, seg, n_lo, n_hi, piece)) break;
     SegCtx sc;
     sc.seg = seg;
     sc.T0 = seg * kWave;
@@ -625,11 +757,11 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     sc.pix = y * W + (sc.active ? sc.xt : 0);
     const PixelCtx c = sc.active ? make_pixel_ctx<MIX>(a, o, b, sc.pix, HW) : zero_pixel_ctx();
     uint32_t bits = 0;
-    // same 3-deep software pipeline as the forward (the mask comes from the stash bits, not from memory)
+    // same software pipeline as the forward (the mask comes from the stash bits, not from memory)
     PlaneGroup<NROWS, U> g0, g1, g2;
-    const int nfull = N / U;
-#define PD_BISSUE(G, I) group_issue<MIX, false, NROWS, U>(G, a, row, lbytes, sdisp, b, y, (I) * U, sc.xt, HW, Wm1, rcpWm1)
-#define PD_BCOMP(G, I) bwd_compute<MIX, HASMASK, NROWS, U>(G, a, o, row, lbytes, kshift, red, bnd, b, y, (I) * U, sc, c, HW, gix_scale, want_plane, bits)
+    const int nfull = (n_hi - n_lo) / U;
+#define PD_BISSUE(GR, I) group_issue<MIX, false, NROWS, U>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, sc.xt, HW, Wm1, rcpWm1)
+#define PD_BCOMP(GR, I) bwd_compute<MIX, HASMASK, NROWS, U>(GR, a, o, row, lbytes, kshift, red, bnd, b, y, n_lo + (I) * U, sc, c, HW, gix_scale, want_plane, bits)
     int gi = 0;
     if (PD_BWD_PF && PD_PF_DEPTH == 2) {
       if (nfull > 0) PD_BISSUE(g0, 0);
@@ -658,7 +790,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     }
 #undef PD_BISSUE
 #undef PD_BCOMP
-    for (int n = nfull * U; n < N; ++n) {
+    for (int n = n_lo + nfull * U; n < n_hi; ++n) {
       PlaneGroup<NROWS, 1> gr;
       group_issue<MIX, false, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
       bwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, bits);
@@ -772,9 +904,21 @@ static void allow_lds(K kernel, size_t shmem) {
 int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
                  hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
-  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + (size_t)d->N * sizeof(float);
-  PD_ROW_DISPATCH(rowshift_fwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a,
-                  rgb_rec, ph_map, stash);
+  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + (size_t)d->N * sizeof(float) +
+                       (size_t)(block.x / kWave) * 2 * 8 * kWave * sizeof(float);
+  const bool mix = (d->flags & PD_MIXTURE) != 0, hasmask = a.has_mask != 0, am = (d->flags & PD_AUTOMASK) != 0;
+#define PD_FWD_LAUNCH(M, K, A)                                                              \
+  do {                                                                                      \
+    allow_lds(rowshift_fwd_kernel<M, K, A>, shmem);                                         \
+    rowshift_fwd_kernel<M, K, A><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash); \
+  } while (0)
+  if (mix) {
+    if (hasmask) { if (am) PD_FWD_LAUNCH(true, true, true); else PD_FWD_LAUNCH(true, true, false); }
+    else         { if (am) PD_FWD_LAUNCH(true, false, true); else PD_FWD_LAUNCH(true, false, false); }
+  } else {
+    if (hasmask) PD_FWD_LAUNCH(false, true, false); else PD_FWD_LAUNCH(false, false, false);
+  }
+#undef PD_FWD_LAUNCH
   return check_launch("rowshift_fwd_kernel");
 }
 
