@@ -70,6 +70,19 @@ __device__ __forceinline__ int block_row(int r, int H) {
   return r;
 }
 
+// The one-row bodies drop the multiplications by the vertical weight: they run only for rows whose single live source
+// row is the row itself with weight exactly 1 (every row whose normalise -> un-normalise round trip is exact).  Anything
+// else with one live row (weight 1 - eps at an image border) is rewritten as a two-row footprint with a zero second
+// weight on the same row, which the two-row bodies handle in full generality.
+__device__ __forceinline__ RowSel two_row_form(RowSel r) {
+  if (r.nrows == 1 && (r.wA != 1.0f || r.wy_main != 1.0f)) {
+    r.nrows = 2;
+    r.yB = r.yA;
+    r.wB = 0.0f;
+  }
+  return r;
+}
+
 // ---- memory access layer ------------------------------------------------------------------------------------------
 // Row-sized buffer resources (SRD in SGPRs, built from workgroup-uniform values only) give three things at once:
 //   * a 32-bit per-lane byte offset instead of 64-bit address arithmetic (the u64 adds were ~15% of all VALU cycles);
@@ -156,8 +169,8 @@ template <int NROWS>
 __device__ __forceinline__ TapW tap_weights(const ColTap& c, const RowSel& r, float live) {
   TapW w;
   const float w0 = c.w0 * live, w1 = c.w1 * live;  // live = 1, or 0 for a plane the padding mask removes
-  w.a0 = w0 * r.wA;
-  w.a1 = w1 * r.wA;
+  w.a0 = (NROWS == 1) ? w0 : w0 * r.wA;           // one-row bodies run only where that row's weight is exactly 1
+  w.a1 = (NROWS == 1) ? w1 : w1 * r.wA;
   w.b0 = w.b1 = 0.0f;
   if (NROWS == 2) {
     w.b0 = w0 * r.wB;
@@ -176,8 +189,8 @@ __device__ __forceinline__ float tap_value(const Taps<NROWS>& t, const TapW& w) 
 // d value / d ix = (ne - nw) * wyA + (se - sw) * wyB   (out-of-image taps already read as zero)
 template <int NROWS>
 __device__ __forceinline__ float tap_dx(const Taps<NROWS>& t, const RowSel& r) {
-  float d = (t.a1 - t.a0) * r.wA;
-  if (NROWS == 2) d += (t.b1 - t.b0) * r.wB;
+  float d = t.a1 - t.a0;
+  if (NROWS == 2) d = d * r.wA + (t.b1 - t.b0) * r.wB;
   return d;
 }
 
@@ -223,56 +236,13 @@ __device__ __forceinline__ void colour_values(const ColourTaps<NROWS>& t, const 
 template <int NROWS>
 __device__ __forceinline__ void colour_dx(const ColourTaps<NROWS>& t, const RowSel& r, float& d0, float& d1,
                                           float& d2) {
-  d0 = (t.ne.x - t.nw.x) * r.wA;
-  d1 = (t.ne.y - t.nw.y) * r.wA;
-  d2 = (t.ne.z - t.nw.z) * r.wA;
+  d0 = t.ne.x - t.nw.x;
+  d1 = t.ne.y - t.nw.y;
+  d2 = t.ne.z - t.nw.z;
   if (NROWS == 2) {
-    d0 += (t.se.x - t.sw.x) * r.wB;
-    d1 += (t.se.y - t.sw.y) * r.wB;
-    d2 += (t.se.z - t.sw.z) * r.wB;
-  }
-}
-
-template <int NROWS>
-__device__ __forceinline__ void colour_taps(const char* __restrict__ lrgb, int W, unsigned off, const TapW& w,
-                                            float& c0, float& c1, float& c2) {
-  const float4 nw = *reinterpret_cast<const float4*>(lrgb + off);
-  const float4 ne = *reinterpret_cast<const float4*>(lrgb + off + 16);
-  c0 = nw.x * w.a0 + ne.x * w.a1;
-  c1 = nw.y * w.a0 + ne.y * w.a1;
-  c2 = nw.z * w.a0 + ne.z * w.a1;
-  if (NROWS == 2) {
-    const unsigned rb = (unsigned)(W + 4) << 4;
-    const float4 sw = *reinterpret_cast<const float4*>(lrgb + rb + off);
-    const float4 se = *reinterpret_cast<const float4*>(lrgb + rb + off + 16);
-    c0 += sw.x * w.b0 + se.x * w.b1;
-    c1 += sw.y * w.b0 + se.y * w.b1;
-    c2 += sw.z * w.b0 + se.z * w.b1;
-  }
-}
-
-template <int NROWS>
-__device__ __forceinline__ void colour_taps_dx(const char* __restrict__ lrgb, int W, unsigned off, const TapW& w,
-                                               const RowSel& r, float& c0, float& c1, float& c2, float& d0, float& d1,
-                                               float& d2) {
-  const float4 nw = *reinterpret_cast<const float4*>(lrgb + off);
-  const float4 ne = *reinterpret_cast<const float4*>(lrgb + off + 16);
-  c0 = nw.x * w.a0 + ne.x * w.a1;
-  c1 = nw.y * w.a0 + ne.y * w.a1;
-  c2 = nw.z * w.a0 + ne.z * w.a1;
-  d0 = (ne.x - nw.x) * r.wA;
-  d1 = (ne.y - nw.y) * r.wA;
-  d2 = (ne.z - nw.z) * r.wA;
-  if (NROWS == 2) {
-    const unsigned rb = (unsigned)(W + 4) << 4;
-    const float4 sw = *reinterpret_cast<const float4*>(lrgb + rb + off);
-    const float4 se = *reinterpret_cast<const float4*>(lrgb + rb + off + 16);
-    c0 += sw.x * w.b0 + se.x * w.b1;
-    c1 += sw.y * w.b0 + se.y * w.b1;
-    c2 += sw.z * w.b0 + se.z * w.b1;
-    d0 += (se.x - sw.x) * r.wB;
-    d1 += (se.y - sw.y) * r.wB;
-    d2 += (se.z - sw.z) * r.wB;
+    d0 = d0 * r.wA + (t.se.x - t.sw.x) * r.wB;
+    d1 = d1 * r.wA + (t.se.y - t.sw.y) * r.wB;
+    d2 = d2 * r.wA + (t.se.z - t.sw.z) * r.wB;
   }
 }
 
@@ -383,12 +353,16 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
       live = mk ? 1.0f : 0.0f;
     }
     const TapW w = tap_weights<NROWS>(g.ct[u], row, live);
+    // x0 = -1: the load was issued at column 0, so its FIRST dword is the right tap; moving the weights instead of the
+    // values costs two selects per row shared by logits and sigma (the colour taps come from LDS and are in place)
     const bool edge = (g.ct[u].x0 == -1);
-    Taps<NROWS> tl = g.tl[u], ts = g.ts[u];
-    fix_edge<NROWS>(tl, edge);
-    if (MIX) fix_edge<NROWS>(ts, edge);
-    const float l = tap_value<NROWS>(tl, w);
-    const float s = MIX ? tap_value<NROWS>(ts, w) : 0.0f;
+    TapW we;
+    we.a0 = edge ? w.a1 : w.a0;
+    we.a1 = edge ? 0.0f : w.a1;
+    we.b0 = (NROWS == 2) ? (edge ? w.b1 : w.b0) : 0.0f;
+    we.b1 = (NROWS == 2) ? (edge ? 0.0f : w.b1) : 0.0f;
+    const float l = tap_value<NROWS>(g.tl[u], we);
+    const float s = MIX ? tap_value<NROWS>(g.ts[u], we) : 0.0f;
     float c0, c1, c2;
     if (kAblate & 2) { c0 = w.a0; c1 = w.a1; c2 = l; }  // diagnostics: no colour taps
     else colour_values<NROWS>(tc[u], w, c0, c1, c2);
@@ -594,7 +568,7 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_FWD_OCC) void rowshift_fwd_kerne
   // LDS: colour rows float4[2*(W+4)] | sdisp[N] | parked partial sums [nwaves][2][8][64]
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   float* parts = sdisp + a.N;
-  const RowSel row = make_row_sel(block_row(blockIdx.x, a.H), a.H);
+  const RowSel row = two_row_form(make_row_sel(block_row(blockIdx.x, a.H), a.H));
   if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
   else                rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
 }
@@ -686,7 +660,7 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
     // adjoint of the horizontal gather: contributions to source x0 (weight w0) and x0+1 (weight w1), if inside
     const bool v0 = (unsigned)t.x0 < (unsigned)W, v1 = (unsigned)(t.x0 + 1) < (unsigned)W;
-    const float live = mk ? row.wy_main : 0.0f;   // padding mask x vertical adjoint weight of the own row
+    const float live = mk ? (NROWS == 1 ? 1.0f : row.wy_main) : 0.0f;   // padding mask x vertical adjoint weight of the own row
     const float m0 = v0 ? t.w0 * live : 0.0f, m1 = v1 ? t.w1 * live : 0.0f;
     const int dl = (mk && (v0 || v1)) ? t.x0 - sc.xt - k : 0;
     const float cl0 = pg.g_l * m0, cl1 = pg.g_l * m1, cs0 = pg.g_s * m0, cs1 = pg.g_s * m1;
@@ -832,7 +806,7 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kerne
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);
   float* red = sdisp + 2 * a.N;
   float* bnd = red + a.N;
-  const RowSel row = make_row_sel(block_row(blockIdx.x, a.H), a.H);
+  const RowSel row = two_row_form(make_row_sel(block_row(blockIdx.x, a.H), a.H));
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }

@@ -14,6 +14,7 @@ from . import _capi as C
 # row-shift kernels against the general ones; leave it alone otherwise.
 SWEEP_IMPL = C.PD_IMPL_AUTO
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
+DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
 
 
 def _desc(B, N, H, W, mode, flags, sign):
@@ -70,6 +71,8 @@ class _PlaneSweep(torch.autograd.Function):
                                         C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                         C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(stash), C.stream_handle(logits.device))
         C.check(rc, "pd_plane_sweep_fwd")
+        if DEBUG_STASH is not None:
+            DEBUG_STASH.append(stash)
         ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
         ctx.cfg = (mode, flags, sign)
         ctx.mark_non_differentiable(stash)

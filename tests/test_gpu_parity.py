@@ -140,7 +140,10 @@ def test_rowshift_kernels_vs_general_kernels_and_oracle(W, side, disps):
     N = len(disps)
     case = build_case(B=2, N=N, H=11, W=W, seed=300 + W, disp_min=0.5, disp_max=9.0, special_disp=disps,
                       sigma_interior=True)
-    run = dict(target_side=side, automask=True)
+    # automask only without a zero-disparity plane: that plane reconstructs the source pixel itself, so where every
+    # other plane is out of view the warped and the identity likelihoods tie to the last ulp and the min() of
+    # trainer.py:734 becomes a coin toss between builds (knife edge (d) in DESIGN.md section 5)
+    run = dict(target_side=side, automask=(0.0 not in disps))
     fast = run_product(case, run)
     ops.SWEEP_IMPL = C.PD_IMPL_GENERAL
     try:
