@@ -153,6 +153,60 @@ int pd_mixture_nll_bwd(int B, int N, int H, int W, int laplacian, const float* e
                        pd_stream_t stream);
 
 /*
+ * Fused tail of DepthDecoder.forward (networks/depth_decoder.py:256-260, 274-291, softmax branch):
+ *   logits = raw_logits * padding_mask; pi = softmax_N(logits); sigma = clamp(sigmoid(raw_sigma), .01, 1);
+ *   probability = (pi / sigma * mask) / sum_N (mixture) or pi; disp = sum_N probability * disp_layered;
+ *   depth = 0.1 * 0.58 * W / disp.
+ * raw_logits, raw_sigma (mixture only), padding_mask (NULL = all ones) [B,N,H,W]; disp_layered [B,N], or [B,N,H,W] with
+ * PD_TAIL_DISP_DENSE.  fwd writes logits (only when there is a mask; without one logits == raw_logits), sigma
+ * (mixture), disp and depth [B,1,H,W] and a stash [B,2,H,W] {log-sum-exp, sum pi*mask/sigma}.  pi / probability are not
+ * materialised by fwd (training reads them for their shape only): pd_decoder_tail_layers writes either or both on demand.
+ * bwd: upstream g_logits, g_sigma [B,N,H,W], g_disp, g_depth [B,1,H,W] (each may be NULL = zero) -> g_raw_logits,
+ * g_raw_sigma [B,N,H,W], g_disp_layered (same layout as disp_layered; the [B,N] form needs `workspace` of
+ * pd_decoder_tail_bwd_workspace_floats floats); outputs that are NULL are skipped.
+ */
+enum pd_tail_flags { PD_TAIL_MIXTURE = 1, PD_TAIL_DISP_DENSE = 2 };
+size_t pd_decoder_tail_bwd_workspace_floats(int B, int N, int H, int W);
+int pd_decoder_tail_fwd(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                        const float* padding_mask, const float* disp_layered, float* logits, float* sigma, float* disp,
+                        float* depth, float* stash, pd_stream_t stream);
+int pd_decoder_tail_layers(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                           const float* padding_mask, const float* stash, float* pi, float* probability,
+                           pd_stream_t stream);
+int pd_decoder_tail_bwd(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                        const float* padding_mask, const float* disp_layered, const float* stash, const float* disp,
+                        const float* g_logits, const float* g_sigma, const float* g_disp, const float* g_depth,
+                        float* g_raw_logits, float* g_raw_sigma, float* g_disp_layered, float* workspace,
+                        pd_stream_t stream);
+
+/*
+ * get_smooth_loss_disp (layers.py:243-256; trainer.py:768):
+ *   out[0] = mean_x |d(x)-d(x+1)| exp(-gamma mean_c|I(x)-I(x+1)|) + the same along y.
+ * disp [B,1,H,W], img [B,C,H,W]; both may be crops of wider tensors: unit column stride, the other strides (in floats)
+ * are passed explicitly.  bwd: g_out[0] (device scalar) -> g_disp, contiguous [B,1,H,W].
+ */
+int pd_smooth_loss_fwd(int B, int C, int H, int W, const float* disp, int64_t disp_stride_b, int64_t disp_stride_h,
+                       const float* img, int64_t img_stride_b, int64_t img_stride_c, int64_t img_stride_h, float gamma,
+                       float* out, pd_stream_t stream);
+int pd_smooth_loss_bwd(int B, int C, int H, int W, const float* disp, int64_t disp_stride_b, int64_t disp_stride_h,
+                       const float* img, int64_t img_stride_b, int64_t img_stride_c, int64_t img_stride_h, float gamma,
+                       const float* g_out, float* g_disp, pd_stream_t stream);
+
+/*
+ * Warps of Trainer.generate_post_process_disp (trainer.py:421-466), forward only:
+ *   pd_warp_softmax  out[b,n] = softmax over n of planes[b,n] sampled at (x + sign*disp[b,n], y)   [B,N,H,W] -> [B,N,H,W]
+ *   pd_warp_sum      out[b,0] = min(cap, sum over n of planes[b,n] sampled at (x + sign*disp[b,n], y))      -> [B,1,H,W]
+ * bilinear, zeros padding, align_corners=True, coordinates through the reference's normalise / un-normalise round trip.
+ * disp [B,N] or, with PD_PP_DISP_DENSE, [B,N,H,W]; PD_PP_FLIP_SRC reads `planes` mirrored along x (the .flip(-1) of
+ * trainer.py:451) without a flipped copy.
+ */
+enum pd_pp_flags { PD_PP_DISP_DENSE = 1, PD_PP_FLIP_SRC = 2 };
+int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp,
+                    float* out, pd_stream_t stream);
+int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp, float cap,
+                float* out, pd_stream_t stream);
+
+/*
  * Geometry modules.
  *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
  *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]

@@ -16,6 +16,8 @@ float64 for a high-precision yard-stick), of the algorithm in the reference's
   * ``layers.py:243-256``   get_smooth_loss_disp
   * ``layers.py:276-306``   SSIM
   * ``layers.py:451-466``   gaussian / laplacian / multimodal_loss
+  * ``networks/depth_decoder.py:256-291``  the decoder's tail
+  * ``trainer.py:404-466``  generate_post_process_disp  
   * torch ``F.grid_sample(bilinear, zeros|border, align_corners=True)`` — the
     third-party op the reference calls at ``trainer.py:573-577, 624-628``;
     restated here from its published formula (``bilinear_sample``) and checked
@@ -325,3 +327,54 @@ def warp_and_loss(src, target, logits, sigma, *, warp_type="disp_warp", target_s
     ph_map, pred = photometric_loss(sweep, target, src, use_mixture_loss=use_mixture_loss,
                                     automask=automask, mask_novel=mask_novel)
     return dict(rgb_rec=sweep["rgb_rec"], ph_map=ph_map, ph_loss=ph_map.mean(), pred=pred, sweep=sweep, grid=grid)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY.md §8(f) rows
+# ---------------------------------------------------------------------------------------------------------------------
+def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, width, use_mixture_loss=True):
+    """networks/depth_decoder.py:256-260, 274-291 (softmax branch): what DepthDecoder.forward does with the outputs of
+    ``dispconv`` / ``sigmaconv``.  Returns the dict entries it writes."""
+    out = {}
+    logits = raw_logits * padding_mask                                  # :259
+    out["logits"] = logits
+    out["probability"] = torch.softmax(logits, 1)                       # :275
+    if use_mixture_loss:
+        sigma = torch.clamp(torch.sigmoid(raw_sigma), 0.01, 1.0)        # :278-279
+        out["sigma"] = sigma
+        out["pi"] = pi = out["probability"]                             # :281
+        weights = pi / sigma * padding_mask                             # :282-283
+        out["probability"] = weights / weights.sum(1, True)             # :284-285
+    out["disp"] = (out["probability"] * disp_layered).sum(1, True)      # :289
+    out["depth"] = 0.1 * 0.58 * width / out["disp"]                     # :291
+    return out
+
+
+def post_process_disp(logits, probability, disp, disp_layered):
+    """trainer.py:421-466: the occlusion-aware blend of the prediction for the image and for its mirror image.  The
+    arguments are the fixed model's outputs for the batch cat([image, flipped image]) (2B leading entries)."""
+    B2, N, H, W = probability.shape
+    B = B2 // 2
+    xs = torch.arange(W, dtype=logits.dtype).view(1, 1, 1, W).expand(B, N, H, W)
+    ys = torch.arange(H, dtype=logits.dtype).view(1, 1, H, 1).expand(B, N, H, W)
+
+    def grid(shift):                                                    # :427-441
+        gx = ((xs + shift) / (W - 1) - 0.5) * 2
+        gy = (ys / (H - 1) - 0.5) * 2
+        return torch.stack([gx, gy], -1).reshape(B * N, H, W, 2)
+
+    grid_r = grid(disp_layered[:B].expand(B, N, H, W))
+    grid_l = grid(-disp_layered[B:].expand(B, N, H, W))
+
+    def warp(t, g):
+        return bilinear_sample(t.reshape(B * N, 1, H, W), g, "zeros").reshape(B, N, H, W)
+
+    plr = torch.softmax(warp(logits[:B], grid_r), 1)                    # :443-446
+    o_l = warp(plr, grid_l).sum(1, True).clamp(max=1)                   # :447-449
+    pfrl = torch.softmax(warp(logits[B:].flip(-1), grid_l), 1)          # :451-453
+    o_fr = warp(pfrl, grid_r).sum(1, True).clamp(max=1)                 # :454-456
+    mean_disp = disp[:B] * 0.5 + disp[B:].flip(-1) * 0.5                # :458
+    disp_pp = mean_disp * o_fr + disp[:B] * (1 - o_fr)                  # :460
+    disp_pp = disp_pp * o_l + disp[-B:].flip(-1) * (1 - o_l)            # :461
+    mask_novel = warp(probability[:B], grid_r).sum(1, True).clamp(max=1)  # :463-465
+    return disp_pp, mask_novel

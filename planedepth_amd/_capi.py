@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS = 1, 2, 4, 8, 16
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
+PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
+PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
 PD_IMPL_AUTO, PD_IMPL_GENERAL = 0, 1
 
 
@@ -27,6 +29,7 @@ class SweepDesc(ctypes.Structure):
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_L = ctypes.c_int64
 _D = ctypes.POINTER(SweepDesc)
 
 # name -> (restype, argtypes); must list every symbol include/planedepth_hip.h declares
@@ -45,6 +48,14 @@ SIGNATURES = {
     "pd_reproj_loss_bwd": (_I, [_I] * 4 + [_P] * 6),
     "pd_mixture_nll_fwd": (_I, [_I] * 5 + [_P] * 5),
     "pd_mixture_nll_bwd": (_I, [_I] * 5 + [_P] * 8),
+    "pd_decoder_tail_bwd_workspace_floats": (ctypes.c_size_t, [_I] * 4),
+    "pd_decoder_tail_fwd": (_I, [_I] * 5 + [_P] * 10),
+    "pd_decoder_tail_layers": (_I, [_I] * 5 + [_P] * 7),
+    "pd_decoder_tail_bwd": (_I, [_I] * 5 + [_P] * 15),
+    "pd_smooth_loss_fwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P]),
+    "pd_smooth_loss_bwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),
+    "pd_warp_softmax": (_I, [_I] * 4 + [_F, _I, _P, _P, _P, _P]),
+    "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_backproject": (_I, [_I] * 3 + [_P] * 4),
     "pd_backproject_bwd": (_I, [_I] * 3 + [_P] * 4),
     "pd_project3d": (_I, [_I] * 3 + [_F] + [_P] * 4),

@@ -1,0 +1,67 @@
+"""Drop-in for the tail of the reference ``DepthDecoder.forward`` (networks/depth_decoder.py:256-291, softmax branch).
+
+The reference computes, after its last convolutions::
+
+    logits = self.convs["dispconv"](x) * padding_mask ; probability = softmax(logits)
+    sigma = clamp(sigmoid(self.convs["sigmaconv"](x)), 0.01, 1) ; pi = probability
+    probability = (pi / sigma * padding_mask) / sum ; disp = sum(probability * disp_layered) ; depth = 0.1*0.58*W/disp
+
+as ~12 full-tensor passes.  ``fused_decoder_tail`` does it in one HIP kernel (and one for the backward) and writes the
+same ``outputs`` entries.  It stays opt-in because ``networks/*`` are meant to drop in unchanged:
+a maintainer replaces lines 256-291 of ``depth_decoder.py`` with::
+
+    from planedepth_amd.decoder_tail import fused_decoder_tail
+    fused_decoder_tail(self.outputs, self.convs["dispconv"](x),
+                       self.convs["sigmaconv"](x) if self.use_mixture_loss else None,
+                       use_mixture_loss=self.use_mixture_loss, all_ones_mask=(self.xz_levels + self.yz_levels == 0))
+
+``--render_probability`` keeps the reference's own code (alpha compositing has no fused tail here).
+"""
+from . import ops
+
+
+class LazyLayers:
+    """``outputs["probability"]`` / ``outputs["pi"]`` stand-in: has ``.shape`` (all the training loop reads,
+    trainer.py:528, 610, 704) and materialises the tensor on first real use."""
+
+    def __init__(self, shape, make):
+        self.shape = tuple(shape)
+        self._make = make
+        self._value = None
+
+    def tensor(self):
+        if self._value is None:
+            self._value = self._make()
+        return self._value
+
+    def __getattr__(self, name):          # anything beyond .shape: behave like the tensor
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+
+def fused_decoder_tail(outputs, dispconv_out, sigmaconv_out=None, *, use_mixture_loss=True, all_ones_mask=False,
+                       materialize_layers=False):
+    """Fills ``outputs`` with "logits", "sigma", "pi", "probability", "disp", "depth" as depth_decoder.py:258-291 does.
+    Reads ``outputs["disp_layered"]`` and ``outputs["padding_mask"]`` (skipped when ``all_ones_mask`` says the decoder
+    built it with ``torch.ones_like``, i.e. xy planes only)."""
+    mask = None if all_ones_mask else outputs["padding_mask"]
+    logits, sigma, disp, depth, layers = ops.decoder_tail(dispconv_out, sigmaconv_out, mask, outputs["disp_layered"],
+                                                          use_mixture_loss=use_mixture_loss)
+    outputs["logits"] = logits
+    if use_mixture_loss:
+        outputs["sigma"] = sigma
+    shape = dispconv_out.shape
+    if materialize_layers:
+        pi, prob = layers(want_pi=use_mixture_loss, want_probability=True)
+        outputs["probability"] = prob
+        if use_mixture_loss:
+            outputs["pi"] = pi
+    else:
+        outputs["probability"] = LazyLayers(shape, lambda: layers(False, True)[1])
+        if use_mixture_loss:
+            outputs["pi"] = LazyLayers(shape, lambda: layers(True, False)[0])
+    outputs["disp"] = disp
+    outputs["depth"] = depth
+    return outputs

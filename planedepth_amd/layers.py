@@ -126,9 +126,6 @@ def multimodal_loss(error, sigma, pi, dist="gaussian"):
 
 
 def get_smooth_loss_disp(disp, img, gamma=1):
-    """Edge-aware smoothness of a disparity image (reference layers.py:243-256).  One plane, not N: cheap; SURVEY §8(f)."""
-    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
-    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
-    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
-    return (gdx * torch.exp(-gamma * gix)).mean() + (gdy * torch.exp(-gamma * giy)).mean()
+    """Edge-aware smoothness of a disparity image (reference layers.py:243-256) — one HIP kernel each way; the 0.2W
+    crops of trainer.py:768 are read in place through their strides."""
+    return ops.smooth_loss_disp(disp, img, gamma)

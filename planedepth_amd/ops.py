@@ -353,6 +353,214 @@ def multimodal_loss(error, sigma, pi, dist="gaussian"):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Post-process warps — forward only, as in the reference (no_grad networks, detached result)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pp_disp(disp_layered, B, N, H, W):
+    """(tensor, flags): per-plane [B,N] when the map is an H/W-expanded view, else the dense [B,N,H,W] map."""
+    if tuple(disp_layered.shape) != (B, N, H, W):
+        disp_layered = disp_layered.expand(B, N, H, W)
+    if disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0:
+        return disp_layered[:, :, 0, 0].contiguous(), 0
+    return disp_layered.contiguous(), C.PD_PP_DISP_DENSE
+
+
+def warp_softmax(planes, disp_layered, sign, flip_src=False):
+    """softmax over the planes of ``planes`` sampled at x + sign * disp (trainer.py:443-446 / 451-453)."""
+    lib = C.load()
+    C.require_gpu_tensor("planes", planes)
+    B, N, H, W = planes.shape
+    with torch.no_grad():
+        planes = planes.detach().contiguous()
+        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
+        out = torch.empty_like(planes)
+        with torch.cuda.device(planes.device):
+            C.check(lib.pd_warp_softmax(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
+                                        C.ptr(planes), C.ptr(disp), C.ptr(out), C.stream_handle(planes.device)),
+                    "pd_warp_softmax")
+    return out
+
+
+def warp_sum(planes, disp_layered, sign, cap=1.0, flip_src=False):
+    """min(cap, sum over the planes of ``planes`` sampled at x + sign * disp) (trainer.py:447-449, 454-456, 463-465)."""
+    lib = C.load()
+    C.require_gpu_tensor("planes", planes)
+    B, N, H, W = planes.shape
+    with torch.no_grad():
+        planes = planes.detach().contiguous()
+        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
+        out = torch.empty(B, 1, H, W, device=planes.device, dtype=torch.float32)
+        with torch.cuda.device(planes.device):
+            C.check(lib.pd_warp_sum(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
+                                    C.ptr(planes), C.ptr(disp), float(cap), C.ptr(out),
+                                    C.stream_handle(planes.device)), "pd_warp_sum")
+    return out
+
+
+def post_process_disp(logits, probability, disp, disp_layered):
+    """trainer.py:421-466 given the fixed model's outputs for cat([image, mirrored image]) -> (disp_pp, mask_novel)."""
+    B = probability.shape[0] // 2
+    with torch.no_grad():
+        dl_r, dl_l = disp_layered[:B], disp_layered[B:]
+        plr = warp_softmax(logits[:B], dl_r, +1.0)                       # :443-446
+        o_l = warp_sum(plr, dl_l, -1.0)                                  # :447-449
+        pfrl = warp_softmax(logits[B:], dl_l, -1.0, flip_src=True)       # :451-453 (the flip is folded into the read)
+        o_fr = warp_sum(pfrl, dl_r, +1.0)                                # :454-456
+        disp_f = disp[B:].flip(-1)
+        mean_disp = disp[:B] * 0.5 + disp_f * 0.5                        # :458
+        disp_pp = mean_disp * o_fr + disp[:B] * (1 - o_fr)               # :460
+        disp_pp = disp_pp * o_l + disp_f * (1 - o_l)                     # :461
+        prob = probability.tensor() if hasattr(probability, "tensor") else probability
+        mask_novel = warp_sum(prob[:B], dl_r, +1.0)                      # :463-465
+    return disp_pp, mask_novel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Smoothness loss (SURVEY.md 8f rank 3)
+# ---------------------------------------------------------------------------------------------------------------------
+def _row_strided(name, t):
+    """A [B,C,H,W] fp32 GPU tensor whose columns are unit-stride (e.g. the crop t[..., k:]) as it is, else a copy."""
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError("%s must be a float32 GPU tensor (got %s on %s)" % (name, t.dtype, t.device))
+    return t if (t.stride(3) == 1 and min(t.stride()[:3]) >= 0) else t.contiguous()
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img, gamma):
+        lib = C.load()
+        B, Cn, H, W = img.shape
+        if tuple(disp.shape) != (B, 1, H, W):
+            raise ValueError("disp must be [B,1,H,W] matching img, got %s vs %s" % (tuple(disp.shape), tuple(img.shape)))
+        disp, img = _row_strided("disp", disp), _row_strided("img", img)
+        out = torch.empty(1, device=disp.device, dtype=torch.float32)
+        with torch.cuda.device(disp.device):
+            C.check(lib.pd_smooth_loss_fwd(B, Cn, H, W, C.ptr(disp), disp.stride(0), disp.stride(2), C.ptr(img),
+                                           img.stride(0), img.stride(1), img.stride(2), float(gamma), C.ptr(out),
+                                           C.stream_handle(disp.device)), "pd_smooth_loss_fwd")
+        ctx.save_for_backward(disp, img)
+        ctx.gamma = float(gamma)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = C.load()
+        disp, img = ctx.saved_tensors
+        B, Cn, H, W = img.shape
+        g_disp = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        g = g.reshape(1).contiguous().float()
+        with torch.cuda.device(disp.device):
+            C.check(lib.pd_smooth_loss_bwd(B, Cn, H, W, C.ptr(disp), disp.stride(0), disp.stride(2), C.ptr(img),
+                                           img.stride(0), img.stride(1), img.stride(2), ctx.gamma, C.ptr(g),
+                                           C.ptr(g_disp), C.stream_handle(disp.device)), "pd_smooth_loss_bwd")
+        return g_disp, None, None
+
+
+def smooth_loss_disp(disp, img, gamma=1.0):
+    """get_smooth_loss_disp (reference layers.py:243-256) as one kernel each way; crops are read in place."""
+    return _SmoothLoss.apply(disp, img, gamma)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Decoder tail (SURVEY.md 8f rank 1)
+# ---------------------------------------------------------------------------------------------------------------------
+class _DecoderTail(torch.autograd.Function):
+    """(raw_logits, raw_sigma, disp_layered[, padding_mask]) -> (logits, sigma, disp, depth, stash)."""
+
+    @staticmethod
+    def forward(ctx, raw_logits, raw_sigma, disp_layered, padding_mask, flags):
+        lib = C.load()
+        B, N, H, W = raw_logits.shape
+        mix = bool(flags & C.PD_TAIL_MIXTURE)
+        C.require_gpu_tensor("raw_logits", raw_logits)
+        if mix:
+            C.require_gpu_tensor("raw_sigma", raw_sigma, (B, N, H, W))
+        C.require_gpu_tensor("disp_layered", disp_layered, (B, N, H, W) if flags & C.PD_TAIL_DISP_DENSE else (B, N))
+        if padding_mask is not None:
+            C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H, W))
+        raw_logits, raw_sigma, disp_layered, padding_mask = map(_contig, (raw_logits, raw_sigma, disp_layered, padding_mask))
+        dev = raw_logits.device
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
+        logits = new(B, N, H, W) if padding_mask is not None else None
+        sigma = new(B, N, H, W) if mix else None
+        disp, depth, stash = new(B, 1, H, W), new(B, 1, H, W), new(B, 2, H, W)
+        with torch.cuda.device(dev):
+            C.check(lib.pd_decoder_tail_fwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
+                                            C.ptr(disp_layered), C.ptr(logits), C.ptr(sigma), C.ptr(disp), C.ptr(depth),
+                                            C.ptr(stash), C.stream_handle(dev)), "pd_decoder_tail_fwd")
+        ctx.save_for_backward(raw_logits, raw_sigma, disp_layered, padding_mask, stash, disp)
+        ctx.flags = flags
+        ctx.mark_non_differentiable(stash)
+        if logits is None:       # no mask: the logits ARE the conv output (reference: logits * ones)
+            logits = raw_logits.view_as(raw_logits)
+        if sigma is None:
+            sigma = new(0)
+            ctx.mark_non_differentiable(sigma)
+        return logits, sigma, disp, depth, stash
+
+    @staticmethod
+    def backward(ctx, g_logits, g_sigma, g_disp, g_depth, _g_stash):
+        lib = C.load()
+        raw_logits, raw_sigma, disp_layered, padding_mask, stash, disp = ctx.saved_tensors
+        B, N, H, W = raw_logits.shape
+        flags = ctx.flags
+        mix = bool(flags & C.PD_TAIL_MIXTURE)
+        need_l, need_s, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and mix, ctx.needs_input_grad[2]
+        if not (need_l or need_s or need_d):
+            return None, None, None, None, None
+        g_raw_logits = torch.empty_like(raw_logits) if need_l else None
+        g_raw_sigma = torch.empty_like(raw_sigma) if need_s else None
+        g_dl = torch.empty_like(disp_layered) if need_d else None
+        ws = None
+        if need_d and not (flags & C.PD_TAIL_DISP_DENSE):
+            ws = torch.empty(lib.pd_decoder_tail_bwd_workspace_floats(B, N, H, W), device=raw_logits.device,
+                             dtype=torch.float32)
+        g_logits, g_sigma, g_disp, g_depth = map(_contig, (g_logits, g_sigma if mix else None, g_disp, g_depth))
+        with torch.cuda.device(raw_logits.device):
+            C.check(lib.pd_decoder_tail_bwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
+                                            C.ptr(disp_layered), C.ptr(stash), C.ptr(disp), C.ptr(g_logits),
+                                            C.ptr(g_sigma), C.ptr(g_disp), C.ptr(g_depth), C.ptr(g_raw_logits),
+                                            C.ptr(g_raw_sigma), C.ptr(g_dl), C.ptr(ws),
+                                            C.stream_handle(raw_logits.device)), "pd_decoder_tail_bwd")
+        return g_raw_logits, g_raw_sigma, g_dl, None, None
+
+
+def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_loss=True):
+    """Tail of DepthDecoder.forward (networks/depth_decoder.py:256-291, softmax branch) in one fused pass.
+
+    Returns (logits, sigma | None, disp, depth, layers) where ``layers()`` materialises ``(pi, probability)`` on demand
+    (no gradient: nothing in the reference's losses reads them).  ``disp_layered`` may be the decoder's expanded view of
+    per-plane scalars or a dense map; ``padding_mask=None`` means all ones (xy planes only).
+    """
+    B, N, H, W = raw_logits.shape
+    if tuple(disp_layered.shape) != (B, N, H, W):
+        disp_layered = disp_layered.expand(B, N, H, W)
+    per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
+    plane = _per_plane_view(disp_layered) if per_plane else disp_layered
+    flags = (C.PD_TAIL_MIXTURE if use_mixture_loss else 0) | (0 if per_plane else C.PD_TAIL_DISP_DENSE)
+    if padding_mask is not None:
+        if padding_mask.dtype != torch.float32:
+            padding_mask = padding_mask.float()
+        if tuple(padding_mask.shape) != (B, N, H, W):
+            padding_mask = padding_mask.expand(B, N, H, W)
+    logits, sigma, disp, depth, stash = _DecoderTail.apply(raw_logits, raw_sigma if use_mixture_loss else None, plane,
+                                                           padding_mask, flags)
+
+    def layers(want_pi=True, want_probability=True):
+        lib = C.load()
+        with torch.no_grad():
+            pi = torch.empty_like(raw_logits) if want_pi else None
+            prob = torch.empty_like(raw_logits) if want_probability else None
+            rl, rs, pm = map(_contig, (raw_logits.detach(), raw_sigma.detach() if use_mixture_loss else None, padding_mask))
+            with torch.cuda.device(raw_logits.device):
+                C.check(lib.pd_decoder_tail_layers(B, N, H, W, flags, C.ptr(rl), C.ptr(rs), C.ptr(pm), C.ptr(stash),
+                                                   C.ptr(pi), C.ptr(prob), C.stream_handle(raw_logits.device)),
+                        "pd_decoder_tail_layers")
+        return pi, prob
+
+    return logits, (sigma if use_mixture_loss else None), disp, depth, layers
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Geometry
 # ---------------------------------------------------------------------------------------------------------------------
 class _Backproject(torch.autograd.Function):

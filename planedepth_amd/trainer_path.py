@@ -172,9 +172,36 @@ def compute_losses(self, inputs, outputs):
     return losses
 
 
+def generate_post_process_disp(self, inputs):
+    """Self-distillation targets (reference trainer.py:404-466): run the FIXED networks on cat([image, mirrored image])
+    exactly as the reference does (:405-419 — the networks are the reference's own, untouched), then the occlusion-aware
+    blend of the two predictions through the fused warp kernels instead of five grid_samples."""
+    opt = self.opt
+    input_images = torch.cat([inputs[("color_aug", "l")], inputs[("color_aug", "l")].flip(-1)], dim=0)
+    input_grids = None
+    if opt.num_ep > 0:
+        grid_fliped = inputs["grid"].clone()
+        grid_fliped[:, 0, :, :] *= -1.
+        grid_fliped = grid_fliped.flip(-1)
+        input_grids = torch.cat([inputs["grid"], grid_fliped], dim=0)
+    if opt.net_type == "ResNet":
+        features = self.fixed_models["encoder"](input_images)
+        outputs = self.fixed_models["depth"](features, input_grids)
+    elif opt.net_type == "PladeNet":
+        outputs = self.models["plade"](input_images, input_grids)
+    elif opt.net_type == "FalNet":
+        outputs = self.models["fal"](input_images)
+    else:
+        raise ValueError("unknown net_type %r" % (opt.net_type,))
+    disp_pp, mask_novel = ops.post_process_disp(outputs["logits"], outputs["probability"], outputs["disp"],
+                                                outputs["disp_layered"])
+    return disp_pp.detach(), mask_novel.detach()
+
+
 def patch_trainer(trainer_cls):
     """Bind the fused hot path onto a reference-style Trainer class (drop-in)."""
     trainer_cls.pred_novel_images = pred_novel_images
     trainer_cls.compute_reprojection_loss = compute_reprojection_loss
     trainer_cls.compute_losses = compute_losses
+    trainer_cls.generate_post_process_disp = generate_post_process_disp
     return trainer_cls

@@ -149,6 +149,84 @@ def module_vectors(ref):
     return {k: v.detach().numpy() for k, v in out.items()}
 
 
+def decoder_tail_vectors(ref):
+    """The reference DepthDecoder's own tail (networks/depth_decoder.py:256-291) on prescribed conv outputs: forward hooks
+    replace what dispconv / sigmaconv return by seeded leaf tensors, everything after them is the reference's code."""
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    H, W, B = 64, 64, 1   # smallest the decoder's five stride-2 levels accept (reflection pad at H/32)
+    for tag, kw in (("mix_xz", dict(no_levels=4, xz_levels=2, use_mixture_loss=True, plane_residual=True)),
+                    ("mix_xy", dict(no_levels=5, xz_levels=0, use_mixture_loss=True, plane_residual=True)),
+                    ("l1_xy", dict(no_levels=4, xz_levels=0, use_mixture_loss=False, plane_residual=False))):
+        torch.manual_seed(11)
+        dec = ref.networks.DepthDecoder([64, 64, 128, 256, 512], use_denseaspp=False, **kw)
+        N = kw["no_levels"] + kw["xz_levels"]
+        feats = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), generator=g) * 0.5
+                 for i, c in enumerate([64, 64, 128, 256, 512])]
+        raw_logits = (torch.randn(B, N, H, W, generator=g) * 3).requires_grad_(True)
+        raw_sigma = (torch.randn(B, N, H, W, generator=g) * 3.5 - 1.0).requires_grad_(True)  # both clamp bounds are hit
+        dec.convs["dispconv"].register_forward_hook(lambda m, i, o: raw_logits)
+        if kw["use_mixture_loss"]:
+            dec.convs["sigmaconv"].register_forward_hook(lambda m, i, o: raw_sigma)
+        ys = torch.linspace(-1, 1, H)[None, None, :, None].expand(B, 1, H, W)
+        xs = torch.linspace(-1, 1, W)[None, None, None, :].expand(B, 1, H, W)
+        grid = torch.cat([xs, ys], 1).contiguous()
+        o = dec(feats, grid)
+        if o["disp_layered"].requires_grad:  # only with plane_residual (the levels are constants otherwise)
+            o["disp_layered"].retain_grad()
+        gw_l = torch.randn(B, N, H, W, generator=g)
+        gw_s = torch.randn(B, N, H, W, generator=g)
+        gw_d = torch.randn(B, 1, H, W, generator=g)
+        gw_z = torch.randn(B, 1, H, W, generator=g) * 0.1
+        obj = (o["logits"] * gw_l).sum() + (o["disp"] * gw_d).sum() + (o["depth"] * gw_z).sum()
+        if kw["use_mixture_loss"]:
+            obj = obj + (o["sigma"] * gw_s).sum()
+        obj.backward()
+        blob = dict(raw_logits=raw_logits, raw_sigma=raw_sigma, padding_mask=o["padding_mask"].float(),
+                    disp_layered=o["disp_layered"], logits=o["logits"], probability=o["probability"], disp=o["disp"],
+                    depth=o["depth"], gw_logits=gw_l, gw_sigma=gw_s, gw_disp=gw_d, gw_depth=gw_z,
+                    g_raw_logits=raw_logits.grad)
+        if o["disp_layered"].grad is not None:
+            blob.update(g_disp_layered=o["disp_layered"].grad)
+        if kw["use_mixture_loss"]:
+            blob.update(sigma=o["sigma"], pi=o["pi"], g_raw_sigma=raw_sigma.grad)
+        out.update({"%s/%s" % (tag, k): v.detach().numpy() for k, v in blob.items()})
+        out["%s/mixture" % tag] = np.asarray(int(kw["use_mixture_loss"]))
+        print("decoder_tail %-8s disp mean %.5f" % (tag, float(o["disp"].detach().mean())))
+    return out
+
+
+def post_process_vectors(ref):
+    """Trainer.generate_post_process_disp (trainer.py:404-466) with the fixed networks replaced by a stub that returns
+    prescribed decoder outputs for the batch cat([image, mirrored image])."""
+    import types
+    g = torch.Generator().manual_seed(909)
+    out = {}
+    for tag, (B, N, H, W, dense) in (("xy", (2, 6, 10, 48, False)), ("rows", (1, 5, 9, 70, True))):
+        logits = torch.randn(2 * B, N, H, W, generator=g) * 2
+        sigma = torch.rand(2 * B, N, H, W, generator=g) * 0.9 + 0.05
+        w = torch.softmax(logits, 1) / sigma
+        probability = w / w.sum(1, True)
+        levels = torch.arange(N, dtype=torch.float32)[None, :, None, None] + torch.rand(2 * B, N, 1, 1, generator=g) - 0.5
+        disp_layered = (0.4 * W) * (1.0 / (0.4 * W)) ** (levels / (N - 1))
+        disp_layered = disp_layered.expand(-1, -1, H, W)
+        if dense:  # row-dependent disparities as xz planes give
+            disp_layered = disp_layered * (0.5 + torch.linspace(0, 1, H)[None, None, :, None])
+        disp = (probability * disp_layered).sum(1, True)
+        fixed = dict(logits=logits, probability=probability, disp=disp, disp_layered=disp_layered)
+        ns = types.SimpleNamespace()
+        ns.opt = types.SimpleNamespace(num_ep=1, net_type="ResNet")
+        ns.softmax = torch.nn.Softmax(1)
+        ns.fixed_models = {"encoder": lambda x: None, "depth": lambda f, gr: fixed}
+        color = torch.rand(B, 3, H, W, generator=g)
+        inputs = {("color_aug", "l"): color, "grid": torch.zeros(B, 2, H, W)}
+        disp_pp, mask_novel = ref.trainer.Trainer.generate_post_process_disp(ns, inputs)
+        out.update({"%s/%s" % (tag, k): v.detach().numpy() for k, v in
+                    dict(fixed, disp_pp=disp_pp, mask_novel=mask_novel).items()})
+        print("post_process %-5s disp_pp mean %.5f mask_novel mean %.5f" % (tag, float(disp_pp.mean()), float(mask_novel.mean())))
+    return out
+
+
 def scalars(res):
     f = lambda t: float(t.double().sum())  # noqa: E731
     a = lambda t: float(t.double().abs().sum())  # noqa: E731
@@ -169,6 +247,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **blob)
         print("%-24s ph=%.8f sum_rgb=%.6f" % (name, float(res["ph_loss"]), float(res["rgb_rec"].sum())))
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "decoder_tail.npz"), **decoder_tail_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "post_process.npz"), **post_process_vectors(ref))
     kat = {}
     for name, _, rkw in FULL_CASES:
         case = survey_fullsize_case()

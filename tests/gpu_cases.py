@@ -27,7 +27,8 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
         inputs[("color", side)] = c["color_r"]
     outputs = {"probability": torch.empty(B, N, H, W, device="meta"), "logits": logits, "sigma": sigma,
                "disp_layered": disp_layered, "padding_mask": c["padding_mask"], "distance": distance, "norm": norm,
-               ("Rt", side): Rt, "disp": torch.zeros(B, 1, H, W, device=device)}
+               ("Rt", side): Rt,
+               "disp": (torch.softmax(logits.detach(), 1) * disp_layered.detach()).sum(1, True)}  # as make_golden.py
     if "mask_novel" in c:
         outputs["mask_novel"] = c["mask_novel"]
     dists = None
@@ -36,7 +37,7 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
         outputs["dists"] = dists
     opt = types.SimpleNamespace(warp_type=warp, match_aug=False, use_mixture_loss=mix, automask=run.get("automask", False),
                                 render_probability=run.get("render_probability", False), alpha_pc=0.0, alpha_self=0.0,
-                                self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=True,
+                                self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=True,
                                 materialize_layers=True, **(opt_extra or {}))
     ns = types.SimpleNamespace(opt=opt, target_sides=[side],
                                perceptual_loss=lambda *a, **k: torch.zeros((), device=device))
@@ -46,6 +47,7 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
     (losses["loss/ph_loss"] + (rgb_rec * c["g_rgb_rec"]).sum()).backward()
     z = torch.zeros_like
     res = dict(rgb_rec=rgb_rec, ph_loss=losses["loss/ph_loss"], ph_map=outputs[("ph_map", side)],
+               smooth_loss=losses["loss/smooth_loss"], total_loss=losses["loss/total_loss"],
                g_logits=logits.grad, g_sigma=sigma.grad if sigma.grad is not None else z(sigma),
                g_disp_pp=disp_pp.grad if disp_pp.grad is not None else z(disp_pp),
                g_Rt=Rt.grad if Rt.grad is not None else z(Rt))

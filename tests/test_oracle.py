@@ -98,3 +98,41 @@ def test_fullsize_known_answers():
         assert abs(float(got["rgb_rec"].double().sum()) - kat[name]["sum_rgb_rec"]) < 1e-6 * kat[name]["sum_rgb_rec"]
         assert abs(float(got["g_logits"].double().abs().sum()) - kat[name]["l1_g_logits"]) < 1e-4 * kat[name]["l1_g_logits"]
         assert abs(float(got["g_sigma"].double().abs().sum()) - kat[name]["l1_g_sigma"]) < 1e-4 * kat[name]["l1_g_sigma"]
+
+
+def _npz_group(path, tag):
+    z = np.load(os.path.join(GOLDEN, path))
+    return {k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/")}
+
+
+@pytest.mark.parametrize("tag", ["mix_xz", "mix_xy", "l1_xy"])
+def test_decoder_tail_against_reference_vectors(tag):
+    """the oracle's decoder tail against what the reference DepthDecoder produced from the same conv
+    outputs (tests/golden/make_golden.py::decoder_tail_vectors), forward and — through autograd — backward."""
+    z = _npz_group("decoder_tail.npz", tag)
+    mix = bool(int(z["mixture"]))
+    rl = z["raw_logits"].clone().requires_grad_(True)
+    rs = z["raw_sigma"].clone().requires_grad_(True)
+    dl = z["disp_layered"].clone().requires_grad_(True)
+    W = rl.shape[-1]
+    o = orc.decoder_tail(rl, rs, z["padding_mask"], dl, W, use_mixture_loss=mix)
+    for k in ("logits", "probability", "disp", "depth") + (("sigma", "pi") if mix else ()):
+        assert rel_err(o[k], z[k]) < TOL, (tag, k, rel_err(o[k], z[k]))
+    obj = (o["logits"] * z["gw_logits"]).sum() + (o["disp"] * z["gw_disp"]).sum() + (o["depth"] * z["gw_depth"]).sum()
+    if mix:
+        obj = obj + (o["sigma"] * z["gw_sigma"]).sum()
+    obj.backward()
+    assert rel_err(rl.grad, z["g_raw_logits"]) < TOL
+    if mix:
+        assert rel_err(rs.grad, z["g_raw_sigma"]) < TOL
+    if "g_disp_layered" in z:
+        assert rel_err(dl.grad, z["g_disp_layered"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["xy", "rows"])
+def test_post_process_against_reference_vectors(tag):
+    """generate_post_process_disp restated, against the reference's own output."""
+    z = _npz_group("post_process.npz", tag)
+    disp_pp, mask_novel = orc.post_process_disp(z["logits"], z["probability"], z["disp"], z["disp_layered"])
+    assert rel_err(disp_pp, z["disp_pp"]) < TOL
+    assert rel_err(mask_novel, z["mask_novel"]) < TOL
