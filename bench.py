@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no_padding_mask", action="store_true", help="never pass a padding mask (diagnostics)")
     ap.add_argument("--no_plane_grad", action="store_true", help="diagnostics: disparities do not require grad")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_next_rows", action="store_true", help="skip the timings of the SURVEY 8f operators")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -161,6 +162,73 @@ def kernel_times(args, c, device, iters):
     return out
 
 
+def next_rows_times(args, device, iters=10):
+    """SURVEY.md §8f rows (decoder tail, smoothness loss, post-process) at the headline shape: average ms per call from
+    CUDA events around the public operators (the launches are on torch's current stream), with the algorithmic bytes
+    each moves.  Reported next to the headline number; not part of `value`."""
+    from planedepth_amd import ops
+    B, N, H, W = args.batch, args.planes, args.height, args.width
+    g = torch.Generator().manual_seed(99)
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(device)  # noqa: E731
+    raw_l, raw_s = mk(B, N, H, W).requires_grad_(True), mk(B, N, H, W).requires_grad_(True)
+    lv = (torch.arange(N, dtype=torch.float32)[None, :, None, None] + torch.rand(B, N, 1, 1, generator=g) - 0.5).to(device)
+    lv.requires_grad_(True)
+    gl, gs, gd = mk(B, N, H, W), mk(B, N, H, W), mk(B, 1, H, W)
+    img = torch.rand(B, 3, H, W, generator=g).to(device)
+    x0 = int(0.2 * W)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(device)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(device)
+        return sum(a.elapsed_time(b) for a, b in ev) / iters
+
+    def tail_fwd():
+        with torch.no_grad():
+            dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+            return ops.decoder_tail(raw_l, raw_s, None, dl)
+
+    def tail_fwd_bwd():
+        dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+        logits, sigma, disp, depth, _ = ops.decoder_tail(raw_l, raw_s, None, dl)
+        torch.autograd.backward([logits, sigma, disp], [gl, gs, gd])
+        raw_l.grad = raw_s.grad = lv.grad = None
+
+    disp_leaf = (torch.rand(B, 1, H, W, generator=g) * 50).to(device).requires_grad_(True)
+
+    def smooth_fwd_bwd():
+        ops.smooth_loss_disp(disp_leaf[..., x0:], img[..., x0:], 2.0).backward()
+        disp_leaf.grad = None
+
+    Bp = max(1, B // 2)
+    pl, pp = mk(2 * Bp, N, H, W), torch.softmax(mk(2 * Bp, N, H, W), 1)
+    pdl = (300.0 * (2.0 / 300.0) ** (lv.detach()[:1].expand(2 * Bp, -1, -1, -1) / (N - 1))).expand(-1, -1, H, W)
+    pdisp = (pp * pdl).sum(1, True)
+
+    def post():
+        ops.post_process_disp(pl, pp, pdisp, pdl)
+
+    t_f, t_fb, t_s, t_p = timed(tail_fwd), timed(tail_fwd_bwd), timed(smooth_fwd_bwd), timed(post)
+    hw4 = H * W * 4
+    tail_f_bytes, tail_b_bytes = (3 * N + 4) * hw4 * B, (6 * N + 4) * hw4 * B
+    post_bytes = (2 * (2 * N) + 2 * N + N + 3) * hw4 * Bp   # 2 warp-softmax (read N, write N) + 3 warp-sums (read N)
+    return {
+        "decoder_tail": {"fwd_ms": round(t_f, 4), "fwd_bwd_ms": round(t_fb, 4),
+                         "fwd_GBs": round(tail_f_bytes / (t_f * 1e-3) / 1e9, 1),
+                         "fwd_bwd_GBs": round((tail_f_bytes + tail_b_bytes) / (t_fb * 1e-3) / 1e9, 1),
+                         "shape": [B, N, H, W]},
+        "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "shape": [B, 1, H, W - x0]},
+        "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
+                         "shape": [2 * Bp, N, H, W]},
+        "note": "CUDA-event time around the public operators (includes their Python launch overhead)",
+    }
+
+
 def measured_traffic(args, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if they were taken on this
     exact workload; None otherwise (bench.py cannot run the profiler around itself)."""
@@ -267,6 +335,8 @@ def main():
                 "fwd_GBs": round(fwd_b * args.batch / (kt["fwd"] * 1e-3) / 1e9, 1),
                 "bwd_GBs": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9, 1),
                 "whole_path_frac_of_peak": round((fwd_b + bwd_b) * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and not args.no_next_rows:
+            result["next_rows"] = next_rows_times(args, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
