@@ -108,6 +108,16 @@ __device__ __forceinline__ void buf_store(Rsrc r, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }
 
+// Offset of plane n inside one image's [N,H,W] block, in floats: a 32-bit product (the host checks N*H*W < 2^31) added
+// to a per-workgroup 64-bit base — the full 64-bit (b*N + n)*HW product per plane and tensor was a third of the scalar
+// instructions of the plane loop.
+__device__ __forceinline__ const float* plane_ptr(const float* image_base, int n, int HW) {
+  return image_base + (unsigned)(n * HW);
+}
+__device__ __forceinline__ float* plane_ptr(float* image_base, int n, int HW) {
+  return image_base + (unsigned)(n * HW);
+}
+
 // The (up to) four taps of one scalar plane, loaded up-front.  Out-of-image taps come back as 0 from the hardware.
 template <int NROWS>
 struct Taps {
@@ -300,7 +310,7 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
-    const float* pl = a.logits + ((long)b * a.N + n) * HW;  // workgroup-uniform
+    const float* pl = plane_ptr(a.logits + (long)b * a.N * HW, n, HW);  // workgroup-uniform
     if (kAblate & 8) {  // diagnostics: no coordinate chain (integer shift, constant weights)
       g.ct[u].x0 = x + (int)sdisp[n]; g.ct[u].w0 = 0.25f; g.ct[u].w1 = 0.75f;
     } else {
@@ -311,7 +321,7 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
 #endif
     g.mval[u] = 1.0f;
     if (HASMASK && !(kAblate & 16))
-      g.mval[u] = buf_load(row_rsrc_uniform(a.padding_mask + ((long)b * a.N + n) * HW + (long)y * a.W, a.W), (unsigned)x << 2);
+      g.mval[u] = buf_load(row_rsrc_uniform(plane_ptr(a.padding_mask + (long)b * a.N * HW + (long)y * a.W, n, HW), a.W), (unsigned)x << 2);
     if (kAblate & 1) {  // diagnostics: no logit / sigma loads
       g.tl[u].a0 = g.tl[u].a1 = g.tl[u].b0 = g.tl[u].b1 = g.ct[u].w0;
       g.ts[u] = g.tl[u];
@@ -319,7 +329,7 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
       const TapPos tp = tap_pos(g.ct[u]);
       g.tl[u] = load_taps<NROWS>(row_rsrc(pl + (long)row.yA * a.W, a.W), row_rsrc(pl + (long)row.yB * a.W, a.W), tp);
       if (MIX) {
-        const float* ps = a.sigma + ((long)b * a.N + n) * HW;
+        const float* ps = plane_ptr(a.sigma + (long)b * a.N * HW, n, HW);
         g.ts[u] = load_taps<NROWS>(row_rsrc(ps + (long)row.yA * a.W, a.W), row_rsrc(ps + (long)row.yB * a.W, a.W), tp);
       }
     }
@@ -637,7 +647,6 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
-    const long pl = ((long)b * N + n) * HW;
     const int k = kshift[n];  // nominal shift floor(s*d), |k| <= W
     bool mk = sc.active;
     if (HASMASK) {
@@ -678,10 +687,10 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     const unsigned xoff = sc.active ? xw4 : 0xFFFFFFF0u;
     float* bp = bnd + (sc.seg * N + n) * 6;
     const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bp);
-    if (o.g_logits) buf_store(row_rsrc(o.g_logits + pl + (long)y * W, W), xoff, out_l);
+    if (o.g_logits) buf_store(row_rsrc(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), W), xoff, out_l);
     if (MIX) {
       const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
-      if (o.g_sigma) buf_store(row_rsrc(o.g_sigma + pl + (long)y * W, W), xoff, out_s);
+      if (o.g_sigma) buf_store(row_rsrc(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), W), xoff, out_s);
     }
     // (per-lane LDS partials, one ds_add_f32 per plane, measured 12% slower than the DPP reduction + one atomic)
     if (want_plane) {
@@ -853,6 +862,7 @@ static int row_threads(int W) {
 
 bool rowshift_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
+         (long)d->N * d->H * d->W < (1L << 31) &&
          (size_t)(d->W + 4) * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
 }
 
