@@ -45,8 +45,11 @@ enum pd_sweep_flags {
   PD_AUTOMASK = 2,    /* opt.automask: min with the identity-reprojection loss (trainer.py:731-734, 739-741)      */
   PD_RENDER_PROB = 4, /* opt.render_probability: alpha compositing instead of softmax (trainer.py:584-591)        */
   PD_DISP_DENSE = 8,  /* disp mode: `plane` is a dense [B,N,H,W] map (xz/yz planes) instead of [B,N] scalars      */
-  PD_DISP_ROWS = 16   /* disp mode: `plane` is [B,N,H], one disparity per plane and ROW (xy + xz planes: the decoder's
+  PD_DISP_ROWS = 16,  /* disp mode: `plane` is [B,N,H], one disparity per plane and ROW (xy + xz planes: the decoder's
                          map is constant along x, depth_decoder.py:153-181).  Only where pd_sweep_uses_rowshift() */
+  PD_MASK_ROWS = 32   /* disp mode: `padding_mask` is [B,N,H], one value per plane and row (the xz horizon mask is
+                         constant along x, depth_decoder.py:166).  Only where pd_sweep_uses_rowshift(): a masked plane
+                         row is treated as shifted out of view, so the mask costs no per-pixel traffic at all */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };

@@ -383,6 +383,13 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
     set_error("PD_DISP_ROWS is served by the row-shift kernels only (pd_sweep_uses_rowshift); pass a dense map instead");
     return PD_ERR_UNSUPPORTED;
   }
+  if (d->flags & PD_MASK_ROWS) {
+    PD_REQUIRE(d->mode == PD_WARP_DISP && padding_mask, "PD_MASK_ROWS needs disp mode and a [B,N,H] padding mask");
+    if (!pd_sweep_uses_rowshift(d)) {
+      set_error("PD_MASK_ROWS is served by the row-shift kernels only (pd_sweep_uses_rowshift); pass the dense mask instead");
+      return PD_ERR_UNSUPPORTED;
+    }
+  }
   return PD_OK;
 }
 
@@ -394,9 +401,12 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.flags = d->flags;
   a.sign = d->sign;
   a.stash_k = kStashBase + ((d->mode == PD_WARP_DISP) ? (d->N + 31) / 32 : 0);
-  a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr) ? 1 : 0;
+  const bool mask_rows = (d->flags & PD_MASK_ROWS) != 0;
+  a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr && !mask_rows) ? 1 : 0;
   a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
-  a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3; a.padding_mask = padding_mask;
+  a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3;
+  a.padding_mask = mask_rows ? nullptr : padding_mask;
+  a.mask_rows = mask_rows ? padding_mask : nullptr;
   a.dists = dists;
   return a;
 }

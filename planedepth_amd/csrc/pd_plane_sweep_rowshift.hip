@@ -282,7 +282,10 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
   for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
     const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
     const float sd = a.sign * a.plane[di];
-    sdisp[i] = (sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f) ? -lim : lim);  // NaN -> +lim: out of view
+    // PD_MASK_ROWS: a masked plane samples as all-zero features (trainer.py:580) — exactly what a plane shifted out
+    // of view does (every tap is outside the row), so the row's mask value just overrides the shift
+    const bool masked = a.mask_rows && a.mask_rows[((long)b * a.N + i) * a.H + yrow] == 0.0f;
+    sdisp[i] = (!masked && sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
   }
 }
 

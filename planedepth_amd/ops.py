@@ -50,7 +50,7 @@ class _PlaneSweep(torch.autograd.Function):
             C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else
                                  ((B, N, H) if flags & C.PD_DISP_ROWS else (B, N)))
             if padding_mask is not None:
-                C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H, W))
+                C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H) if flags & C.PD_MASK_ROWS else (B, N, H, W))
         else:
             C.require_gpu_tensor("H_t2s", plane, (B * N, 3, 3))
             C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
@@ -159,11 +159,16 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
         padding_mask = padding_mask.float()
     if padding_mask is not None and tuple(padding_mask.shape) != (B, N, H, W):
         padding_mask = padding_mask.expand(B, N, H, W)
+    flags = _flags(use_mixture_loss, automask, dense=not (per_plane or rows), render=render_probability, rows=rows)
+    if padding_mask is not None and row_uniform and (per_plane or rows) and not render_probability:
+        # the mask of xy / xz planes is constant along x as well (depth_decoder.py:157, 166): hand over its first column
+        probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, SWEEP_IMPL)
+        if C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)):
+            padding_mask = padding_mask[..., 0]
+            flags |= C.PD_MASK_ROWS
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
     return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
-                             dists if render_probability else None, C.PD_WARP_DISP,
-                             _flags(use_mixture_loss, automask, dense=not (per_plane or rows), render=render_probability,
-                                    rows=rows), sign)
+                             dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
 
 
 def homography_matrices(d, n, T, K, inv_K):

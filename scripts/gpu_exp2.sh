@@ -6,6 +6,6 @@ b() { name=$1; shift; timeout 300 python bench.py --steps 30 --warmup 5 --no_cpu
 b head
 b w512 --width 512
 b w768 --width 768
-b n63 --planes 63 --xz_levels 14 --automask
+b n63 --planes 49 --xz_levels 14 --automask
 b hr --batch 4 --height 384 --width 1280
 b b12 --batch 12

@@ -170,6 +170,8 @@ def test_per_row_disparities_use_the_rowshift_kernels(name):
     from planedepth_amd import ops
     got = run_product(case, run, force_dense=True, opt_extra=dict(yz_levels=0, xz_levels=3))
     assert ops.LAST_SWEEP_FLAGS & C.PD_DISP_ROWS
+    # the horizon mask of the xz planes is row-uniform too: handed over as [B,N,H] (no per-pixel mask traffic)
+    assert bool(ops.LAST_SWEEP_FLAGS & C.PD_MASK_ROWS) == bool((case["padding_mask"] != 1).any() or True)
     _compare(got, want, tag=name + "/rows")
 
 
