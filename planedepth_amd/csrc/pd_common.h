@@ -135,6 +135,55 @@ __device__ __forceinline__ float dpp_zero(float v) {  // lanes without a source 
 
 // lane i receives lane i-1 across the whole wave; lane 0 receives 0
 __device__ __forceinline__ float wave_shift_up1(float v) { return dpp_zero<0x138>(v); }
+// lane i receives lane i+1 (wave_shl:1); lane 63 receives `fallback`
+__device__ __forceinline__ int wave_from_next(int v, int fallback) {
+  return __builtin_amdgcn_update_dpp(fallback, v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float wave_from_next(float v) { return dpp_zero<0x130>(v); }
+// lane i receives lane i-1 (wave_shr:1); lane 0 receives `fallback`
+__device__ __forceinline__ int wave_from_prev(int v, int fallback) {
+  return __builtin_amdgcn_update_dpp(fallback, v, 0x138, 0xF, 0xF, false);
+}
+
+// ---- wave-cooperative adjoint of `bilinear` --------------------------------------------------------------------------
+// The general backward is bound by the L2 atomic units (4 fp32 atomics per pixel, plane and tensor: measured at one
+// atomic per clock and L2 channel).  Neighbouring target pixels usually land on neighbouring source pixels: where lane
+// i+1's LEFT column is lane i's RIGHT column on the same source rows, lane i adds lane i+1's left-tap contributions to
+// its own right-tap ones and lane i+1 skips its left atomics — two atomics per lane instead of four.  Both helpers
+// must be called by all 64 lanes of the wave (`live` = this lane contributes at all).
+struct ScatterPlan {
+  bool take;   // absorb the next lane's left taps into my right taps
+  bool taken;  // my left taps are absorbed by the previous lane
+};
+__device__ __forceinline__ ScatterPlan plan_scatter(const Tap& t, int W, bool live) {
+  constexpr int kNone = -(1 << 30), kNone2 = -(1 << 29);  // never one apart from each other or from a real key
+  // (source row, left column) as one integer; x0 is clamped to [-2, W], so a pitch of W + 4 keeps "keys one apart"
+  // equivalent to "same row, adjacent column" (with pitch W, column -1 of row y+1 would follow column W-1 of row y)
+  const int key = live ? t.y0 * (W + 4) + (t.x0 + 2) : kNone;
+  const int give = (live && t.vx1) ? key : kNone2;                // my right column exists: I can absorb
+  // The cross-lane reads come first, unconditionally: inside a short-circuit `&&` they would run under a partial
+  // EXEC mask, and a disabled source lane reads as the fallback — the two sides of a pair would then disagree.
+  const int next_key = wave_from_next(key, kNone);      // lane 63: kNone  -> never takes
+  const int prev_give = wave_from_prev(give, kNone2);   // lane 0:  kNone2 -> never taken
+  ScatterPlan p;
+  p.take = (next_key == give + 1);
+  p.taken = (prev_give + 1 == key);
+  return p;
+}
+__device__ __forceinline__ void bilinear_scatter_wave(float* __restrict__ p, const Tap& t, int W, float g, bool live,
+                                                      const ScatterPlan& sp) {
+  const float cL0 = g * (t.wx0 * t.wy0), cR0 = g * (t.wx1 * t.wy0), cL1 = g * (t.wx0 * t.wy1), cR1 = g * (t.wx1 * t.wy1);
+  const float nL0 = wave_from_next(cL0), nL1 = wave_from_next(cL1);   // the next lane's left taps (same addresses as my right)
+  if (!live) return;
+  float* r0 = p + (long)t.y0 * W + t.x0;
+  float* r1 = r0 + W;
+  if (!sp.taken) {
+    if (t.vx0 && t.vy0) unsafeAtomicAdd(r0, cL0);
+    if (t.vx0 && t.vy1) unsafeAtomicAdd(r1, cL1);
+  }
+  if (t.vx1 && t.vy0) unsafeAtomicAdd(r0 + 1, sp.take ? cR0 + nL0 : cR0);
+  if (t.vx1 && t.vy1) unsafeAtomicAdd(r1 + 1, sp.take ? cR1 + nL1 : cR1);
+}
 
 // Sum over the 64 lanes; the total is valid in lanes 48..63 (use lane 63).
 __device__ __forceinline__ float wave_sum_hi(float v) {

@@ -173,6 +173,11 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
     float gk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) gk[k] = 0.0f;
+    // what this lane scatters for plane n (filled in below; the scatter itself runs wave-wide after the branches)
+    Tap st;
+    st.x0 = st.y0 = 0; st.wx0 = st.wx1 = st.wy0 = st.wy1 = 0.0f; st.vx0 = st.vx1 = st.vy0 = st.vy1 = false;
+    float sg_l = 0.0f, sg_s = 0.0f;
+    bool live = false;
     if (active) {
       bool mk;
       const PlaneGeom g = plane_coords<MODE>(a, b, n, x, y, iy_disp, mk);
@@ -208,8 +213,7 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
           pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
         }
         const float g_l = pg.g_l, g_s = pg.g_s, gc0 = pg.gc0, gc1 = pg.gc1, gc2 = pg.gc2;
-        if (MIX && o.g_sigma) bilinear_scatter(o.g_sigma + pl, t, a.W, g_s);
-        if (o.g_logits) bilinear_scatter(o.g_logits + pl, t, a.W, g_l);
+        st = t; sg_l = g_l; sg_s = g_s; live = true;
         if (want_plane) {
           // d loss / d (ix, iy) in pixels, then back through grid_sample's un-normalisation ((size-1)/2) and the
           // reference's normalisation (*2, /(size-1)) in autograd's order.
@@ -233,11 +237,17 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
       if (render && !mk && o.g_dists && n < a.N - 1) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = 0.0f;
       if (dense && want_plane) o.g_plane[pl + pix] = gd_dense;
     }
+    {  // adjoint of the bilinear gather, all 64 lanes together (pd_common.h: neighbours share their atomics)
+      const long pl = ((long)b * a.N + n) * HW;
+      const ScatterPlan sp = plan_scatter(st, a.W, live);
+      if (MIX && o.g_sigma) bilinear_scatter_wave(o.g_sigma + pl, st, a.W, sg_s, live, sp);
+      if (o.g_logits) bilinear_scatter_wave(o.g_logits + pl, st, a.W, sg_l, live, sp);
+    }
     if (reduce_plane) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float v = wave_sum(gk[k]);
-        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[n * K + k], v);  // LDS atomic, 4 waves
+        const float v = wave_sum_hi(gk[k]);  // DPP reduction (no LDS round trips), total in lane 63
+        if ((threadIdx.x & (kWave - 1)) == kWave - 1) atomicAdd(&red[n * K + k], v);  // LDS atomic, 4 waves
       }
     }
   }
