@@ -177,12 +177,15 @@ __device__ __forceinline__ void bilinear_scatter_wave(float* __restrict__ p, con
   if (!live) return;
   float* r0 = p + (long)t.y0 * W + t.x0;
   float* r1 = r0 + W;
+  // contributions that are exactly zero are skipped: rows whose vertical round trip is exact (3 of 4 in disp mode) have
+  // wy1 == 0 and would otherwise spend half of their atomics on adding 0.0
   if (!sp.taken) {
-    if (t.vx0 && t.vy0) unsafeAtomicAdd(r0, cL0);
-    if (t.vx0 && t.vy1) unsafeAtomicAdd(r1, cL1);
+    if (t.vx0 && t.vy0 && cL0 != 0.0f) unsafeAtomicAdd(r0, cL0);
+    if (t.vx0 && t.vy1 && cL1 != 0.0f) unsafeAtomicAdd(r1, cL1);
   }
-  if (t.vx1 && t.vy0) unsafeAtomicAdd(r0 + 1, sp.take ? cR0 + nL0 : cR0);
-  if (t.vx1 && t.vy1) unsafeAtomicAdd(r1 + 1, sp.take ? cR1 + nL1 : cR1);
+  const float a0 = sp.take ? cR0 + nL0 : cR0, a1 = sp.take ? cR1 + nL1 : cR1;
+  if (t.vx1 && t.vy0 && a0 != 0.0f) unsafeAtomicAdd(r0 + 1, a0);
+  if (t.vx1 && t.vy1 && a1 != 0.0f) unsafeAtomicAdd(r1 + 1, a1);
 }
 
 // Sum over the 64 lanes; the total is valid in lanes 48..63 (use lane 63).
