@@ -412,6 +412,7 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.sign = d->sign;
   a.stash_k = kStashBase + ((d->mode == PD_WARP_DISP) ? (d->N + 31) / 32 : 0);
   const bool mask_rows = (d->flags & PD_MASK_ROWS) != 0;
+  a.fast_rows = (d->impl == PD_IMPL_FAST_ROWS) ? 1 : 0;
   a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr && !mask_rows) ? 1 : 0;
   a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
   a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3;

@@ -1,1 +1,1 @@
-python scripts/diag_w70.py 2>&1 | tail -5
+python scripts/diag_w130.py 2>&1 | tail -9
