@@ -216,6 +216,13 @@ int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* 
                 float* out, pd_stream_t stream);
 
 /*
+ * Trainer.add_flip_right_inputs (trainer.py:252-276): out [2B,C,H,W] = cat([own, flip(other, -1)]);
+ * negate_c0 flips the sign of channel 0 in the mirrored half (the x-coordinate channel of `grid`, trainer.py:258-260).
+ */
+int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other, int negate_c0, float* out,
+                pd_stream_t stream);
+
+/*
  * Geometry modules.
  *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
  *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]

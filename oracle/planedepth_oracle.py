@@ -378,3 +378,21 @@ def post_process_disp(logits, probability, disp, disp_layered):
     disp_pp = disp_pp * o_l + disp[-B:].flip(-1) * (1 - o_l)            # :461
     mask_novel = warp(probability[:B], grid_r).sum(1, True).clamp(max=1)  # :463-465
     return disp_pp, mask_novel
+
+
+def add_flip_right_inputs(inputs, novel_frame_ids=()):
+    """trainer.py:252-276: batch doubling with the mirrored other view (restated; pure data movement)."""
+    new = {}
+    for key in ("color", "color_aug", "depth_gt"):
+        if (key, "l") in inputs and (key, "r") in inputs:
+            new[(key, "l")] = torch.cat([inputs[(key, "l")], inputs[(key, "r")].flip(-1)], 0)
+            new[(key, "r")] = torch.cat([inputs[(key, "r")], inputs[(key, "l")].flip(-1)], 0)
+    g = inputs["grid"].clone()
+    g[:, 0] *= -1.0
+    new["grid"] = torch.cat([inputs["grid"], g.flip(-1)], 0)
+    for key in ("K", "inv_K", ("Rt", "l"), ("Rt", "r")):
+        new[key] = inputs[key].repeat(2, 1, 1)
+    for f in novel_frame_ids:
+        for key in ("color", "color_aug"):
+            new[(key, f)] = torch.cat([inputs[(key, f)], inputs[(key, f)].flip(-1)], 0)
+    return new

@@ -6,7 +6,7 @@ from . import decoder_tail, layers, ops, synthetic, trainer_path  # noqa: F401
 from .decoder_tail import fused_decoder_tail  # noqa: F401
 from .layers import (SSIM, BackprojectDepth, HomographyWarp, Project3D, disp_to_depth,  # noqa: F401
                      get_smooth_loss_disp, multimodal_loss)
-from .trainer_path import (compute_losses, compute_reprojection_loss, generate_post_process_disp,  # noqa: F401
+from .trainer_path import (add_flip_right_inputs, compute_losses, compute_reprojection_loss, generate_post_process_disp,  # noqa: F401
                            patch_trainer, pred_novel_images)
 
 __version__ = "0.1.0"

@@ -420,6 +420,24 @@ def post_process_disp(logits, probability, disp, disp_layered):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Batch doubling of add_flip_right_inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def cat_flip(own, other, negate_c0=False):
+    """cat([own, other.flip(-1)], dim=0) in one kernel (trainer.py:253-262); ``negate_c0`` for the grid tensor."""
+    lib = C.load()
+    C.require_gpu_tensor("own", own)
+    C.require_gpu_tensor("other", other, tuple(own.shape))
+    B, Cn, H, W = own.shape
+    with torch.no_grad():
+        own, other = own.contiguous(), other.contiguous()
+        out = torch.empty(2 * B, Cn, H, W, device=own.device, dtype=torch.float32)
+        with torch.cuda.device(own.device):
+            C.check(lib.pd_cat_flip(B, Cn, H, W, C.ptr(own), C.ptr(other), int(bool(negate_c0)), C.ptr(out),
+                                    C.stream_handle(own.device)), "pd_cat_flip")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Smoothness loss (SURVEY.md 8f rank 3)
 # ---------------------------------------------------------------------------------------------------------------------
 def _row_strided(name, t):

@@ -198,10 +198,29 @@ def generate_post_process_disp(self, inputs):
     return disp_pp.detach(), mask_novel.detach()
 
 
+def add_flip_right_inputs(self, inputs):
+    """Batch doubling with the mirrored other view (reference trainer.py:252-276): the same dict, one kernel per image
+    tensor instead of a flip copy plus a cat copy.  Inputs are data: no gradients."""
+    new_inputs = {}
+    for key in ("color", "color_aug", "depth_gt"):
+        if (key, "l") in inputs and (key, "r") in inputs:
+            new_inputs[(key, "l")] = ops.cat_flip(inputs[(key, "l")], inputs[(key, "r")])
+            new_inputs[(key, "r")] = ops.cat_flip(inputs[(key, "r")], inputs[(key, "l")])
+    new_inputs["grid"] = ops.cat_flip(inputs["grid"], inputs["grid"], negate_c0=True)   # :258-261
+    for key in ("K", "inv_K", ("Rt", "l"), ("Rt", "r")):
+        new_inputs[key] = inputs[key].repeat(2, 1, 1)
+    # the left +1/-1 frame becomes the right side, but it should not affect the training (reference comment, :271)
+    for f in self.opt.novel_frame_ids:
+        for key in ("color", "color_aug"):
+            new_inputs[(key, f)] = ops.cat_flip(inputs[(key, f)], inputs[(key, f)])
+    return new_inputs
+
+
 def patch_trainer(trainer_cls):
     """Bind the fused hot path onto a reference-style Trainer class (drop-in)."""
     trainer_cls.pred_novel_images = pred_novel_images
     trainer_cls.compute_reprojection_loss = compute_reprojection_loss
     trainer_cls.compute_losses = compute_losses
     trainer_cls.generate_post_process_disp = generate_post_process_disp
+    trainer_cls.add_flip_right_inputs = add_flip_right_inputs
     return trainer_cls

@@ -542,3 +542,22 @@ def test_post_process_fullsize_vs_oracle():
     got = ops.post_process_disp(logits.cuda(), prob.cuda(), disp.cuda(), dl.cuda())
     assert rel_err(got[0].cpu(), want[0]) < TOL
     assert rel_err(got[1].cpu(), want[1]) < TOL
+
+
+def test_add_flip_right_inputs_is_bit_exact():
+    """the batch-doubling kernel against the oracle's cat/flip restatement of trainer.py:252-276."""
+    import types
+    import planedepth_amd as pa
+    from oracle import planedepth_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 3, 13, 37
+    inputs = {(k, s): torch.rand(B, 3, H, W, generator=g) for k in ("color", "color_aug") for s in ("l", "r", -1, 1)}
+    inputs.update({("depth_gt", s): torch.rand(B, 1, H, W, generator=g) for s in ("l", "r")})
+    inputs["grid"] = torch.randn(B, 2, H, W, generator=g)
+    inputs.update({k: torch.randn(B, 4, 4, generator=g) for k in ("K", "inv_K", ("Rt", "l"), ("Rt", "r"))})
+    want = orc.add_flip_right_inputs(inputs, novel_frame_ids=(-1, 1))
+    ns = types.SimpleNamespace(opt=types.SimpleNamespace(novel_frame_ids=[-1, 1]))
+    got = pa.add_flip_right_inputs(ns, {k: v.cuda() for k, v in inputs.items()})
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k].cpu(), want[k]), k

@@ -39,3 +39,38 @@ def test_live(bkw, rkw):
             assert float(got[k].abs().max()) == 0.0, k
         else:
             assert rel_err(got[k], w) < 2e-6, (k, rel_err(got[k], w))
+
+
+def test_add_flip_right_inputs_live():
+    """trainer.py:252-276 against the oracle's restatement (bit-exact data movement)."""
+    import types
+    import torch
+    from ref_import import load_reference
+    from oracle import planedepth_oracle as orc
+    ref = load_reference()
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 6, 10
+    inputs = {(k, s): torch.rand(B, 3, H, W, generator=g) for k in ("color", "color_aug") for s in ("l", "r", 1)}
+    inputs.update({("depth_gt", s): torch.rand(B, 1, H, W, generator=g) for s in ("l", "r")})
+    inputs["grid"] = torch.randn(B, 2, H, W, generator=g)
+    inputs.update({k: torch.randn(B, 4, 4, generator=g) for k in ("K", "inv_K", ("Rt", "l"), ("Rt", "r"))})
+    ns = types.SimpleNamespace(opt=types.SimpleNamespace(novel_frame_ids=[1]))
+    want = ref.trainer.Trainer.add_flip_right_inputs(ns, inputs)
+    got = orc.add_flip_right_inputs(inputs, novel_frame_ids=(1,))
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_next_row_fixtures_are_what_the_reference_produces_now():
+    """Regenerate the decoder-tail and post-process vectors from the reference and compare with the committed fixtures
+    (guards against stale fixtures; the oracle is checked against those fixtures in test_oracle.py)."""
+    import numpy as np
+    from make_golden import decoder_tail_vectors, post_process_vectors
+    from ref_import import load_reference
+    ref = load_reference()
+    for fname, fresh in (("decoder_tail.npz", decoder_tail_vectors(ref)), ("post_process.npz", post_process_vectors(ref))):
+        stored = np.load(os.path.join(GOLDEN, fname))
+        assert set(stored.files) == set(fresh)
+        for k in stored.files:
+            np.testing.assert_allclose(stored[k], fresh[k], rtol=1e-6, atol=1e-7, err_msg="%s:%s" % (fname, k))
