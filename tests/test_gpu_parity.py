@@ -561,3 +561,24 @@ def test_add_flip_right_inputs_is_bit_exact():
     assert set(got) == set(want)
     for k in want:
         assert torch.equal(got[k].cpu(), want[k]), k
+
+
+@pytest.mark.parametrize("label,case_kw,run,opt_extra", [
+    # BASELINE configs[2]/[3] plane count: 49 xy + 14 xz planes, horizon mask, automask (per-row disparities + row masks)
+    ("n63_xz", dict(B=1, N=63, H=192, W=640, n_xz=14), dict(automask=True), dict(yz_levels=0, xz_levels=14)),
+    # BASELINE config (5): high resolution
+    ("hr", dict(B=1, N=49, H=384, W=1280), dict(), dict(yz_levels=0, xz_levels=0)),
+])
+def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extra):
+    """The other full-size configurations of BASELINE.json / SURVEY §8d against the fp32 oracle (B=1)."""
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import survey_fullsize_case
+    case = survey_fullsize_case(sigma_interior=True, **case_kw)
+    got = run_product(case, run, opt_extra=opt_extra)
+    if label == "n63_xz":
+        assert ops.LAST_SWEEP_FLAGS & C.PD_DISP_ROWS and ops.LAST_SWEEP_FLAGS & C.PD_MASK_ROWS
+    want = run_oracle(case, run)
+    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_disp_pp"), tag=label)
+    _compare(got, want, keys=("g_sigma",), tag=label, tol=2e-4)
