@@ -51,6 +51,16 @@ def test_argument_validation_needs_no_gpu():
     assert b"warp mode" in lib.pd_last_error()
     assert lib.pd_ssim_fwd(0, 3, 8, 8, None, None, None, None) == 1
     assert lib.pd_grid_sample_fwd(1, 1, 4, 4, 4, 4, 9, None, None, None, None) == 1
+    # the next-row entry points validate before they launch, too
+    assert lib.pd_decoder_tail_fwd(1, 4, 8, 8, C.PD_TAIL_MIXTURE, *([None] * 10)) == 1
+    assert b"NULL" in lib.pd_last_error()
+    assert lib.pd_decoder_tail_fwd(1, 4, 8, 8, 64, *([None] * 10)) == 1
+    assert b"flags" in lib.pd_last_error()
+    assert lib.pd_smooth_loss_fwd(1, 3, 1, 8, None, 0, 0, None, 0, 0, 0, 1.0, None, None) == 1
+    assert lib.pd_warp_sum(1, 4, 8, 8, 1.0, 0, None, None, 1.0, None, None) == 1
+    assert lib.pd_cat_flip(0, 3, 8, 8, None, None, 0, None, None) == 1
+    assert lib.pd_mixture_nll_fwd(1, 4, 8, 8, 1, None, None, None, None, None) == 1
+    assert lib.pd_decoder_tail_bwd_workspace_floats(2, 49, 192, 640) == 2 * 480 * 49
 
 
 def test_ops_refuse_cpu_tensors():
@@ -65,6 +75,16 @@ def test_ops_refuse_cpu_tensors():
         ops.grid_sample(src, torch.zeros(B, H, W, 2))
     with pytest.raises(NotImplementedError):
         ops.grid_sample(src, torch.zeros(B, H, W, 2), padding_mode="reflection")
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.decoder_tail(lg, lg, None, torch.ones(B, N, 1, 1).expand(B, N, H, W))
+    with pytest.raises((C.PlaneDepthHipError, TypeError)):
+        ops.smooth_loss_disp(src[:, :1], src, 2.0)
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.warp_sum(lg, torch.ones(B, N, 1, 1).expand(B, N, H, W), 1.0)
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.cat_flip(src, src)
+    with pytest.raises(C.PlaneDepthHipError):
+        ops.multimodal_loss(lg, lg.sigmoid(), lg.softmax(1), "lap")
 
 
 def test_product_never_imports_the_oracle():
