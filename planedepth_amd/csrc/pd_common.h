@@ -88,6 +88,44 @@ __device__ __forceinline__ float bilinear_vg(const float* __restrict__ p, const 
   return nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
 }
 
+// The same footprint in "kernel form": clamped element offsets + coefficients that are zero for taps outside the image,
+// shared by every tensor sampled at this position.  Sampling is then four unconditional loads and four FMAs per tensor
+// (value), four more per derivative — no validity selects at the loads (the general sweep kernels are VALU-bound and
+// sample five tensors per pixel and plane).  A zero coefficient times a finite border value is an exact zero, which is
+// what padding_mode="zeros" asks for.
+struct TapK {
+  unsigned o00, o01, o10, o11;  // BYTE offsets of (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1) inside an [H,W] plane: unsigned
+                                // 32-bit, so a load is "uniform base + zero-extended lane offset" (no 64-bit lane math)
+  float w00, w01, w10, w11;    // value weights
+  float x00, x01, x10, x11;    // d value / d ix coefficients
+  float y00, y01, y10, y11;    // d value / d iy coefficients
+};
+__device__ __forceinline__ TapK tap_kernel(const Tap& t, int W, int H) {
+  TapK k;
+  const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
+  const int ya = min(max(t.y0, 0), H - 1) * W, yb = min(max(t.y0 + 1, 0), H - 1) * W;
+  k.o00 = (unsigned)(ya + xa) << 2; k.o01 = (unsigned)(ya + xb) << 2;
+  k.o10 = (unsigned)(yb + xa) << 2; k.o11 = (unsigned)(yb + xb) << 2;
+  const float m00 = (t.vx0 && t.vy0) ? 1.0f : 0.0f, m01 = (t.vx1 && t.vy0) ? 1.0f : 0.0f;
+  const float m10 = (t.vx0 && t.vy1) ? 1.0f : 0.0f, m11 = (t.vx1 && t.vy1) ? 1.0f : 0.0f;
+  k.w00 = t.wx0 * t.wy0 * m00; k.w01 = t.wx1 * t.wy0 * m01; k.w10 = t.wx0 * t.wy1 * m10; k.w11 = t.wx1 * t.wy1 * m11;
+  k.x00 = -t.wy0 * m00; k.x01 = t.wy0 * m01; k.x10 = -t.wy1 * m10; k.x11 = t.wy1 * m11;
+  k.y00 = -t.wx0 * m00; k.y01 = -t.wx1 * m01; k.y10 = t.wx0 * m10; k.y11 = t.wx1 * m11;
+  return k;
+}
+__device__ __forceinline__ float at_byte(const float* __restrict__ p, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off);
+}
+__device__ __forceinline__ float sample_k(const float* __restrict__ p, const TapK& k) {
+  return at_byte(p, k.o00) * k.w00 + at_byte(p, k.o01) * k.w01 + at_byte(p, k.o10) * k.w10 + at_byte(p, k.o11) * k.w11;
+}
+__device__ __forceinline__ float sample_vg_k(const float* __restrict__ p, const TapK& k, float& dx, float& dy) {
+  const float nw = at_byte(p, k.o00), ne = at_byte(p, k.o01), sw = at_byte(p, k.o10), se = at_byte(p, k.o11);
+  dx = nw * k.x00 + ne * k.x01 + sw * k.x10 + se * k.x11;
+  dy = nw * k.y00 + ne * k.y01 + sw * k.y10 + se * k.y11;
+  return nw * k.w00 + ne * k.w01 + sw * k.w10 + se * k.w11;
+}
+
 // Adjoint of `bilinear`: scatter g to the (valid) taps with hardware fp32 atomics (global_atomic_add_f32).
 __device__ __forceinline__ void bilinear_scatter(float* __restrict__ p, const Tap& t, int W, float g) {
   float* r0 = p + (long)t.y0 * W + t.x0;

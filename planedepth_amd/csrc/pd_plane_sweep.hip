@@ -109,13 +109,13 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
     }
     float l = 0.0f, s = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     if (mk) {  // rec_features * padding_mask (trainer.py:580): a masked plane samples as all-zero features
-      const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
+      const TapK t = tap_kernel(make_tap(g.ix, g.iy, a.W, a.H), a.W, a.H);
       const long pl = ((long)b * a.N + n) * HW;
-      l = bilinear(a.logits + pl, t, a.W);
-      if (MIX) s = bilinear(a.sigma + pl, t, a.W);
-      c0 = bilinear(srcb, t, a.W);
-      c1 = bilinear(srcb + HW, t, a.W);
-      c2 = bilinear(srcb + 2 * HW, t, a.W);
+      l = sample_k(a.logits + pl, t);
+      if (MIX) s = sample_k(a.sigma + pl, t);
+      c0 = sample_k(srcb, t);
+      c1 = sample_k(srcb + HW, t);
+      c2 = sample_k(srcb + 2 * HW, t);
     }
     if (render) {
       const bool last = (n == a.N - 1);
@@ -190,11 +190,12 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
       if (mk) {
         const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
         float dlx, dly, dsx = 0, dsy = 0, d0x, d0y, d1x, d1y, d2x, d2y;
-        const float l = bilinear_vg(a.logits + pl, t, a.W, dlx, dly);
-        const float c0 = bilinear_vg(srcb, t, a.W, d0x, d0y);
-        const float c1 = bilinear_vg(srcb + HW, t, a.W, d1x, d1y);
-        const float c2 = bilinear_vg(srcb + 2 * HW, t, a.W, d2x, d2y);
-        const float s = MIX ? bilinear_vg(a.sigma + pl, t, a.W, dsx, dsy) : 0.0f;
+        const TapK tk = tap_kernel(t, a.W, a.H);
+        const float l = sample_vg_k(a.logits + pl, tk, dlx, dly);
+        const float c0 = sample_vg_k(srcb, tk, d0x, d0y);
+        const float c1 = sample_vg_k(srcb + HW, tk, d1x, d1y);
+        const float c2 = sample_vg_k(srcb + 2 * HW, tk, d2x, d2y);
+        const float s = MIX ? sample_vg_k(a.sigma + pl, tk, dsx, dsy) : 0.0f;
         PlaneGrad pg;
         if (render) {  // alpha compositing: d prob_k / d alpha_n for k >= n through the transmittance (trainer.py:584-591)
           const bool last = (n == a.N - 1);
@@ -304,13 +305,13 @@ __global__ __launch_bounds__(kBlock) void sweep_layers_kernel(SweepArgs a, Layer
       float l = 0, s = 0, c0 = 0, c1 = 0, c2 = 0;
       const long pl = ((long)b * a.N + n) * HW;
       if (mk) {
-        const Tap t = make_tap(g.ix, g.iy, a.W, a.H);
-        l = bilinear(a.logits + pl, t, a.W);
-        if (MIX) s = bilinear(a.sigma + pl, t, a.W);
+        const TapK t = tap_kernel(make_tap(g.ix, g.iy, a.W, a.H), a.W, a.H);
+        l = sample_k(a.logits + pl, t);
+        if (MIX) s = sample_k(a.sigma + pl, t);
         if (pass == 1 && o.rgb_rec_layered) {
-          c0 = bilinear(srcb, t, a.W);
-          c1 = bilinear(srcb + HW, t, a.W);
-          c2 = bilinear(srcb + 2 * HW, t, a.W);
+          c0 = sample_k(srcb, t);
+          c1 = sample_k(srcb + HW, t);
+          c2 = sample_k(srcb + 2 * HW, t);
         }
       }
       const float sg = fminf(fmaxf(s, kSigmaMin), kSigmaMax);
