@@ -4,6 +4,7 @@ Every function here launches hand-written HIP kernels through ctypes on torch's 
 device memory, streams and autograd plumbing only; there is no eager / CPU implementation behind these ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -12,7 +13,7 @@ from . import _capi as C
 
 # Kernel selection for the sweep (C.PD_IMPL_AUTO | C.PD_IMPL_GENERAL).  Tests flip it to cross-check the specialised
 # row-shift kernels against the general ones; leave it alone otherwise.
-SWEEP_IMPL = C.PD_IMPL_AUTO
+SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
 
