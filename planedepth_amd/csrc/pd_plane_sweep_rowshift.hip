@@ -539,7 +539,10 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
       for (; gi + 2 <= nfull; gi += 2) {
         PD_FISSUE(g1, gi + 1);
         PD_FCOMP(g0, gi);
-        if (gi + 2 < nfull) PD_FISSUE(g0, gi + 2);
+        // Unconditional on purpose: under an `if` the waitcnt pass has to assume the loads were NOT issued, counts too
+        // few operations in flight and makes every second group wait for the loads issued right before it (found in
+        // the ISA: vmcnt(7)..(0) instead of (15)..(8)).  On the last round this re-loads the final group; nobody reads it.
+        PD_FISSUE(g0, min(gi + 2, nfull - 1));
         PD_FCOMP(g1, gi + 1);
       }
       if (gi < nfull) PD_FCOMP(g0, gi);
@@ -772,7 +775,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
       for (; gi + 2 <= nfull; gi += 2) {
         PD_BISSUE(g1, gi + 1);
         PD_BCOMP(g0, gi);
-        if (gi + 2 < nfull) PD_BISSUE(g0, gi + 2);
+        PD_BISSUE(g0, min(gi + 2, nfull - 1));  // unconditional: see the forward
         PD_BCOMP(g1, gi + 1);
       }
       if (gi < nfull) PD_BCOMP(g0, gi);
