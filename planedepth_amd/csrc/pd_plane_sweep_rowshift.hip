@@ -552,9 +552,9 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
       for (; gi + 3 <= nfull; gi += 3) {
         PD_FISSUE(g2, gi + 2);
         PD_FCOMP(g0, gi);
-        if (gi + 3 < nfull) PD_FISSUE(g0, gi + 3);
+        PD_FISSUE(g0, min(gi + 3, nfull - 1));
         PD_FCOMP(g1, gi + 1);
-        if (gi + 4 < nfull) PD_FISSUE(g1, gi + 4);
+        PD_FISSUE(g1, min(gi + 4, nfull - 1));
         PD_FCOMP(g2, gi + 2);
       }
       if (gi < nfull) PD_FCOMP(g0, gi);
@@ -785,9 +785,9 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
       for (; gi + 3 <= nfull; gi += 3) {
         PD_BISSUE(g2, gi + 2);
         PD_BCOMP(g0, gi);
-        if (gi + 3 < nfull) PD_BISSUE(g0, gi + 3);
+        PD_BISSUE(g0, min(gi + 3, nfull - 1));
         PD_BCOMP(g1, gi + 1);
-        if (gi + 4 < nfull) PD_BISSUE(g1, gi + 4);
+        PD_BISSUE(g1, min(gi + 4, nfull - 1));
         PD_BCOMP(g2, gi + 2);
       }
       if (gi < nfull) PD_BCOMP(g0, gi);
