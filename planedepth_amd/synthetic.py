@@ -18,6 +18,16 @@ def intrinsics(B, H, W):
     return K, inv_K
 
 
+def dataset_intrinsics(B, H, W):
+    """K / inv_K with the dataset's own float32 arithmetic (kitti_dataset.py:29-32 scaled in place, mono_dataset.py:
+    194-198) — an ulp away from ``intrinsics`` (which keeps the values BASELINE.md's known answers were taken with)."""
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    K[0, :] *= W
+    K[1, :] *= H
+    inv_K = np.linalg.pinv(K)
+    return torch.from_numpy(K)[None].repeat(B, 1, 1), torch.from_numpy(inv_K)[None].repeat(B, 1, 1)
+
+
 def small_pose(gen, B, rot=0.01, trans=0.05, stereo=False):
     """A rigid motion [B,4,4]: stereo = identity with tx=-0.1, otherwise a small random rotation + translation."""
     T = torch.eye(4)[None].repeat(B, 1, 1)
@@ -93,3 +103,50 @@ def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=Fals
     return dict(color_l=color_l, color_r=color_r, logits=logits, sigma=sigma, disp_pp=disp_pp,
                 row_gain=row_gain, padding_mask=padding_mask, K=K, inv_K=inv_K, Rt=Rt,
                 g_rgb_rec=torch.randn(B, 3, H, W, generator=g2) * 1e-5, dense_disp=bool(n_xz))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference data pipeline's conventions without the dataset
+# ---------------------------------------------------------------------------------------------------------------------
+def crop_grid(H, W, full_h, full_w, h0, w0):
+    """``inputs["grid"]`` as ``RandomResizeCrop`` makes it (datasets/pair_transforms.py:35-37): x / y coordinates in
+    [-1, 1] over the RESIZED full image (``full_w`` x ``full_h``), cropped to the ``H x W`` window at (h0, w0).
+    ``Resize`` (no crop, pair_transforms.py:63-64) is the special case full = (H, W), h0 = w0 = 0.  -> [2,H,W]."""
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, full_w), torch.linspace(-1, 1, full_h), indexing="xy")
+    return torch.stack([gx, gy], 0)[:, h0:h0 + H, w0:w0 + W].clone()
+
+
+def kitti_like_inputs(B, H, W, seed=0, *, crop=True, novel_frame_ids=(), device="cpu"):
+    """A minibatch with the keys, shapes and conventions of the reference's KITTI pipeline (datasets/mono_dataset.py:
+    193-211 + pair_transforms.py), from a seeded generator instead of image files:
+
+    * ``("color", s)``, ``("color_aug", s)`` for s in l, r (+ novel frame ids): [B,3,H,W] in [0,1];
+    * ``"grid"`` [B,2,H,W]: per-sample random resize factor and crop window as RandomResizeCrop draws them
+      (``crop=False``: the plain Resize grid);
+    * ``"K"`` = K_KITTI scaled by (W, H), ``"inv_K"`` = ``np.linalg.pinv(K)`` (mono_dataset.py:194-198);
+    * ``("Rt","l")`` / ``("Rt","r")``: identity with tx = +0.1 / -0.1 (mono_dataset.py:203-211).
+    """
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    inputs = {}
+    for s in ("l", "r") + tuple(novel_frame_ids):
+        img = torch.rand(B, 3, H, W, generator=g)
+        inputs[("color", s)] = img
+        inputs[("color_aug", s)] = img.clone()
+    grids = []
+    for _ in range(B):
+        if crop:
+            full_h0, full_w0 = 375, 1242                                       # KITTI full resolution
+            fmin = max((H + 1) / full_h0, (W + 1) / full_w0)                   # pair_transforms.py:29
+            factor = rng.uniform(fmin, max(fmin, 1.0))
+            fh, fw = int(full_h0 * factor), int(full_w0 * factor)
+            h0, w0 = rng.randint(0, fh - H + 1), rng.randint(0, fw - W + 1)
+            grids.append(crop_grid(H, W, fh, fw, h0, w0))
+        else:
+            grids.append(crop_grid(H, W, H, W, 0, 0))
+    inputs["grid"] = torch.stack(grids, 0)
+    inputs["K"], inputs["inv_K"] = dataset_intrinsics(B, H, W)
+    Tl, Tr = torch.eye(4)[None].repeat(B, 1, 1), torch.eye(4)[None].repeat(B, 1, 1)
+    Tl[:, 0, 3], Tr[:, 0, 3] = 0.1, -0.1
+    inputs[("Rt", "l")], inputs[("Rt", "r")] = Tl, Tr
+    return {k: v.to(device) for k, v in inputs.items()}

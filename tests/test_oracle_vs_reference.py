@@ -74,3 +74,37 @@ def test_next_row_fixtures_are_what_the_reference_produces_now():
         assert set(stored.files) == set(fresh)
         for k in stored.files:
             np.testing.assert_allclose(stored[k], fresh[k], rtol=1e-6, atol=1e-7, err_msg="%s:%s" % (fname, k))
+
+
+def test_synthetic_pipeline_follows_the_reference_conventions():
+    """grid / K / inv_K / Rt of planedepth_amd.synthetic.kitti_like_inputs against what the
+    reference's own transforms and dataset code produce (datasets/pair_transforms.py, mono_dataset.py:193-211)."""
+    import importlib
+    import random
+    import numpy as np
+    import torch
+    from ref_import import load_reference
+    from planedepth_amd import synthetic
+    load_reference()
+    pt = importlib.import_module("datasets.pair_transforms")
+    H, W = 24, 80
+    # Resize: the plain grid
+    out = pt.Resize((H, W))({("color", "r", -1): torch.rand(3, 37, 123), ("color", "l", -1): torch.rand(3, 37, 123)})
+    assert torch.equal(out["grid"], synthetic.crop_grid(H, W, H, W, 0, 0))
+    # RandomResizeCrop: replay its random draws to learn (factor, h0, w0), then rebuild the grid
+    FH, FW = 60, 200
+    np.random.seed(5); random.seed(5)
+    src = {("color", "r", -1): torch.rand(3, FH, FW), ("color", "l", -1): torch.rand(3, FH, FW)}
+    out = pt.RandomResizeCrop((H, W), factor=(0.75, 1.5))(dict(src))
+    np.random.seed(5); random.seed(5)
+    fmin = max(max((H + 1) / FH, (W + 1) / FW), 0.75)
+    factor = np.random.uniform(low=fmin, high=1.5)
+    h0 = random.randint(0, int(FH * factor - H)); w0 = random.randint(0, int(FW * factor - W))
+    assert torch.equal(out["grid"], synthetic.crop_grid(H, W, int(FH * factor), int(FW * factor), h0, w0))
+    # K, inv_K, Rt as the dataset builds them
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    K[0, :] *= W; K[1, :] *= H
+    batch = synthetic.kitti_like_inputs(2, H, W, seed=1)
+    assert np.array_equal(batch["K"][0].numpy(), K) and np.array_equal(batch["inv_K"][1].numpy(), np.linalg.pinv(K))
+    assert float(batch[("Rt", "l")][0, 0, 3]) == np.float32(0.1) and float(batch[("Rt", "r")][1, 0, 3]) == np.float32(-0.1)
+    assert tuple(batch["grid"].shape) == (2, 2, H, W) and float(batch["grid"].abs().max()) <= 1.0
