@@ -93,11 +93,12 @@ def build_step(args, c, device):
         if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182)
             disp_layered = disp_layered * c["row_gain"]
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
-                   "disp_layered": disp_layered, "padding_mask": pm_arg,
-                   "distance": 0.1 * 0.58 * W / disp_pp[:, :, 0, 0], "norm": norm, ("Rt", "r"): Rt}
+                   "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm, ("Rt", "r"): Rt}
+        if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
+            outputs["distance"] = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
-        ph = outputs[("ph_map", "r")].mean()
+        ph = outputs[("ph_mean", "r")]  # = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
         rgb_rec = outputs[("rgb_rec", "r")]
         torch.autograd.backward([ph, rgb_rec], [None, g_rgb])
         return ph
@@ -133,19 +134,20 @@ def kernel_times(args, c, device, iters):
     stash = torch.empty(B, k, H, W, device=device)
     gl, gs, gp = torch.empty_like(c["logits"]), torch.empty_like(c["sigma"]), torch.empty_like(plane)
     ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=device)
-    gph = torch.full((B, 1, H, W), 1.0 / (B * H * W), device=device)
+    phm = torch.empty(1, device=device)     # fused mean of ph_map and its upstream gradient (d loss / d mean = 1)
+    gphm = torch.ones(1, device=device)
     st = C.stream_handle(device)
     sig = c["sigma"] if mix else None
 
     def fwd():
         C.check(lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
                                        C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(ph),
-                                       C.ptr(stash), st), "fwd")
+                                       C.ptr(phm), C.ptr(stash), st), "fwd")
 
     def bwd():
         C.check(lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
                                        C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(stash),
-                                       C.ptr(c["g_rgb_rec"]), C.ptr(gph), C.ptr(gl), C.ptr(gs if mix else None),
+                                       C.ptr(c["g_rgb_rec"]), None, C.ptr(gphm), C.ptr(gl), C.ptr(gs if mix else None),
                                        C.ptr(None if args.no_plane_grad else gp), None, C.ptr(ws), st), "bwd")
 
     out = {}

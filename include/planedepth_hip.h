@@ -100,18 +100,21 @@ size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d);
  * outputs
  *   rgb_rec       [B,3,H,W]  outputs[("rgb_rec", side)]
  *   ph_map        [B,1,H,W]  per-pixel photometric loss BEFORE the mean / mask_novel product of trainer.py:735-742
+ *   ph_mean       [1] or NULL: mean(ph_map), i.e. the `.mean()` of trainer.py:742 fused into the sweep (block sums and
+ *                 one fp32 atomic per wave: the last bits depend on the order; use ph_map where that matters)
  *   stash         [B, pd_sweep_stash_floats/(H*W), H, W] opaque, consumed by pd_plane_sweep_bwd
  */
 int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                        const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
-                       const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map, float* stash,
-                       pd_stream_t stream);
+                       const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map, float* ph_mean,
+                       float* stash, pd_stream_t stream);
 
 /*
  * Backward of the above: what autograd computes through trainer.py:567-603 + 728-742 in the reference
  * (grid_sampler_2d_backward, softmax/clamp/div/sum/log/abs backward ...).
  *   g_rgb_rec [B,3,H,W] upstream gradient of rgb_rec (perceptual loss etc.), may be NULL (= zeros)
  *   g_ph_map  [B,1,H,W] upstream gradient of ph_map, may be NULL (= zeros)
+ *   g_ph_mean [1] device scalar: upstream gradient of ph_mean, may be NULL (= zero); both gradients add up
  * outputs (each may be NULL to skip it)
  *   g_logits, g_sigma  [B,N,H,W]  — fully overwritten
  *   g_plane            same shape as `plane` (disp: [B,N] or dense [B,N,H,W]; homography: [B*N,3,3]) — overwritten
@@ -121,8 +124,8 @@ int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tg
 int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                        const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                        const float* padding_mask, const float* dists, const float* rgb_rec, const float* stash,
-                       const float* g_rgb_rec, const float* g_ph_map, float* g_logits, float* g_sigma, float* g_plane,
-                       float* g_dists, float* workspace, pd_stream_t stream);
+                       const float* g_rgb_rec, const float* g_ph_map, const float* g_ph_mean, float* g_logits,
+                       float* g_sigma, float* g_plane, float* g_dists, float* workspace, pd_stream_t stream);
 
 /*
  * The per-plane tensors the reference stores in `outputs` and the fused path never needs (trainer.py:582-602):

@@ -39,8 +39,8 @@ SIGNATURES = {
     "pd_sweep_uses_rowshift": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
     "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),
-    "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 13),
-    "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 19),
+    "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 14),
+    "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 20),
     "pd_plane_sweep_layers": (_I, [_D] + [_P] * 14),
     "pd_ssim_fwd": (_I, [_I] * 4 + [_P] * 4),
     "pd_ssim_bwd": (_I, [_I] * 4 + [_P] * 6),

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
   const int HW = a.H * a.W;
   const int pix = blockIdx.x * kBlock + threadIdx.x;
   const int b = blockIdx.y;
-  if (pix >= HW) return;
+  float ph_val = 0.0f;  // this pixel's ph (0 for lanes past the image), summed per wave for the fused mean
+  if (pix < HW) {
   const int y = pix / a.W, x = pix - y * a.W;
   const bool automask = a.flags & PD_AUTOMASK;
   const bool has_mask = (MODE == PD_WARP_DISP) && a.has_mask;
@@ -136,6 +137,19 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
   rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
   rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
   ph_map[(long)b * HW + pix] = r.ph;
+  ph_val = r.ph;
+  }
+  if (a.ph_mean) {  // fused `.mean()` of trainer.py:742 (all threads get here): one atomic per workgroup
+    __shared__ float wsum[kBlock / kWave];
+    const float v = wave_sum(ph_val);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+      for (int w = 0; w < kBlock / kWave; ++w) t += wsum[w];
+      unsafeAtomicAdd(a.ph_mean, t * a.inv_numel);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -420,6 +434,8 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.padding_mask = mask_rows ? nullptr : padding_mask;
   a.mask_rows = mask_rows ? padding_mask : nullptr;
   a.dists = dists;
+  a.ph_mean = nullptr;
+  a.inv_numel = 1.0f / ((float)d->B * (float)d->H * (float)d->W);
   return a;
 }
 
@@ -457,13 +473,17 @@ extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
 extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                                   const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                                   const float* padding_mask, const float* dists, float* rgb_rec, float* ph_map,
-                                  float* stash, pd_stream_t stream) {
+                                  float* ph_mean, float* stash, pd_stream_t stream) {
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && ph_map && stash, "tgt/rgb_rec/ph_map/stash must not be NULL");
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   // the stash always reserves the mask words in disp mode (pd_sweep_stash_floats); they are written when a mask exists
   SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
+  if (ph_mean) {  // the kernels add into it: start from zero (an async memset on the same stream)
+    a.ph_mean = ph_mean;
+    if (hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
+  }
   if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d))
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
@@ -475,9 +495,9 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
 extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                                   const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                                   const float* padding_mask, const float* dists, const float* rgb_rec,
-                                  const float* stash, const float* g_rgb_rec, const float* g_ph_map, float* g_logits,
-                                  float* g_sigma, float* g_plane, float* g_dists, float* workspace,
-                                  pd_stream_t stream_) {
+                                  const float* stash, const float* g_rgb_rec, const float* g_ph_map,
+                                  const float* g_ph_mean, float* g_logits, float* g_sigma, float* g_plane,
+                                  float* g_dists, float* workspace, pd_stream_t stream_) {
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && stash, "tgt/rgb_rec/stash must not be NULL");
@@ -490,7 +510,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
   o.g_dists = (d->flags & PD_RENDER_PROB) ? g_dists : nullptr;
-  o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map;
+  o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
   if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) return rowshift_bwd(d, ak, o, stream);
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;

@@ -475,7 +475,7 @@ __device__ __forceinline__ FwdAcc fetch_acc(const float* __restrict__ slot, int 
 }
 
 template <bool MIX>
-__device__ __forceinline__ void fwd_store(const SweepArgs& a, const FwdAcc& acc, int b, int pix, int HW, float t0,
+__device__ __forceinline__ float fwd_store(const SweepArgs& a, const FwdAcc& acc, int b, int pix, int HW, float t0,
                                           float t1, float t2, float ea, bool automask, float* __restrict__ rgb_rec,
                                           float* __restrict__ ph_map, float* __restrict__ stash) {
   const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
@@ -488,10 +488,11 @@ __device__ __forceinline__ void fwd_store(const SweepArgs& a, const FwdAcc& acc,
   rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
   rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
   ph_map[(long)b * HW + pix] = r.ph;
+  return r.ph;
 }
 
 template <bool MIX, bool HASMASK, bool AUTO, int NROWS>
-__device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
+__device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
                                                   float* parts, float* __restrict__ rgb_rec,
                                                   float* __restrict__ ph_map, float* __restrict__ stash) {
   constexpr int U = (NROWS == 1) ? PD_FWD_U : (PD_FWD_U > 1 ? PD_FWD_U / 2 : 1);
@@ -510,6 +511,7 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nseg = (a.W + kWave - 1) / kWave;
   const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  float ph_sum = 0.0f;  // this lane's share of sum(ph_map) (returned: the kernel adds the wave totals to a.ph_mean)
   auto target_pixel = [&](int pix, float& t0, float& t1, float& t2, float& ea) {
     t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
     t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
@@ -569,11 +571,11 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
       group_issue<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
       fwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
     }
-    if (piece < 0) fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
+    if (piece < 0) ph_sum += fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
     else park_acc(parts + ((wave * 2 + piece) * 8) * kWave, lane, acc);
     }
   }
-  if (rw.r == 0) return;  // workgroup-uniform
+  if (rw.r == 0) return ph_sum;  // workgroup-uniform
   __syncthreads();
   if (wave < rw.r) {  // wave j merges the pieces of left-over segment j (in plane order) and finishes its pixels
     const int j = wave, x = (rw.full * nwaves + j) * kWave + lane;
@@ -589,9 +591,10 @@ __device__ __forceinline__ void rowshift_fwd_body(const SweepArgs& a, const RowS
       const int pix = y * a.W + x;
       float t0, t1, t2, ea;
       target_pixel(pix, t0, t1, t2, ea);
-      fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
+      ph_sum += fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
     }
   }
+  return ph_sum;
 }
 
 template <bool MIX, bool HASMASK, bool AUTO>
@@ -603,8 +606,21 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_FWD_OCC) void rowshift_fwd_kerne
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   float* parts = sdisp + a.N;
   const RowSel row = two_row_form(make_row_sel(block_row(blockIdx.x, a.H), a.H), a.fast_rows != 0);
-  if (row.nrows == 2) rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
-  else                rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  float ph_sum;
+  if (row.nrows == 2) ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  else                ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup (one per wave
+    // measured +13 us on the forward: 6144 atomics on a single address serialise in L2)
+    const float v = wave_sum_hi(ph_sum);
+    __syncthreads();  // everybody is done with `parts`
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) parts[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += parts[w];
+      unsafeAtomicAdd(a.ph_mean, t * a.inv_numel);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ struct SweepArgs {
   int fast_rows;           // PD_IMPL_FAST_ROWS: the row-shift kernels drop eps-weighted second source rows
   const float* mask_rows;  // PD_MASK_ROWS: [B,N,H] (row-shift kernels only; padding_mask is NULL then)
   const float* dists;  // PD_RENDER_PROB: [B,N-1,H,W] inter-plane distances at the TARGET pixel (trainer.py:587)
+  float* ph_mean;      // forward, optional: one float that receives mean(ph_map) (block sums, one atomic per wave)
+  float inv_numel;     // 1 / (B*H*W)
 };
 
 struct BwdOut {
@@ -45,6 +47,7 @@ struct BwdOut {
   const float* stash;
   const float* g_rgb_rec;
   const float* g_ph_map;
+  const float* g_ph_mean;  // optional: device scalar, upstream gradient of mean(ph_map)
 };
 
 // ---- forward: online softmax / mixture accumulators of ONE target pixel over the planes ---------------------------
@@ -169,7 +172,11 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const SweepArgs& a, const Bwd
   const float Sn = st[HW];
   c.mx = st[2 * HW];
   const float sel = st[3 * HW];
-  const float gp = (o.g_ph_map && sel == 0.0f) ? o.g_ph_map[(long)b * HW + pix] : 0.0f;
+  float gp = 0.0f;  // d loss / d ph_map at this pixel: per-pixel upstream gradient + the fused mean's share
+  if (sel == 0.0f) {
+    if (o.g_ph_map) gp = o.g_ph_map[(long)b * HW + pix];
+    if (o.g_ph_mean) gp += o.g_ph_mean[0] * a.inv_numel;
+  }
   const float r0 = o.rgb_rec[((long)b * 3 + 0) * HW + pix];
   const float r1 = o.rgb_rec[((long)b * 3 + 1) * HW + pix];
   const float r2 = o.rgb_rec[((long)b * 3 + 2) * HW + pix];

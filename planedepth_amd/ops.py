@@ -30,7 +30,10 @@ def _contig(t):
 # Fused plane sweep + photometric loss
 # ---------------------------------------------------------------------------------------------------------------------
 class _PlaneSweep(torch.autograd.Function):
-    """(src, tgt, logits, sigma, plane, ...) -> (rgb_rec [B,3,H,W], ph_map [B,1,H,W]).
+    """(src, tgt, logits, sigma, plane, ...) -> (rgb_rec [B,3,H,W], ph_map [B,1,H,W], ph_mean []).
+
+    ``ph_mean`` is ``ph_map.mean()`` accumulated inside the sweep kernel (the `.mean()` of trainer.py:742 without a
+    reduction kernel of its own); its upstream gradient is a device scalar that the backward kernel applies per pixel.
 
     Gradients: logits, sigma, plane (disp_layered or H_t2s).  src / tgt are images (no gradient, as in the reference
     where they are dataset tensors).
@@ -66,21 +69,23 @@ class _PlaneSweep(torch.autograd.Function):
         k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
         rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
         ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
+        ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
         stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
         with torch.cuda.device(logits.device):
             rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                         C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
-                                        C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(stash), C.stream_handle(logits.device))
+                                        C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(ph_mean), C.ptr(stash),
+                                        C.stream_handle(logits.device))
         C.check(rc, "pd_plane_sweep_fwd")
         if DEBUG_STASH is not None:
             DEBUG_STASH.append(stash)
         ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
         ctx.cfg = (mode, flags, sign)
-        ctx.mark_non_differentiable(stash)
-        return rgb_rec, ph_map
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward, not as zero tensors
+        return rgb_rec, ph_map, ph_mean.reshape(())
 
     @staticmethod
-    def backward(ctx, g_rgb_rec, g_ph_map):
+    def backward(ctx, g_rgb_rec, g_ph_map, g_ph_mean):
         lib = C.load()
         src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = ctx.saved_tensors
         mode, flags, sign = ctx.cfg
@@ -97,10 +102,12 @@ class _PlaneSweep(torch.autograd.Function):
             ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=logits.device,
                              dtype=torch.float32)
         g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
+        if g_ph_mean is not None:
+            g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
         with torch.cuda.device(logits.device):
             rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                         C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
-                                        C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map),
+                                        C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
                                         C.ptr(g_logits), C.ptr(g_sigma), C.ptr(g_plane), C.ptr(g_dists), C.ptr(ws),
                                         C.stream_handle(logits.device))
         C.check(rc, "pd_plane_sweep_bwd")
@@ -133,7 +140,8 @@ def _per_plane_view(disp_layered):
 
 
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
-                     use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False):
+                     use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False,
+                     return_mean=False):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
 
     ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
@@ -168,8 +176,9 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
             padding_mask = padding_mask[..., 0]
             flags |= C.PD_MASK_ROWS
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
-    return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
-                             dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
+    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
+                            dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
+    return out if return_mean else out[:2]  # (rgb_rec, ph_map[, ph_map.mean() fused into the kernel])
 
 
 def homography_matrices(d, n, T, K, inv_K):
@@ -190,7 +199,7 @@ def homography_matrices(d, n, T, K, inv_K):
 
 
 def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
-                           automask=False, render_probability=False, dists=None):
+                           automask=False, render_probability=False, dists=None, return_mean=False):
     """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
 
     distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
@@ -199,9 +208,10 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
     H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
     inv_K3 = inv_K[:, :3, :3]
-    return _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach(),
-                             inv_K3.detach(), None, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
-                             _flags(use_mixture_loss, automask, render=render_probability), 0.0)
+    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach(),
+                            inv_K3.detach(), None, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
+                            _flags(use_mixture_loss, automask, render=render_probability), 0.0)
+    return out if return_mean else out[:2]
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",

@@ -72,19 +72,21 @@ def pred_novel_images(self, inputs, outputs):
         tgt = inputs[(cname, target_side)]
         sigma = outputs["sigma"] if mix else None
         if opt.warp_type == "disp_warp":
-            rgb_rec, ph_map = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
-                                                   padding_mask, target_side=target_side,
-                                                   use_mixture_loss=mix, automask=automask,
-                                                   render_probability=render, dists=dists, row_uniform=row_uniform)
+            rgb_rec, ph_map, ph_mean = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
+                                                            padding_mask, target_side=target_side,
+                                                            use_mixture_loss=mix, automask=automask,
+                                                            render_probability=render, dists=dists,
+                                                            row_uniform=row_uniform, return_mean=True)
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
                                  padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix,
                                  render_probability=render, dists=dists)
         elif opt.warp_type == "homography_warp":
             T = outputs[("Rt", target_side)]
-            rgb_rec, ph_map = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma, outputs["distance"],
-                                                         outputs["norm"], T, inputs["K"], inputs["inv_K"],
-                                                         use_mixture_loss=mix, automask=automask,
-                                                         render_probability=render, dists=dists)
+            rgb_rec, ph_map, ph_mean = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma,
+                                                                  outputs["distance"], outputs["norm"], T, inputs["K"],
+                                                                  inputs["inv_K"], use_mixture_loss=mix,
+                                                                  automask=automask, render_probability=render,
+                                                                  dists=dists, return_mean=True)
             with torch.no_grad():
                 ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
                 H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
@@ -98,6 +100,7 @@ def pred_novel_images(self, inputs, outputs):
                                       "homography_warp" % (opt.warp_type,))
         outputs[("rgb_rec", target_side)] = rgb_rec
         outputs[("ph_map", target_side)] = ph_map
+        outputs[("ph_mean", target_side)] = ph_mean  # ph_map.mean(), accumulated by the sweep kernel itself
         outputs[("sweep", target_side)] = handle
         if getattr(opt, "materialize_layers", False):
             for k, v in handle.layers().items():
@@ -125,18 +128,18 @@ def compute_losses(self, inputs, outputs):
         mask = outputs["mask_novel"] if "mask_novel" in outputs else None
         if mask is not None:
             pred = pred * mask + target * (1.0 - mask)
-        if opt.use_mixture_loss:
-            ph_loss = outputs[("ph_map", target_side)]  # mixture NLL (+ automask min), fused with the warp
-            if mask is not None:
-                ph_loss = ph_loss * mask
-        elif mask is None:
-            ph_loss = outputs[("ph_map", target_side)]  # mean_c |rgb_rec - target| (+ automask min), fused
+        if mask is None:
+            # mixture NLL or mean_c |rgb_rec - target| (+ automask min) AND its `.mean()` (trainer.py:742) come out
+            # of the sweep kernel; the backward takes the scalar's gradient directly
+            ph_loss = outputs[("ph_mean", target_side)]
+        elif opt.use_mixture_loss:
+            ph_loss = (outputs[("ph_map", target_side)] * mask).mean()
         else:  # L1 on the blended prediction: [B,3,H,W] elementwise work, left to torch
             ph_loss = torch.abs(pred - target).mean(1, True)
             if opt.automask:
                 ph_auto = torch.abs(inputs[(cname, "l")] - target).mean(1, True)
                 ph_loss, _ = torch.cat([ph_loss, ph_auto], dim=1).min(1, True)
-        ph_loss = ph_loss.mean()
+            ph_loss = ph_loss.mean()
         losses["loss/ph_loss"] += ph_loss
         total_loss += ph_loss
 

@@ -43,7 +43,7 @@ def test_desc_layout_and_host_queries():
 def test_argument_validation_needs_no_gpu():
     lib = C.load()
     d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_DISP, C.PD_MIXTURE, 1.0, 0)
-    null = [None] * 13
+    null = [None] * 14
     assert lib.pd_plane_sweep_fwd(ctypes.byref(d), *null) == 1  # PD_ERR_ARG: NULL tensors
     assert b"NULL" in lib.pd_last_error()
     d.mode = 7

@@ -110,7 +110,7 @@ def test_homography_kernel_with_pinned_matrices(mix, automask):
     lgd, sgd, Hd = (case["logits"].to(dev).requires_grad_(True), case["sigma"].to(dev).requires_grad_(True),
                     Hm.to(dev).requires_grad_(True))
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if automask else 0)
-    rgb, ph = ops._PlaneSweep.apply(case["color_l"].to(dev), case["color_r"].to(dev), lgd, sgd if mix else None, Hd,
+    rgb, ph, _ = ops._PlaneSweep.apply(case["color_l"].to(dev), case["color_r"].to(dev), lgd, sgd if mix else None, Hd,
                                     Rn64.float().reshape(B * N, 3).to(dev), case["inv_K"][:, :3, :3].to(dev), None, None, C.PD_WARP_HOMOGRAPHY,
                                     flags, 0.0)
     (ph.mean() + (rgb * case["g_rgb_rec"].to(dev)).sum()).backward()
@@ -582,3 +582,30 @@ def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extr
     want = run_oracle(case, run)
     _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_disp_pp"), tag=label)
     _compare(got, want, keys=("g_sigma",), tag=label, tol=2e-4)
+
+
+@pytest.mark.parametrize("impl", ["rows", "general"])
+def test_fused_mean_of_ph_map(impl):
+    """The `.mean()` of trainer.py:742 accumulated inside the sweep kernel (ph_mean) equals ph_map.mean(), and a loss
+    built on it back-propagates the same gradients as one built on ph_map.mean()."""
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    case = build_case(B=2, N=7, H=18, W=150, seed=77, disp_min=0.5, disp_max=30.0, sigma_interior=True)
+    c = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.items()}
+    B, N, H, W = c["logits"].shape
+    ops.SWEEP_IMPL = C.PD_IMPL_GENERAL if impl == "general" else C.PD_IMPL_AUTO
+    try:
+        grads = []
+        for fused in (True, False):
+            lg, sg, dp = (c[k].clone().requires_grad_(True) for k in ("logits", "sigma", "disp_pp"))
+            rgb, ph_map, ph_mean = ops.plane_sweep_disp(c["color_l"], c["color_r"], lg, sg, dp.expand(B, N, H, W), None,
+                                                        automask=True, return_mean=True)
+            assert abs(float(ph_mean) - float(ph_map.mean())) < 2e-6 * abs(float(ph_map.mean()))
+            loss = (ph_mean if fused else ph_map.mean()) * 1.7 + (rgb * c["g_rgb_rec"]).sum()
+            loss.backward()
+            grads.append((lg.grad, sg.grad, dp.grad))
+        for a, b in zip(*grads):
+            assert rel_err(a.cpu(), b.cpu()) < 2e-6
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
