@@ -81,6 +81,7 @@ def build_step(args, c, device):
     norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
     shape_probe = torch.empty(B, N, H, W, device="meta")
     g_rgb = c["g_rgb_rec"]
+    one = torch.ones((), device=device)  # d loss / d ph_loss
     pm = None if args.no_padding_mask else c["padding_mask"]
     if pm is None:
         pm_arg = None
@@ -100,7 +101,7 @@ def build_step(args, c, device):
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
         ph = outputs[("ph_mean", "r")]  # = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
         rgb_rec = outputs[("rgb_rec", "r")]
-        torch.autograd.backward([ph, rgb_rec], [None, g_rgb])
+        torch.autograd.backward([ph, rgb_rec], [one, g_rgb])
         return ph
 
     return step, (logits, sigma, disp_pp)
