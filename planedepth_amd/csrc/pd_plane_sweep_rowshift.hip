@@ -46,7 +46,7 @@ constexpr int kMaxRowThreads = 1024;
 #define PD_FWD_PF 1
 #endif
 #ifndef PD_FWD_OCC
-#define PD_FWD_OCC 3
+#define PD_FWD_OCC 4  // the mask-free forward fits 128 VGPRs without spilling; with a per-pixel mask it needs 3 (below)
 #endif
 #ifndef PD_BWD_U
 #define PD_BWD_U 2
@@ -598,7 +598,7 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
 }
 
 template <bool MIX, bool HASMASK, bool AUTO>
-__global__ __launch_bounds__(kRowThreadsMax, PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+__global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
                                                                      float* __restrict__ stash) {
   extern __shared__ float4 lds4[];
