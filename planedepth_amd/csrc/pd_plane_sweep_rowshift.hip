@@ -57,6 +57,10 @@ constexpr int kMaxRowThreads = 1024;
 #ifndef PD_BWD_PF
 #define PD_BWD_PF 1
 #endif
+#ifndef PD_TC_PREFETCH
+#define PD_TC_PREFETCH 1  // colour taps (LDS) ride along with the prefetched plane group; 0: read when the group is reduced
+#endif
+#define PD_TC_IN_GROUP (PD_PF_DEPTH == 2 && PD_TC_PREFETCH)
 #ifndef PD_BWD_OCC
 #define PD_BWD_OCC 3
 #endif
@@ -316,7 +320,7 @@ template <int NROWS, int U>
 struct PlaneGroup {
   ColTap ct[U];
   Taps<NROWS> tl[U], ts[U];
-#if PD_PF_DEPTH == 2
+#if PD_TC_IN_GROUP
   ColourTaps<NROWS> tc[U];  // LDS colour taps ride along with the global loads (their latency overlaps too)
 #endif
   float mval[U];
@@ -337,7 +341,7 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
     } else {
       g.ct[u] = make_col_tap((float)x + sdisp[n], Wm1, rcpWm1);
     }
-#if PD_PF_DEPTH == 2
+#if PD_TC_IN_GROUP
     if (!(kAblate & 2)) g.tc[u] = load_colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W));
 #endif
     g.mval[u] = 1.0f;
@@ -362,7 +366,7 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
                                             const char* __restrict__ lrgb, int b, int n0, int pix, int HW, float t0,
                                             float t1, float t2, float ea, bool automask, FwdAcc& acc, uint32_t& bits,
                                             float* __restrict__ stash) {
-#if PD_PF_DEPTH == 2
+#if PD_TC_IN_GROUP
   const ColourTaps<NROWS>* tc = g.tc;
 #else
   ColourTaps<NROWS> tc[U];  // all LDS reads of the group first, then the arithmetic
@@ -677,7 +681,7 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
                                             const PixelCtx& c, int HW, float gix_scale, bool want_plane,
                                             uint32_t& bits) {
   const int W = a.W, N = a.N;
-#if PD_PF_DEPTH == 2
+#if PD_TC_IN_GROUP
   const ColourTaps<NROWS>* tc = g.tc;
 #else
   ColourTaps<NROWS> tc[U];  // all LDS reads of the group first, then the arithmetic
