@@ -24,14 +24,16 @@ __device__ __forceinline__ float edge_weight(const SmoothArgs& a, const float* _
   return __expf(-a.gamma * (s / (float)a.C));
 }
 
+constexpr int kSmoothRows = 8;  // image rows per block of the forward: few blocks, few atomics on the single output
+
 __global__ __launch_bounds__(kBlock) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ out) {
   __shared__ float red[kBlock / kWave];
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y, y0 = blockIdx.x * kSmoothRows, y1 = min(y0 + kSmoothRows, a.H);
+  const float* db = a.disp + b * a.d_sb;
+  const float* ib = a.img + b * a.i_sb;
   float v = 0.0f;
-  if (pix < a.H * a.W) {
-    const int y = pix / a.W, x = pix - y * a.W;
-    const float* db = a.disp + b * a.d_sb;
-    const float* ib = a.img + b * a.i_sb;
+  for (int i = threadIdx.x; i < (y1 - y0) * a.W; i += kBlock) {
+    const int y = y0 + i / a.W, x = i % a.W;
     const float d = db[y * a.d_sh + x];
     const long ip = y * a.i_sh + x;
     if (x + 1 < a.W) v += fabsf(d - db[y * a.d_sh + x + 1]) * edge_weight(a, ib, ip, ip + 1) * a.inv_nx;
@@ -91,7 +93,7 @@ extern "C" int pd_smooth_loss_fwd(int B, int C, int H, int W, const float* disp,
                            img_stride_h, gamma)) return rc;
   PD_REQUIRE(out, "NULL output");
   if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
-  smooth_fwd_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(a, out);
+  smooth_fwd_kernel<<<dim3(ceil_div(H, kSmoothRows), B), kBlock, 0, (hipStream_t)stream>>>(a, out);
   return check_launch("smooth_fwd_kernel");
 }
 
