@@ -10,6 +10,9 @@
 // from the per-pixel stash {log-sum-exp, sum(pi*mask/sigma)}.
 // Algorithmic bytes per pixel: forward reads 2N (+N mask) floats, writes N (sigma) (+N logits when there is a mask)
 // + 4; backward reads 4N (+N) and writes 2N.  HBM-bound streaming, no reuse.
+#include <initializer_list>
+#include <stdint.h>
+
 #include "pd_common.h"
 
 namespace pd {
@@ -28,61 +31,117 @@ struct TailArgs {
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float clamp_sigma(float s) { return fminf(fmaxf(s, kTailSigmaMin), kTailSigmaMax); }
 
-template <bool MIX, bool HASMASK>
+// PX pixels per thread: 4 (one 16-byte access per tensor and plane) when H*W is a multiple of 4 and every pointer is
+// 16-byte aligned, else 1.  The arithmetic is per pixel either way.
+template <int PX>
+struct Px {
+  float v[PX];
+};
+template <int PX>
+__device__ __forceinline__ Px<PX> ldv(const float* __restrict__ p) {
+  Px<PX> r;
+  if (PX == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1 % PX] = t.y; r.v[2 % PX] = t.z; r.v[3 % PX] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int PX>
+__device__ __forceinline__ void stv(float* __restrict__ p, const Px<PX>& r) {
+  if (PX == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % PX], r.v[2 % PX], r.v[3 % PX]);
+  else p[0] = r.v[0];
+}
+template <int PX>
+__device__ __forceinline__ Px<PX> splat(float x) {
+  Px<PX> r;
+#pragma unroll
+  for (int j = 0; j < PX; ++j) r.v[j] = x;
+  return r;
+}
+
+template <bool MIX, bool HASMASK, int PX>
 __global__ __launch_bounds__(kBlock) void tail_fwd_kernel(TailArgs a, float* __restrict__ logits, float* __restrict__ sigma,
                                                           float* __restrict__ disp, float* __restrict__ depth,
                                                           float* __restrict__ stash) {
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  const int pix = (blockIdx.x * kBlock + threadIdx.x) * PX, b = blockIdx.y;
   if (pix >= a.HW) return;
   const long base = (long)b * a.N * a.HW + pix;
-  float m = -INFINITY, Z = 0.0f, Sw = 0.0f, Sd = 0.0f;  // running reference, sum e^(l-m), sum of weights, sum w*d
-#pragma unroll 4
+  float m[PX], Z[PX], Sw[PX], Sd[PX];  // running reference, sum e^(l-m), sum of weights, sum w*d
+#pragma unroll
+  for (int j = 0; j < PX; ++j) { m[j] = -INFINITY; Z[j] = Sw[j] = Sd[j] = 0.0f; }
+#pragma unroll 2
   for (int n = 0; n < a.N; ++n) {
     const long i = base + (long)n * a.HW;
-    const float mk = HASMASK ? a.mask[i] : 1.0f;
-    const float l = a.raw_logits[i] * mk;                        // depth_decoder.py:259
-    if (HASMASK) logits[i] = l;
-    float inv = 1.0f;
-    if (MIX) {
-      const float sg = clamp_sigma(sigmoid_f(a.raw_sigma[i]));   // :278-279
-      sigma[i] = sg;
-      inv = mk / sg;                                             // :282-283 (mask applied to the weights)
+    const Px<PX> mk = HASMASK ? ldv<PX>(a.mask + i) : splat<PX>(1.0f);
+    const Px<PX> rl = ldv<PX>(a.raw_logits + i);
+    const Px<PX> rs = MIX ? ldv<PX>(a.raw_sigma + i) : splat<PX>(0.0f);
+    const Px<PX> dv = a.dense ? ldv<PX>(a.dl + i) : splat<PX>(a.dl[b * a.N + n]);
+    Px<PX> lo, so;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      const float l = rl.v[j] * mk.v[j];                           // depth_decoder.py:259
+      lo.v[j] = l;
+      float inv = 1.0f;
+      if (MIX) {
+        const float sg = clamp_sigma(sigmoid_f(rs.v[j]));          // :278-279
+        so.v[j] = sg;
+        inv = mk.v[j] / sg;                                        // :282-283 (mask applied to the weights)
+      }
+      if (l > m[j]) {  // move the reference to the new maximum
+        const float sc = __expf(m[j] - l);
+        Z[j] *= sc; Sw[j] *= sc; Sd[j] *= sc;
+        m[j] = l;
+      }
+      const float e = __expf(l - m[j]);
+      const float w = e * inv;
+      Z[j] += e;
+      Sw[j] += w;
+      Sd[j] += w * dv.v[j];
     }
-    const float d = a.dense ? a.dl[i] : a.dl[b * a.N + n];
-    if (l > m) {  // move the reference to the new maximum
-      const float sc = __expf(m - l);
-      Z *= sc; Sw *= sc; Sd *= sc;
-      m = l;
-    }
-    const float e = __expf(l - m);
-    const float w = e * inv;
-    Z += e;
-    Sw += w;
-    Sd += w * d;
+    if (HASMASK) stv<PX>(logits + i, lo);
+    if (MIX) stv<PX>(sigma + i, so);
   }
-  const float dsp = Sd / Sw;                                      // :284-285, 289 (the softmax normaliser cancels)
-  disp[(long)b * a.HW + pix] = dsp;
-  depth[(long)b * a.HW + pix] = 0.1f * 0.58f * (float)a.W / dsp;  // :291
-  stash[((long)b * 2 + 0) * a.HW + pix] = m + __logf(Z);          // log-sum-exp of the masked logits
-  stash[((long)b * 2 + 1) * a.HW + pix] = Sw / Z;                 // sum_N pi * mask / sigma
+  Px<PX> o_disp, o_depth, o_lse, o_sn;
+#pragma unroll
+  for (int j = 0; j < PX; ++j) {
+    const float dsp = Sd[j] / Sw[j];                                // :284-285, 289 (the softmax normaliser cancels)
+    o_disp.v[j] = dsp;
+    o_depth.v[j] = 0.1f * 0.58f * (float)a.W / dsp;                 // :291
+    o_lse.v[j] = m[j] + __logf(Z[j]);                               // log-sum-exp of the masked logits
+    o_sn.v[j] = Sw[j] / Z[j];                                       // sum_N pi * mask / sigma
+  }
+  stv<PX>(disp + (long)b * a.HW + pix, o_disp);
+  stv<PX>(depth + (long)b * a.HW + pix, o_depth);
+  stv<PX>(stash + ((long)b * 2 + 0) * a.HW + pix, o_lse);
+  stv<PX>(stash + ((long)b * 2 + 1) * a.HW + pix, o_sn);
 }
 
 // pi and probability (depth_decoder.py:275, 281-285) for callers that want the tensors.
-template <bool MIX, bool HASMASK>
+template <bool MIX, bool HASMASK, int PX>
 __global__ __launch_bounds__(kBlock) void tail_layers_kernel(TailArgs a, const float* __restrict__ stash,
                                                              float* __restrict__ pi, float* __restrict__ prob) {
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  const int pix = (blockIdx.x * kBlock + threadIdx.x) * PX, b = blockIdx.y;
   if (pix >= a.HW) return;
   const long base = (long)b * a.N * a.HW + pix;
-  const float lse = stash[((long)b * 2 + 0) * a.HW + pix];
-  const float invS = 1.0f / stash[((long)b * 2 + 1) * a.HW + pix];
-#pragma unroll 4
+  const Px<PX> lse = ldv<PX>(stash + ((long)b * 2 + 0) * a.HW + pix);
+  const Px<PX> sn = ldv<PX>(stash + ((long)b * 2 + 1) * a.HW + pix);
+#pragma unroll 2
   for (int n = 0; n < a.N; ++n) {
     const long i = base + (long)n * a.HW;
-    const float mk = HASMASK ? a.mask[i] : 1.0f;
-    const float p = __expf(a.raw_logits[i] * mk - lse);
-    if (pi) pi[i] = p;
-    if (prob) prob[i] = MIX ? p * mk / clamp_sigma(sigmoid_f(a.raw_sigma[i])) * invS : p;
+    const Px<PX> mk = HASMASK ? ldv<PX>(a.mask + i) : splat<PX>(1.0f);
+    const Px<PX> rl = ldv<PX>(a.raw_logits + i);
+    const Px<PX> rs = MIX ? ldv<PX>(a.raw_sigma + i) : splat<PX>(0.0f);
+    Px<PX> op, oq;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      const float p = __expf(rl.v[j] * mk.v[j] - lse.v[j]);
+      op.v[j] = p;
+      oq.v[j] = MIX ? p * mk.v[j] / clamp_sigma(sigmoid_f(rs.v[j])) / sn.v[j] : p;
+    }
+    if (pi) stv<PX>(pi + i, op);
+    if (prob) stv<PX>(prob + i, oq);
   }
 }
 
@@ -90,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void tail_layers_kernel(TailArgs a, const f
 // (+ the depth term): d disp / d w_n = (d_n - disp) / S, and since sum_k pi_k (d loss / d pi_k) = gD/S * sum_k w_k
 // (d_k - disp) = 0 exactly, the softmax backward needs no second reduction:
 //   g_logits_n += gD (d_n - disp) P_n;   g_sigma_n -= gD (d_n - disp) P_n / sigma_n;   g_d_n = gD P_n.
-template <bool MIX, bool HASMASK>
+template <bool MIX, bool HASMASK, int PX>
 __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(TailArgs a, const float* __restrict__ stash,
                                                           const float* __restrict__ disp,
                                                           const float* __restrict__ g_logits,
@@ -101,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(TailArgs a, const floa
                                                           float* __restrict__ g_raw_sigma, float* __restrict__ g_dl,
                                                           float* __restrict__ partials) {
   extern __shared__ float red[];  // [N] block sums of the per-plane disparity gradient
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  const int pix = (blockIdx.x * kBlock + threadIdx.x) * PX, b = blockIdx.y;
   const bool reduce = (g_dl != nullptr) && !a.dense;
   if (reduce) {
     for (int i = threadIdx.x; i < a.N; i += kBlock) red[i] = 0.0f;
@@ -109,37 +168,49 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(TailArgs a, const floa
   }
   const bool active = pix < a.HW;
   const long base = (long)b * a.N * a.HW + (active ? pix : 0);
-  float lse = 0.0f, invS = 0.0f, dsp = 1.0f, gD = 0.0f;
+  Px<PX> lse = splat<PX>(0.0f), sn = splat<PX>(1.0f), dsp = splat<PX>(1.0f), gD = splat<PX>(0.0f);
   if (active) {
-    lse = stash[((long)b * 2 + 0) * a.HW + pix];
-    invS = 1.0f / stash[((long)b * 2 + 1) * a.HW + pix];
-    dsp = disp[(long)b * a.HW + pix];
-    if (g_disp) gD = g_disp[(long)b * a.HW + pix];
-    if (g_depth) gD -= g_depth[(long)b * a.HW + pix] * (0.1f * 0.58f * (float)a.W) / (dsp * dsp);
+    lse = ldv<PX>(stash + ((long)b * 2 + 0) * a.HW + pix);
+    sn = ldv<PX>(stash + ((long)b * 2 + 1) * a.HW + pix);
+    dsp = ldv<PX>(disp + (long)b * a.HW + pix);
+    if (g_disp) gD = ldv<PX>(g_disp + (long)b * a.HW + pix);
+    if (g_depth) {
+      const Px<PX> gz = ldv<PX>(g_depth + (long)b * a.HW + pix);
+#pragma unroll
+      for (int j = 0; j < PX; ++j) gD.v[j] -= gz.v[j] * (0.1f * 0.58f * (float)a.W) / (dsp.v[j] * dsp.v[j]);
+    }
   }
   const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll 2
   for (int n = 0; n < a.N; ++n) {
     const long i = base + (long)n * a.HW;
     float gd = 0.0f;
     if (active) {
-      const float mk = HASMASK ? a.mask[i] : 1.0f;
-      const float p = __expf(a.raw_logits[i] * mk - lse);
-      float sgu = 1.0f, sg = 1.0f, P = p;
-      if (MIX) {
-        sgu = sigmoid_f(a.raw_sigma[i]);
-        sg = clamp_sigma(sgu);
-        P = p * mk / sg * invS;
+      const Px<PX> mk = HASMASK ? ldv<PX>(a.mask + i) : splat<PX>(1.0f);
+      const Px<PX> rl = ldv<PX>(a.raw_logits + i);
+      const Px<PX> rs = MIX ? ldv<PX>(a.raw_sigma + i) : splat<PX>(0.0f);
+      const Px<PX> dv = a.dense ? ldv<PX>(a.dl + i) : splat<PX>(a.dl[b * a.N + n]);
+      const Px<PX> gl = g_logits ? ldv<PX>(g_logits + i) : splat<PX>(0.0f);
+      const Px<PX> gs = (MIX && g_sigma) ? ldv<PX>(g_sigma + i) : splat<PX>(0.0f);
+      Px<PX> o_l, o_s, o_d;
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        const float p = __expf(rl.v[j] * mk.v[j] - lse.v[j]);
+        float sgu = 1.0f, sg = 1.0f, P = p;
+        if (MIX) {
+          sgu = sigmoid_f(rs.v[j]);
+          sg = clamp_sigma(sgu);
+          P = p * mk.v[j] / sg / sn.v[j];
+        }
+        const float t = gD.v[j] * (dv.v[j] - dsp.v[j]) * P;
+        o_l.v[j] = (gl.v[j] + t) * mk.v[j];
+        const float gsig = gs.v[j] - t / sg;
+        o_s.v[j] = (sgu == sg) ? gsig * sgu * (1.0f - sgu) : 0.0f;   // clamp gate (inclusive bounds), sigmoid'
+        o_d.v[j] = gD.v[j] * P;
+        gd += o_d.v[j];
       }
-      const float d = a.dense ? a.dl[i] : a.dl[b * a.N + n];
-      const float t = gD * (d - dsp) * P;
-      if (g_raw_logits) g_raw_logits[i] = ((g_logits ? g_logits[i] : 0.0f) + t) * mk;
-      if (MIX && g_raw_sigma) {
-        const float gs = (g_sigma ? g_sigma[i] : 0.0f) - t / sg;
-        g_raw_sigma[i] = (sgu == sg) ? gs * sgu * (1.0f - sgu) : 0.0f;  // clamp gate (inclusive bounds), sigmoid'
-      }
-      gd = gD * P;
-      if (g_dl && a.dense) g_dl[i] = gd;
+      if (g_raw_logits) stv<PX>(g_raw_logits + i, o_l);
+      if (MIX && g_raw_sigma) stv<PX>(g_raw_sigma + i, o_s);
+      if (g_dl && a.dense) stv<PX>(g_dl + i, o_d);
     }
     if (reduce) {
       const float v = wave_sum_hi(gd);
@@ -183,16 +254,29 @@ static TailArgs tail_args(int N, int H, int W, int flags, const float* raw_logit
   return a;
 }
 
-#define PD_TAIL_DISPATCH(KERNEL, mix, hasmask, grid, shmem, stream, ...)                                     \
+#define PD_TAIL_DISPATCH_PX(KERNEL, PX, mix, hasmask, grid, shmem, stream, ...)                             \
   do {                                                                                                       \
     if (mix) {                                                                                               \
-      if (hasmask) KERNEL<true, true><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                         \
-      else         KERNEL<true, false><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                        \
+      if (hasmask) KERNEL<true, true, PX><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                     \
+      else         KERNEL<true, false, PX><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                    \
     } else {                                                                                                 \
-      if (hasmask) KERNEL<false, true><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                        \
-      else         KERNEL<false, false><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                       \
+      if (hasmask) KERNEL<false, true, PX><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                    \
+      else         KERNEL<false, false, PX><<<grid, kBlock, shmem, stream>>>(__VA_ARGS__);                   \
     }                                                                                                        \
   } while (0)
+#define PD_TAIL_DISPATCH(KERNEL, px, mix, hasmask, grid, shmem, stream, ...)                                 \
+  do {                                                                                                       \
+    if ((px) == 4) PD_TAIL_DISPATCH_PX(KERNEL, 4, mix, hasmask, grid, shmem, stream, __VA_ARGS__);           \
+    else           PD_TAIL_DISPATCH_PX(KERNEL, 1, mix, hasmask, grid, shmem, stream, __VA_ARGS__);           \
+  } while (0)
+
+// 4 pixels per thread when every row of 4 is whole and 16-byte aligned in every tensor involved
+static int tail_px(int H, int W, std::initializer_list<const void*> ptrs) {
+  if (((long)H * W) % 4 != 0) return 1;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return 1;
+  return 4;
+}
 
 }  // namespace pd
 
@@ -211,9 +295,11 @@ extern "C" int pd_decoder_tail_fwd(int B, int N, int H, int W, int flags, const 
   PD_REQUIRE(!(flags & PD_TAIL_MIXTURE) || sigma, "mixture needs the sigma output");
   PD_REQUIRE(!padding_mask || logits, "a padding mask needs the logits output");
   const TailArgs a = tail_args(N, H, W, flags, raw_logits, raw_sigma, padding_mask, disp_layered);
-  dim3 grid(ceil_div(H * W, kBlock), B);
-  PD_TAIL_DISPATCH(tail_fwd_kernel, a.mix, padding_mask != nullptr, grid, 0, (hipStream_t)stream, a, logits, sigma, disp,
-                   depth, stash);
+  const int px = tail_px(H, W, {raw_logits, raw_sigma, padding_mask, a.dense ? disp_layered : nullptr, logits, sigma,
+                                disp, depth, stash});
+  dim3 grid(ceil_div(ceil_div(H * W, px), kBlock), B);
+  PD_TAIL_DISPATCH(tail_fwd_kernel, px, a.mix, padding_mask != nullptr, grid, 0, (hipStream_t)stream, a, logits, sigma,
+                   disp, depth, stash);
   return check_launch("tail_fwd_kernel");
 }
 
@@ -223,8 +309,9 @@ extern "C" int pd_decoder_tail_layers(int B, int N, int H, int W, int flags, con
   if (int rc = tail_validate(B, N, H, W, flags, raw_logits, raw_sigma, raw_logits)) return rc;
   PD_REQUIRE(stash && (pi || probability), "NULL pointer");
   const TailArgs a = tail_args(N, H, W, flags, raw_logits, raw_sigma, padding_mask, nullptr);
-  dim3 grid(ceil_div(H * W, kBlock), B);
-  PD_TAIL_DISPATCH(tail_layers_kernel, a.mix, padding_mask != nullptr, grid, 0, (hipStream_t)stream, a, stash, pi,
+  const int px = tail_px(H, W, {raw_logits, raw_sigma, padding_mask, stash, pi, probability});
+  dim3 grid(ceil_div(ceil_div(H * W, px), kBlock), B);
+  PD_TAIL_DISPATCH(tail_layers_kernel, px, a.mix, padding_mask != nullptr, grid, 0, (hipStream_t)stream, a, stash, pi,
                    probability);
   return check_launch("tail_layers_kernel");
 }
@@ -241,9 +328,12 @@ extern "C" int pd_decoder_tail_bwd(int B, int N, int H, int W, int flags, const 
   const bool reduce = g_disp_layered && !a.dense;
   PD_REQUIRE(!reduce || workspace, "per-plane disparity gradient needs the workspace");
   PD_REQUIRE((size_t)N * sizeof(float) <= 64 * 1024, "too many planes");
-  dim3 grid(ceil_div(H * W, kBlock), B);
+  const int px = tail_px(H, W, {raw_logits, raw_sigma, padding_mask, a.dense ? disp_layered : nullptr, stash, disp,
+                                g_logits, g_sigma, g_disp, g_depth, g_raw_logits, g_raw_sigma,
+                                a.dense ? g_disp_layered : nullptr});
+  dim3 grid(ceil_div(ceil_div(H * W, px), kBlock), B);
   const size_t shmem = reduce ? (size_t)N * sizeof(float) : 0;
-  PD_TAIL_DISPATCH(tail_bwd_kernel, a.mix, padding_mask != nullptr, grid, shmem, (hipStream_t)stream, a, stash, disp,
+  PD_TAIL_DISPATCH(tail_bwd_kernel, px, a.mix, padding_mask != nullptr, grid, shmem, (hipStream_t)stream, a, stash, disp,
                    g_logits, g_sigma, g_disp, g_depth, g_raw_logits, g_raw_sigma, g_disp_layered, workspace);
   if (int rc = check_launch("tail_bwd_kernel")) return rc;
   if (reduce) {
