@@ -69,6 +69,17 @@ constexpr int kRowThreadsMax = 512;  // row workgroups use <= 8 waves (row_threa
 
 // Row handled by workgroup r of an image.  The dispatcher deals consecutive workgroups to the 8 XCDs round-robin; the
 // banded mapping gives each XCD (its own L2) a contiguous band of rows instead of every 8th row.
+// (image, row) of this workgroup: row-major over the images (all images' row 0, then row 1, ...).  The rows that need
+// two source rows (inexact vertical round trip) cluster at small y, so they are dispatched FIRST: longest jobs first
+// instead of image 7's heavy rows starting in the last round (forward 0.148 -> 0.137 ms).  Variant 8 = image-major.
+__device__ __forceinline__ int wg_image(int B, int H) {
+  if (kVariant & 8) return blockIdx.y;
+  return (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)B);
+}
+__device__ __forceinline__ int wg_rowid(int B, int H) {
+  if (kVariant & 8) return blockIdx.x;
+  return (int)((blockIdx.y * gridDim.x + blockIdx.x) / (unsigned)B);
+}
 __device__ __forceinline__ int block_row(int r, int H) {
   if ((kVariant & 1) && (H % 8 == 0)) return (r & 7) * (H >> 3) + (r >> 3);
   return r;
@@ -300,7 +311,7 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
     if (NROWS == 2) lrgb[RS + g] = z;
   }
   const float lim = (float)(W + 2);
-  const int yrow = block_row(blockIdx.x, a.H);
+  const int yrow = block_row(wg_rowid(a.B, a.H), a.H);
   for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
     const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
     const float sd = a.sign * a.plane[di];
@@ -502,7 +513,7 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
   constexpr int U = (NROWS == 1) ? PD_FWD_U : (PD_FWD_U > 1 ? PD_FWD_U / 2 : 1);
   constexpr int G = HASMASK ? 32 : U;  // chunk of the work split (mask words of the stash are written whole)
   static_assert(32 % U == 0, "plane groups must tile the 32-plane mask words");
-  const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
+  const int y = block_row(wg_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
   const int HW = a.H * a.W, N = a.N;
   // mixture kernels are specialised on the automask flag (it costs an exponential per plane); L1 reads it at run time
   const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rows
   // LDS: colour rows float4[2*(W+4)] | sdisp[N] | parked partial sums [nwaves][2][8][64]
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   float* parts = sdisp + a.N;
-  const RowSel row = two_row_form(make_row_sel(block_row(blockIdx.x, a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(wg_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
   float ph_sum;
   if (row.nrows == 2) ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
   else                ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
@@ -748,7 +759,7 @@ template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
                                                   float* sdisp, int* kshift, float* red, float* bnd, float4* lrgb) {
   constexpr int U = PD_BWD_U;
-  const int y = block_row(blockIdx.x, a.H), b = blockIdx.y;
+  const int y = block_row(wg_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
   const int HW = a.H * a.W, W = a.W, N = a.N;
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: stays in SGPRs
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kerne
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);
   float* red = sdisp + 2 * a.N;
   float* bnd = red + a.N;
-  const RowSel row = two_row_form(make_row_sel(block_row(blockIdx.x, a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(wg_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }
