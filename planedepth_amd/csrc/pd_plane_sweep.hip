@@ -428,6 +428,10 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.stash_k = kStashBase + ((d->mode == PD_WARP_DISP) ? (d->N + 31) / 32 : 0);
   const bool mask_rows = (d->flags & PD_MASK_ROWS) != 0;
   a.fast_rows = (d->impl == PD_IMPL_FAST_ROWS) ? 1 : 0;
+  // row pairs need one scalar disparity per plane (the sampling column is then the same in both rows) and no per-pixel
+  // or per-row mask; PD_NO_ROWPAIR=1 (environment) switches them off for A/B runs
+  a.pairs = (d->mode == PD_WARP_DISP && !(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS | PD_MASK_ROWS | PD_RENDER_PROB)) &&
+             padding_mask == nullptr && !a.fast_rows && !getenv("PD_NO_ROWPAIR")) ? 1 : 0;
   a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr && !mask_rows) ? 1 : 0;
   a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
   a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3;

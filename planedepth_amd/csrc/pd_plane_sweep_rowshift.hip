@@ -46,7 +46,7 @@ constexpr int kMaxRowThreads = 1024;
 #define PD_FWD_PF 1
 #endif
 #ifndef PD_FWD_OCC
-#define PD_FWD_OCC 4  // the mask-free forward fits 128 VGPRs without spilling; with a per-pixel mask it needs 3 (below)
+#define PD_FWD_OCC 3  // (the single-row bodies alone fit 128 VGPRs = 4 waves per SIMD; the pair body needs ~147)
 #endif
 #ifndef PD_BWD_U
 #define PD_BWD_U 2
@@ -612,6 +612,184 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
   return ph_sum;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row pairs for the rows whose vertical round trip is inexact.
+// ---------------------------------------------------------------------------------------------------------------
+// Such a row y samples (1 - eps) * row y + eps * row p with p = y +- 1 ("leans" on p).  Served alone it loads two
+// source rows for one target row (a quarter of the rows at H = 192: +25% HBM reads in both kernels, which are bound by
+// exactly that).  When p itself is exact, or leans back on y, one workgroup computes BOTH target rows from the two
+// source rows it loads anyway (one thread = the same column of both rows; the sampling column does not depend on the row
+// when disparities are per plane), and the workgroup of p retires at once.  The rule is local (rows y-1 .. y+1), so every
+// workgroup decides its own role without a table:
+//   * y leans on p, p leans back on y  -> the lower of the two leads;
+//   * y leans on p, p exact            -> y leads unless p-1 also leans on p and y = p+1 (the upper neighbour wins);
+//   * y leans on p, p leans elsewhere  -> y stays a single two-source-row row (a chain; rare).
+// At H = 192: 48 inexact rows -> 26 pairs, 10 left alone (re-reads 25% -> 5% of the rows); H = 384: 94 -> 60 + 14.
+enum PairRole { kSingle = 0, kLeader = 1, kAbsorbed = 2 };
+
+__device__ __forceinline__ int row_lean(int y, int H) {  // 0: exact; +-1: direction of the second source row
+  if (y < 0 || y >= H) return 0;
+  const RowSel r = make_row_sel(y, H);
+  if (r.nrows != 2) return 0;
+  return (r.yA == y) ? +1 : -1;  // rows (y, y+1) or (y-1, y)
+}
+__device__ __forceinline__ bool leads(int y, int H) {  // y is inexact and takes its partner along
+  const int l = row_lean(y, H);
+  if (l == 0) return false;
+  const int p = y + l;
+  const int lp = row_lean(p, H);
+  if (lp == -l) return y < p;                       // mutual
+  if (lp != 0) return false;                        // chain
+  if (l == -1) return row_lean(p - 1, H) != +1;     // p = y-1 is exact: its lower neighbour has the first call on it
+  return true;
+}
+__device__ __forceinline__ PairRole pair_role(int y, int H, int& partner) {
+  partner = y;
+  const int l = row_lean(y, H);
+  if (l != 0) {
+    partner = y + l;
+    if (leads(y, H)) return kLeader;
+    return (row_lean(partner, H) == -l && leads(partner, H)) ? kAbsorbed : kSingle;  // mutual: the other one leads
+  }
+  if (row_lean(y - 1, H) == +1 && leads(y - 1, H)) { partner = y - 1; return kAbsorbed; }
+  if (row_lean(y + 1, H) == -1 && leads(y + 1, H)) { partner = y + 1; return kAbsorbed; }
+  return kSingle;
+}
+
+// Weights of the pair (leader y, partner p) on the two source rows: target y = a0*R_y + b0*R_p, target p = a1*R_p + b1*R_y
+struct PairW {
+  float a0, b0, a1, b1;
+};
+__device__ __forceinline__ PairW pair_weights(int y, int p, int H) {
+  PairW w;
+  const RowSel ry = make_row_sel(y, H), rp = make_row_sel(p, H);
+  w.a0 = (ry.yA == y) ? ry.wA : ry.wB;
+  w.b0 = (ry.yA == y) ? ry.wB : ry.wA;
+  if (rp.nrows == 2) {  // mutual lean
+    w.a1 = (rp.yA == p) ? rp.wA : rp.wB;
+    w.b1 = (rp.yA == p) ? rp.wB : rp.wA;
+  } else {
+    w.a1 = rp.wA;  // exact row: 1
+    w.b1 = 0.0f;
+  }
+  return w;
+}
+
+struct PairPx { float t0, t1, t2, ea; FwdAcc acc; };
+
+template <bool MIX, int U>
+__device__ __forceinline__ void pair_accumulate(const PlaneGroup<2, U>& g, const PairW& pw, PairPx& pL, PairPx& pP,
+                                                bool automask) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float w0 = g.ct[u].w0, w1 = g.ct[u].w1;
+    const bool edge = (g.ct[u].x0 == -1);  // the loads were issued at column 0: their first dword is the RIGHT tap
+    const float e0 = edge ? w1 : w0, e1 = edge ? 0.0f : w1;
+    const Taps<2>& tl = g.tl[u];
+    const Taps<2>& ts = g.ts[u];
+    const ColourTaps<2>& tc = g.tc[u];
+    const float hlA = tl.a0 * e0 + tl.a1 * e1, hlB = tl.b0 * e0 + tl.b1 * e1;
+    const float hsA = MIX ? ts.a0 * e0 + ts.a1 * e1 : 0.0f, hsB = MIX ? ts.b0 * e0 + ts.b1 * e1 : 0.0f;
+    const float rA = tc.nw.x * w0 + tc.ne.x * w1, gA = tc.nw.y * w0 + tc.ne.y * w1, bA = tc.nw.z * w0 + tc.ne.z * w1;
+    const float rB = tc.sw.x * w0 + tc.se.x * w1, gB = tc.sw.y * w0 + tc.se.y * w1, bB = tc.sw.z * w0 + tc.se.z * w1;
+    fwd_accumulate<MIX>(pL.acc, pw.a0 * hlA + pw.b0 * hlB, pw.a0 * hsA + pw.b0 * hsB, pw.a0 * rA + pw.b0 * rB,
+                        pw.a0 * gA + pw.b0 * gB, pw.a0 * bA + pw.b0 * bB, pL.t0, pL.t1, pL.t2, pL.ea, automask);
+    fwd_accumulate<MIX>(pP.acc, pw.a1 * hlB + pw.b1 * hlA, pw.a1 * hsB + pw.b1 * hsA, pw.a1 * rB + pw.b1 * rA,
+                        pw.a1 * gB + pw.b1 * gA, pw.a1 * bB + pw.b1 * bA, pP.t0, pP.t1, pP.t2, pP.ea, automask);
+  }
+}
+
+template <bool MIX, bool AUTO>
+__device__ __forceinline__ float rowpair_fwd_body(const SweepArgs& a, int yL, int yP, int b, float4* lrgb, float* sdisp,
+                                                  float* parts, float* __restrict__ rgb_rec,
+                                                  float* __restrict__ ph_map, float* __restrict__ stash) {
+  static_assert(PD_TC_IN_GROUP, "the pair bodies use the two-group pipeline with colour taps in the group");
+  constexpr int U = PD_FWD_U > 1 ? PD_FWD_U / 2 : 1;  // planes per group; each carries both rows
+  constexpr int G = U;
+  const int HW = a.H * a.W, N = a.N;
+  const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
+  const float Wm1 = (float)(a.W - 1), rcpWm1 = refined_rcp(Wm1);
+  const float* srcb = a.src + (long)b * 3 * HW;
+  const PairW pw = pair_weights(yL, yP, a.H);
+  RowSel rows;  // the two-row loaders' "source rows A and B" are the leader's row and the partner's row
+  rows.nrows = 2; rows.yA = yL; rows.yB = yP; rows.wA = rows.wB = rows.wy_main = 1.0f;
+  stage_row_constants<2>(a, b, rows, lrgb, sdisp);
+  __syncthreads();
+  const char* lbytes = reinterpret_cast<const char*>(lrgb);
+  const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (a.W + kWave - 1) / kWave;
+  const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  float ph_sum = 0.0f;
+  auto target_pixel = [&](int pix, PairPx& p) {
+    p.t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+    p.t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+    p.t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+    p.ea = 0.0f;
+    if (automask) p.ea = fabsf(srcb[pix] - p.t0) + fabsf(srcb[HW + pix] - p.t1) + fabsf(srcb[2 * HW + pix] - p.t2);
+  };
+  // parked partial sums: the single-row layout [nwaves][2 pieces][8][64] holds row L; row P follows in a second copy
+  auto slot = [&](int w, int piece, int r) { return parts + (((r * nwaves + w) * 2 + piece) * 8) * kWave; };
+  for (int it = 0;; ++it) {
+    int seg, n_lo, n_hi, piece;
+    if (!work_item(rw, it, wave, nwaves, N, G, seg, n_lo, n_hi, piece)) break;
+    const int x = seg * kWave + lane;
+    if (x < a.W) {
+      const int pixL = yL * a.W + x, pixP = yP * a.W + x;
+      PairPx pL, pP;
+      target_pixel(pixL, pL);
+      target_pixel(pixP, pP);
+      PlaneGroup<2, U> g0, g1;
+      const int nfull = (n_hi - n_lo) / U;
+#define PD_PISSUE(GR, I) group_issue<MIX, false, 2, U>(GR, a, rows, lbytes, sdisp, b, yL, n_lo + (I) * U, x, HW, Wm1, rcpWm1)
+      int gi = 0;
+      if (nfull > 0) PD_PISSUE(g0, 0);
+      for (; gi + 2 <= nfull; gi += 2) {
+        PD_PISSUE(g1, gi + 1);
+        pair_accumulate<MIX, U>(g0, pw, pL, pP, automask);
+        PD_PISSUE(g0, min(gi + 2, nfull - 1));  // unconditional: see the single-row forward
+        pair_accumulate<MIX, U>(g1, pw, pL, pP, automask);
+      }
+      if (gi < nfull) pair_accumulate<MIX, U>(g0, pw, pL, pP, automask);
+#undef PD_PISSUE
+      for (int n = n_lo + nfull * U; n < n_hi; ++n) {  // remainder planes (only at the end of the plane axis)
+        PlaneGroup<2, 1> gr;
+        group_issue<MIX, false, 2, 1>(gr, a, rows, lbytes, sdisp, b, yL, n, x, HW, Wm1, rcpWm1);
+        pair_accumulate<MIX, 1>(gr, pw, pL, pP, automask);
+      }
+      if (piece < 0) {
+        ph_sum += fwd_store<MIX>(a, pL.acc, b, pixL, HW, pL.t0, pL.t1, pL.t2, pL.ea, automask, rgb_rec, ph_map, stash);
+        ph_sum += fwd_store<MIX>(a, pP.acc, b, pixP, HW, pP.t0, pP.t1, pP.t2, pP.ea, automask, rgb_rec, ph_map, stash);
+      } else {
+        park_acc(slot(wave, piece, 0), lane, pL.acc);
+        park_acc(slot(wave, piece, 1), lane, pP.acc);
+      }
+    }
+  }
+  if (rw.r == 0) return ph_sum;  // workgroup-uniform
+  __syncthreads();
+  if (wave < rw.r) {  // wave j merges the pieces of left-over segment j (in plane order) for both rows
+    const int j = wave, x = (rw.full * nwaves + j) * kWave + lane;
+    if (x < a.W) {
+      for (int r = 0; r < 2; ++r) {
+        FwdAcc acc;
+        acc.m = -3.0e38f;  // finite: merging the empty sum must not produce inf - inf
+        for (int w2 = 0; w2 < nwaves; ++w2) {
+          int cb2, ce2;
+          slice_of(rw.r, rw.cps, w2, nwaves, cb2, ce2);
+          if (cb2 < (j + 1) * rw.cps && ce2 > j * rw.cps && ce2 > cb2)
+            acc = merge_acc(acc, fetch_acc(slot(w2, cb2 < j * rw.cps ? 1 : 0, r), lane));
+        }
+        const int pix = (r ? yP : yL) * a.W + x;
+        PairPx p;
+        target_pixel(pix, p);
+        ph_sum += fwd_store<MIX>(a, acc, b, pix, HW, p.t0, p.t1, p.t2, p.ea, automask, rgb_rec, ph_map, stash);
+      }
+    }
+  }
+  return ph_sum;
+}
+
 template <bool MIX, bool HASMASK, bool AUTO>
 __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
@@ -620,10 +798,22 @@ __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rows
   // LDS: colour rows float4[2*(W+4)] | sdisp[N] | parked partial sums [nwaves][2][8][64]
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   float* parts = sdisp + a.N;
-  const RowSel row = two_row_form(make_row_sel(block_row(wg_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
-  float ph_sum;
-  if (row.nrows == 2) ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
-  else                ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  const int y = block_row(wg_rowid(a.B, a.H), a.H);
+  const RowSel row = two_row_form(make_row_sel(y, a.H), a.fast_rows != 0);
+  float ph_sum = 0.0f;
+  int partner = y;
+  // row pairs: per-plane scalar disparities and no per-pixel mask (then the sampling column is shared by the rows)
+  const PairRole role = (a.pairs && !HASMASK) ? pair_role(y, a.H, partner) : kSingle;
+  if (role == kAbsorbed) {
+    // this row is computed by its neighbour's workgroup
+  } else if (role == kLeader) {
+    if (!HASMASK)
+      ph_sum = rowpair_fwd_body<MIX, AUTO>(a, y, partner, wg_image(a.B, a.H), lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  } else if (row.nrows == 2) {
+    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  } else {
+    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+  }
   if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup (one per wave
     // measured +13 us on the forward: 6144 atomics on a single address serialise in L2)
     const float v = wave_sum_hi(ph_sum);
@@ -944,7 +1134,7 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
                  hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
   const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + (size_t)d->N * sizeof(float) +
-                       (size_t)(block.x / kWave) * 2 * 8 * kWave * sizeof(float);
+                       (size_t)(block.x / kWave) * 2 * 8 * kWave * sizeof(float) * (a.pairs ? 2 : 1);
   const bool mix = (d->flags & PD_MIXTURE) != 0, hasmask = a.has_mask != 0, am = (d->flags & PD_AUTOMASK) != 0;
 #define PD_FWD_LAUNCH(M, K, A)                                                              \
   do {                                                                                      \

@@ -30,6 +30,7 @@ struct SweepArgs {
   const float* plane_aux;
   const float* inv_K3;
   const float* padding_mask;
+  int pairs;               // forward: inexact rows take their neighbour along (per-plane disparities, no mask)
   int fast_rows;           // PD_IMPL_FAST_ROWS: the row-shift kernels drop eps-weighted second source rows
   const float* mask_rows;  // PD_MASK_ROWS: [B,N,H] (row-shift kernels only; padding_mask is NULL then)
   const float* dists;  // PD_RENDER_PROB: [B,N-1,H,W] inter-plane distances at the TARGET pixel (trainer.py:587)
