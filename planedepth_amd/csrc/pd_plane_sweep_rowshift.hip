@@ -69,9 +69,16 @@ constexpr int kRowThreadsMax = 512;  // row workgroups use <= 8 waves (row_threa
 
 // Row handled by workgroup r of an image.  The dispatcher deals consecutive workgroups to the 8 XCDs round-robin; the
 // banded mapping gives each XCD (its own L2) a contiguous band of rows instead of every 8th row.
-// (image, row) of this workgroup: row-major over the images (all images' row 0, then row 1, ...).  The rows that need
-// two source rows (inexact vertical round trip) cluster at small y, so they are dispatched FIRST: longest jobs first
-// instead of image 7's heavy rows starting in the last round (forward 0.148 -> 0.137 ms).  Variant 8 = image-major.
+// (image, row) of this workgroup: row-major over the images (all images' row 0, then row 1, ...).  Two effects:
+// (1) the rows that need two source rows (inexact vertical round trip) cluster at small y, so they are dispatched
+//     FIRST — longest jobs first instead of the last image's heavy rows starting in the last round (forward 0.148 ->
+//     0.137 ms);
+// (2) consecutive workgroups go to the 8 XCDs round-robin, so with B a multiple of 8 the rows y and y+1 of one image
+//     (B workgroups apart) share an XCD and run at the same time: the second source row of an inexact row is its
+//     neighbour's main row and mostly hits in that XCD's L2 (PMC at B = 8: backward HBM traffic 995 -> 909 MB).  Padding
+//     B to a multiple of 8 to get this for every batch size was measured and rejected: the padding workgroups all land
+//     on the same XCDs and leave them idle (B = 4: 4.1 k -> 2.4 k images/s).
+// Variant 8 = the image-major order.
 __device__ __forceinline__ int wg_image(int B, int H) {
   if (kVariant & 8) return blockIdx.y;
   return (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)B);
