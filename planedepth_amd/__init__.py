@@ -7,6 +7,6 @@ from .decoder_tail import fused_decoder_tail  # noqa: F401
 from .layers import (SSIM, BackprojectDepth, HomographyWarp, Project3D, disp_to_depth,  # noqa: F401
                      get_smooth_loss_disp, multimodal_loss)
 from .trainer_path import (add_flip_right_inputs, compute_losses, compute_reprojection_loss, generate_post_process_disp,  # noqa: F401
-                           patch_trainer, pred_novel_images)
+                           patch_trainer, pred_novel_images, pred_self_images)
 
 __version__ = "0.1.0"

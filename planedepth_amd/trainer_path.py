@@ -201,6 +201,24 @@ def generate_post_process_disp(self, inputs):
     return disp_pp.detach(), mask_novel.detach()
 
 
+def pred_self_images(self, inputs, outputs):
+    """Reproject the right view into the left one through the predicted depth (reference trainer.py:605-633): depth from
+    ``outputs["disp"]`` -> BackprojectDepth -> Project3D -> ``F.grid_sample(padding_mode="border")``, each a HIP kernel
+    here.  Writes ``outputs["self_rec"]`` as the reference does.  (Only live with ``--alpha_self`` > 0, where the
+    reference itself then fails on a key mismatch in compute_losses; kept for the module-level parity.)"""
+    from .layers import BackprojectDepth, Project3D
+    disp = outputs["disp"]
+    B, N, H, W = outputs["probability"].shape
+    depth = 0.1 * 0.58 * W / disp
+    T = inputs[("Rt", "r")]
+    bp = getattr(self, "backproject_depth", None) or BackprojectDepth(H, W)
+    pj = getattr(self, "project_3d", None) or Project3D(H, W)
+    cam_points = bp(depth, inputs["inv_K"])
+    pix_coords = pj(cam_points, inputs["K"], T)
+    features = inputs[(_color_name(self.opt), "r")]
+    outputs["self_rec"] = ops.grid_sample(features, pix_coords, padding_mode="border")
+
+
 def add_flip_right_inputs(self, inputs):
     """Batch doubling with the mirrored other view (reference trainer.py:252-276): the same dict, one kernel per image
     tensor instead of a flip copy plus a cat copy.  Inputs are data: no gradients."""
@@ -226,4 +244,5 @@ def patch_trainer(trainer_cls):
     trainer_cls.compute_losses = compute_losses
     trainer_cls.generate_post_process_disp = generate_post_process_disp
     trainer_cls.add_flip_right_inputs = add_flip_right_inputs
+    trainer_cls.pred_self_images = pred_self_images
     return trainer_cls

@@ -609,3 +609,35 @@ def test_fused_mean_of_ph_map(impl):
             assert rel_err(a.cpu(), b.cpu()) < 2e-6
     finally:
         ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+
+
+def test_pred_self_images_vs_oracle():
+    """trainer.py:605-633 through the HIP modules (backproject, project, border-mode grid_sample), forward and the
+    gradient w.r.t. the disparity, against the oracle's restatement of the same chain."""
+    import types
+    import planedepth_amd as pa
+    from oracle import planedepth_oracle as orc
+    from planedepth_amd.synthetic import intrinsics, small_pose
+    g = torch.Generator().manual_seed(21)
+    B, N, H, W = 2, 4, 20, 48
+    K, inv_K = intrinsics(B, H, W)
+    T = small_pose(g, B, stereo=True)
+    disp = (torch.rand(B, 1, H, W, generator=g) * 20 + 2)
+    color = torch.rand(B, 3, H, W, generator=g)
+    gw = torch.randn(B, 3, H, W, generator=g)
+
+    d64 = disp.double().requires_grad_(True)
+    depth = 0.1 * 0.58 * W / d64
+    cam = orc.backproject_depth(depth, inv_K.double())
+    grid = orc.project_3d(cam, K.double(), T.double(), H, W)
+    want = orc.bilinear_sample(color.double(), grid, "border")
+    (want * gw.double()).sum().backward()
+
+    dg = disp.cuda().requires_grad_(True)
+    ns = types.SimpleNamespace(opt=types.SimpleNamespace(match_aug=False))
+    outputs = {"disp": dg, "probability": torch.empty(B, N, H, W, device="meta")}
+    inputs = {("Rt", "r"): T.cuda(), "K": K.cuda(), "inv_K": inv_K.cuda(), ("color", "r"): color.cuda()}
+    pa.pred_self_images(ns, inputs, outputs)
+    (outputs["self_rec"] * gw.cuda()).sum().backward()
+    assert rel_err(outputs["self_rec"].detach().cpu(), want.detach().float()) < TOL
+    assert rel_err(dg.grad.cpu(), d64.grad.float()) < 5e-4   # bilinear derivative through fp32 coordinates
