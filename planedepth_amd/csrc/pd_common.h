@@ -237,6 +237,25 @@ __device__ __forceinline__ float wave_sum_hi(float v) {
   return v;
 }
 
+// Sums of TWO values over the wave for the price of one reduction (gfx950 v_permlane32_swap): returns a's total in
+// lane 31 and b's total in lane 63.
+__device__ __forceinline__ float half_wave_sums_hi(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lanes 0-31: a_lo + a_hi, lanes 32-63: b_lo + b_hi
+  v += dpp_zero<0xB1>(v);
+  v += dpp_zero<0x4E>(v);
+  v += dpp_zero<0x124>(v);
+  v += dpp_zero<0x128>(v);
+  v += dpp_zero<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold the half-wave totals
+  return v;
+}
+
+// LDS float add without a return value, kept out of the compiler's atomic optimiser (which wraps a uniform-address
+// atomic in a readlane loop: ~20 instructions per call in the backward's plane loop).
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(p), v, 0, 0, false);
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }

@@ -61,6 +61,9 @@ constexpr int kMaxRowThreads = 1024;
 #define PD_TC_PREFETCH 1  // colour taps (LDS) ride along with the prefetched plane group; 0: read when the group is reduced
 #endif
 #define PD_TC_IN_GROUP (PD_PF_DEPTH == 2 && PD_TC_PREFETCH)
+#ifndef PD_BWD_PF_DEPTH
+#define PD_BWD_PF_DEPTH PD_PF_DEPTH  // the backward's own pipeline depth (experiments)
+#endif
 #ifndef PD_BWD_OCC
 #define PD_BWD_OCC 3
 #endif
@@ -140,6 +143,11 @@ __device__ __forceinline__ Rsrc row_rsrc_uniform(const float* row, int W) {
   const uint64_t p = reinterpret_cast<uint64_t>(row);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, W * 4, 0x00020000);
+}
+// Descriptor with an explicit extent: 0 bytes turns every access through it into a hardware no-op (how the backward
+// skips a gradient nobody asked for without a branch per plane).
+__device__ __forceinline__ Rsrc row_rsrc_bytes(const float* row, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ float buf_load(Rsrc r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
@@ -886,8 +894,8 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
                                             const RowSel& row, const char* __restrict__ lrgb,
                                             const int* __restrict__ kshift, float* __restrict__ red,
                                             float* __restrict__ bnd, int b, int y, int n0, const SegCtx& sc,
-                                            const PixelCtx& c, int HW, float gix_scale, bool want_plane,
-                                            uint32_t& bits) {
+                                            const PixelCtx& c, int HW, float gix_scale, int want_plane,
+                                            int gl_bytes, int gs_bytes, uint32_t& bits) {
   const int W = a.W, N = a.N;
 #if PD_TC_IN_GROUP
   const ColourTaps<NROWS>* tc = g.tc;
@@ -896,10 +904,11 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
 #pragma unroll
   for (int u = 0; u < U; ++u) tc[u] = load_colour_taps<NROWS>(lrgb, W, colour_off(g.ct[u].x0, W));
 #endif
+  float gds[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
-    const int k = kshift[n];  // nominal shift floor(s*d), |k| <= W
+    const int k = __builtin_amdgcn_readfirstlane(kshift[n]);  // nominal shift floor(s*d), |k| <= W; wave-uniform
     bool mk = sc.active;
     if (HASMASK) {
       if ((n & 31) == 0)
@@ -939,15 +948,26 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     const unsigned xoff = sc.active ? xw4 : 0xFFFFFFF0u;
     float* bp = bnd + (sc.seg * N + n) * 6;
     const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bp);
-    if (o.g_logits) buf_store(row_rsrc(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), W), xoff, out_l);
+    buf_store(row_rsrc_bytes(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), gl_bytes), xoff, out_l);
     if (MIX) {
       const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
-      if (o.g_sigma) buf_store(row_rsrc(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), W), xoff, out_s);
+      buf_store(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), gs_bytes), xoff, out_s);
     }
-    // (per-lane LDS partials, one ds_add_f32 per plane, measured 12% slower than the DPP reduction + one atomic)
-    if (want_plane) {
-      const float v = wave_sum_hi(gd);
-      if (sc.lane == kWave - 1) atomicAdd(&red[n], v);
+    gds[u] = gd;
+  }
+  // Disparity gradient: wave totals into the row's LDS accumulators.  Two planes share one reduction: after
+  // v_permlane32_swap the lower half-wave holds plane u's two half sums and the upper half plane u+1's, so five DPP
+  // steps serve both (lanes 31 and 63 end up with the totals).  (Per-lane LDS partials, one ds_add_f32 per plane and
+  // lane, measured 12% slower.)
+  if (want_plane) {
+#pragma unroll
+    for (int u = 0; u + 1 < U; u += 2) {
+      const float v = half_wave_sums_hi(gds[u], gds[u + 1]);
+      if ((sc.lane & 31) == 31) lds_add(&red[n0 + u + (sc.lane >> 5)], v);
+    }
+    if (U & 1) {
+      const float v = wave_sum_hi(gds[U - 1]);
+      if (sc.lane == kWave - 1) lds_add(&red[n0 + U - 1], v);
     }
   }
 }
@@ -961,7 +981,10 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: stays in SGPRs
   const int nseg = (W + kWave - 1) / kWave;
-  const bool want_plane = (o.g_plane != nullptr);
+  // workgroup-uniform switches as scalars (as lane masks each costs two VALU instructions per plane and use)
+  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
+  const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);  // 0: the stores become no-ops
+  const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
   stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
   for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
   __syncthreads();
@@ -996,9 +1019,9 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     PlaneGroup<NROWS, U> g0, g1, g2;
     const int nfull = (n_hi - n_lo) / U;
 #define PD_BISSUE(GR, I) group_issue<MIX, false, NROWS, U>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, sc.xt, HW, Wm1, rcpWm1)
-#define PD_BCOMP(GR, I) bwd_compute<MIX, HASMASK, NROWS, U>(GR, a, o, row, lbytes, kshift, red, bnd, b, y, n_lo + (I) * U, sc, c, HW, gix_scale, want_plane, bits)
+#define PD_BCOMP(GR, I) bwd_compute<MIX, HASMASK, NROWS, U>(GR, a, o, row, lbytes, kshift, red, bnd, b, y, n_lo + (I) * U, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits)
     int gi = 0;
-    if (PD_BWD_PF && PD_PF_DEPTH == 2) {
+    if (PD_BWD_PF && PD_BWD_PF_DEPTH == 2) {
       if (nfull > 0) PD_BISSUE(g0, 0);
       for (; gi + 2 <= nfull; gi += 2) {
         PD_BISSUE(g1, gi + 1);
@@ -1028,7 +1051,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     for (int n = n_lo + nfull * U; n < n_hi; ++n) {
       PlaneGroup<NROWS, 1> gr;
       group_issue<MIX, false, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
-      bwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, bits);
+      bwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits);
     }
   }
   __syncthreads();
