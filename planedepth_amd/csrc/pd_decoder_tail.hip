@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void tail_bwd_kernel(TailArgs a, const floa
     }
     if (reduce) {
       const float v = wave_sum_hi(gd);
-      if (lane == kWave - 1) atomicAdd(&red[n], v);
+      if (lane == kWave - 1) lds_add(&red[n], v);
     }
   }
   if (reduce) {

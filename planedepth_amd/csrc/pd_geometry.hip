@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void project3d_bwd_kernel(int H, int W, flo
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
       const float s = wave_sum(gk[k]);
-      if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[k], s);
+      if ((threadIdx.x & (kWave - 1)) == 0) lds_add(&red[k], s);
     }
     __syncthreads();
     if (threadIdx.x < 12) partials[((long)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = red[threadIdx.x];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void homography_grid_bwd_kernel(int H, int 
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const float s = wave_sum(gk[k]);
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&red[k], s);
+    if ((threadIdx.x & (kWave - 1)) == 0) lds_add(&red[k], s);
   }
   __syncthreads();
   if (threadIdx.x < 9) partials[((long)m * gridDim.x + blockIdx.x) * 9 + threadIdx.x] = red[threadIdx.x];

@@ -259,10 +259,15 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
       if (o.g_logits) bilinear_scatter_wave(o.g_logits + pl, st, a.W, sg_l, live, sp);
     }
     if (reduce_plane) {
+      const int ln = threadIdx.x & (kWave - 1);
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float v = wave_sum_hi(gk[k]);  // DPP reduction (no LDS round trips), total in lane 63
-        if ((threadIdx.x & (kWave - 1)) == kWave - 1) atomicAdd(&red[n * K + k], v);  // LDS atomic, 4 waves
+      for (int k = 0; k + 1 < K; k += 2) {  // two components per DPP reduction: totals in lanes 31 and 63
+        const float v = half_wave_sums_hi(gk[k], gk[k + 1]);
+        if ((ln & 31) == 31) lds_add(&red[n * K + k + (ln >> 5)], v);  // LDS atomic, 4 waves
+      }
+      if (K & 1) {
+        const float v = wave_sum_hi(gk[K - 1]);
+        if (ln == kWave - 1) lds_add(&red[n * K + K - 1], v);
       }
     }
   }
