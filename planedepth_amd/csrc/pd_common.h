@@ -158,6 +158,34 @@ __device__ __forceinline__ float normalise_roundtrip(float px, float size_m1) {
   return unnormalise(normalise(px, size_m1), size_m1);
 }
 
+// Correctly rounded a / b from the correctly rounded reciprocal of b (Markstein's theorem; b = W-1 is an integer
+// <= 2^24 and a is far from the over/underflow range, so no special cases arise).  Verified bit-for-bit against
+// IEEE division over the whole coordinate range by tests/test_gpu_parity.py::test_fast_division_is_exact.
+__device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
+  const float q0 = a * rcp_b;
+  const float r = fmaf(-q0, b, a);
+  return fmaf(r, rcp_b, q0);
+}
+
+__device__ __forceinline__ float refined_rcp(float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, y, 1.0f);
+  return fmaf(e, y, y);
+}
+
+// normalise_roundtrip with the division by the (workgroup-uniform) size done through its refined reciprocal: the same
+// bits as the IEEE division (Markstein) for every finite px; an infinite px is passed through as IEEE division would
+// (the correction step alone would turn it into NaN).  (g + 1)/2 = fl(2h + 1)/2 = fl(h + 0.5): scaling by 2 commutes
+// with rounding.  The IEEE expansion costs ~11 VALU instructions per coordinate, this 7.
+__device__ __forceinline__ float normalise_roundtrip_rcp(float px, float size_m1, float rcp_size_m1) {
+#pragma clang fp contract(off)
+  const float q = div_by(px, size_m1, rcp_size_m1);
+  const float h = q - 0.5f;
+  const float hh = h + 0.5f;
+  const float r = hh * size_m1;
+  return (fabsf(px) == __builtin_inff()) ? px * size_m1 : r;   // +-inf stays +-inf (size_m1 > 0)
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

@@ -36,21 +36,6 @@ struct ColTap {    // horizontal footprint of one target pixel on one plane
   float w0, w1;    // torch's weights (x1 - ix), (ix - x0)
 };
 
-// Correctly rounded a / b from the correctly rounded reciprocal of b (Markstein's theorem; b = W-1 is an integer
-// <= 2^24 and a is far from the over/underflow range, so no special cases arise).  Verified bit-for-bit against
-// IEEE division over the whole coordinate range by tests/test_gpu_parity.py::test_fast_division_is_exact.
-__device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
-  const float q0 = a * rcp_b;
-  const float r = fmaf(-q0, b, a);
-  return fmaf(r, rcp_b, q0);
-}
-
-__device__ __forceinline__ float refined_rcp(float b) {
-  float y = __builtin_amdgcn_rcpf(b);
-  const float e = fmaf(-b, y, 1.0f);
-  return fmaf(e, y, y);
-}
-
 // ix = unnormalise(normalise(px)) of the reference, bit for bit, in 7 operations:
 //   reference:  q = px/(W-1);  g = (q - 0.5)*2;            [trainer.py:550-552]
 //               ix = ((g + 1)/2) * (W-1)                    [grid_sample, align_corners=True]

@@ -58,7 +58,7 @@ def build_case(B, N, H, W, seed, *, disp_min, disp_max, n_xz=0, dense_disp=False
         sigma = 0.011 + 0.978 * sigma
     res = torch.rand(B, N, 1, 1, generator=g) - 0.5
     level = torch.arange(N, dtype=torch.float32)[None, :, None, None] + res
-    disp_pp = disp_max * (disp_min / disp_max) ** (level / (N - 1))  # [B,N,1,1], the learnable per-plane disparity
+    disp_pp = disp_max * (disp_min / disp_max) ** (level / max(N - 1, 1))  # [B,N,1,1], the learnable per-plane disparity
     if special_disp is not None:
         disp_pp = torch.tensor(special_disp, dtype=torch.float32)[None, :, None, None].repeat(B, 1, 1, 1)
     padding_mask = torch.ones(B, N, H, W)
