@@ -280,9 +280,13 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
     }
     {  // adjoint of the bilinear gather, all 64 lanes together (pd_common.h: neighbours share their atomics)
       const long pl = ((long)b * a.N + n) * HW;
+#ifdef PD_GEN_NOSCATTER  // diagnostics: the kernel without its atomics (keeps the values alive through one lane's store)
+      if (sg_l + sg_s == 123.456f) o.g_logits[pl] = sg_l;
+#else
       const ScatterPlan sp = plan_scatter(st, a.W, live);
       if (MIX && o.g_sigma) bilinear_scatter_wave(o.g_sigma + pl, st, a.W, sg_s, live, sp);
       if (o.g_logits) bilinear_scatter_wave(o.g_logits + pl, st, a.W, sg_l, live, sp);
+#endif
     }
     if (reduce_plane) {
       const int ln = threadIdx.x & (kWave - 1);

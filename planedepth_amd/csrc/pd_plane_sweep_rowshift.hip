@@ -54,6 +54,12 @@ constexpr int kMaxRowThreads = 1024;
 #ifndef PD_PF_DEPTH
 #define PD_PF_DEPTH 2  // groups in the software pipeline (2: one group ahead, colour taps prefetched too; 3: two ahead)
 #endif
+#ifndef PD_STORE_AUX
+#define PD_STORE_AUX 0  // cache-policy bits of the gradient stores (experiments: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef PD_LOAD_AUX
+#define PD_LOAD_AUX 0   // same for the tap loads
+#endif
 #ifndef PD_BWD_PF
 #define PD_BWD_PF 1
 #endif
@@ -153,7 +159,7 @@ __device__ __forceinline__ float buf_load(Rsrc r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 __device__ __forceinline__ void buf_store(Rsrc r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, PD_STORE_AUX);
 }
 
 // Offset of plane n inside one image's [N,H,W] block, in floats: a 32-bit product (the host checks N*H*W < 2^31) added
@@ -175,7 +181,7 @@ struct Taps {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f buf_load2(Rsrc r, unsigned byte_off) {  // 8 bytes at any 4-byte-aligned offset
-  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, PD_LOAD_AUX));
 }
 
 // Both horizontal taps of a row come from ONE 8-byte load at column x0 (measured on gfx950, scripts/probes/buf_probe:
