@@ -60,6 +60,9 @@ constexpr int kMaxRowThreads = 1024;
 #ifndef PD_LOAD_AUX
 #define PD_LOAD_AUX 0   // same for the tap loads
 #endif
+#ifndef PD_BWD_REVERSE
+#define PD_BWD_REVERSE 0  // experiment: backward walks the rows in reverse (measured 1.4 % slower per step)
+#endif
 #ifndef PD_BWD_PF
 #define PD_BWD_PF 1
 #endif
@@ -95,6 +98,13 @@ __device__ __forceinline__ int wg_image(int B, int H) {
 __device__ __forceinline__ int wg_rowid(int B, int H) {
   if (kVariant & 8) return blockIdx.x;
   return (int)((blockIdx.y * gridDim.x + blockIdx.x) / (unsigned)B);
+}
+// Experiment (PD_BWD_REVERSE): the backward walking the rows in the opposite order of the forward, hoping that what the
+// forward touched last is still in the memory-side cache when autograd starts the backward right after it.  Measured:
+// step 0.437 vs 0.431 ms — no cache benefit, and the long two-source-row rows end up in the tail.
+__device__ __forceinline__ int bwd_rowid(int B, int H) {
+  const int r = wg_rowid(B, H);
+  return PD_BWD_REVERSE ? H - 1 - r : r;
 }
 __device__ __forceinline__ int block_row(int r, int H) {
   if ((kVariant & 1) && (H % 8 == 0)) return (r & 7) * (H >> 3) + (r >> 3);
@@ -314,7 +324,7 @@ __device__ __forceinline__ void colour_dx(const ColourTaps<NROWS>& t, const RowS
 // sdisp[n] = sign * disparity clamped to +-(W+2) (beyond +-(W+1) nothing is in view either way).
 template <int NROWS>
 __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, const RowSel& r, float4* __restrict__ lrgb,
-                                                    float* __restrict__ sdisp) {
+                                                    float* __restrict__ sdisp, int yrow) {
   const int W = a.W, HW = a.H * a.W, RS = W + 4;
   const float* srcb = a.src + (long)b * 3 * HW;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -332,7 +342,6 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
     if (NROWS == 2) lrgb[RS + g] = z;
   }
   const float lim = (float)(W + 2);
-  const int yrow = block_row(wg_rowid(a.B, a.H), a.H);
   for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
     const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
     const float sd = a.sign * a.plane[di];
@@ -540,7 +549,7 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
   const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
   const float Wm1 = (float)(a.W - 1), rcpWm1 = refined_rcp(Wm1);
   const float* srcb = a.src + (long)b * 3 * HW;
-  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
+  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp, y);
   __syncthreads();
   const char* lbytes = reinterpret_cast<const char*>(lrgb);
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -734,7 +743,7 @@ __device__ __forceinline__ float rowpair_fwd_body(const SweepArgs& a, int yL, in
   const PairW pw = pair_weights(yL, yP, a.H);
   RowSel rows;  // the two-row loaders' "source rows A and B" are the leader's row and the partner's row
   rows.nrows = 2; rows.yA = yL; rows.yB = yP; rows.wA = rows.wB = rows.wy_main = 1.0f;
-  stage_row_constants<2>(a, b, rows, lrgb, sdisp);
+  stage_row_constants<2>(a, b, rows, lrgb, sdisp, yL);
   __syncthreads();
   const char* lbytes = reinterpret_cast<const char*>(lrgb);
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -982,7 +991,7 @@ template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
                                                   float* sdisp, int* kshift, float* red, float* bnd, float4* lrgb) {
   constexpr int U = PD_BWD_U;
-  const int y = block_row(wg_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
+  const int y = block_row(bwd_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
   const int HW = a.H * a.W, W = a.W, N = a.N;
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: stays in SGPRs
@@ -991,7 +1000,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
   const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);  // 0: the stores become no-ops
   const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
-  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp);
+  stage_row_constants<NROWS>(a, b, row, lrgb, sdisp, y);
   for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
@@ -1096,7 +1105,7 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kerne
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);
   float* red = sdisp + 2 * a.N;
   float* bnd = red + a.N;
-  const RowSel row = two_row_form(make_row_sel(block_row(wg_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }
