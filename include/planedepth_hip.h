@@ -119,7 +119,8 @@ int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, const float* tg
  *   g_logits, g_sigma  [B,N,H,W]  — fully overwritten
  *   g_plane            same shape as `plane` (disp: [B,N] or dense [B,N,H,W]; homography: [B*N,3,3]) — overwritten
  *   g_dists            [B,N-1,H,W] gradient of `dists` (PD_RENDER_PROB only) — overwritten
- *   workspace          pd_sweep_bwd_workspace_floats(d) floats of scratch (only needed when g_plane != NULL)
+ *   workspace          pd_sweep_bwd_workspace_floats(d) floats of scratch (partial sums of g_plane; boundary spill of
+ *                      the row-shift kernels) — uninitialised is fine, one per concurrent call
  */
 int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                        const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,

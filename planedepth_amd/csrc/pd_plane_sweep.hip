@@ -549,9 +549,13 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
+  o.side = nullptr;
   o.g_dists = (d->flags & PD_RENDER_PROB) ? g_dists : nullptr;
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
-  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) return rowshift_bwd(d, ak, o, stream);
+  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) {
+    PD_REQUIRE(workspace, "the row-shift backward needs workspace (pd_sweep_bwd_workspace_floats)");
+    return rowshift_bwd(d, ak, o, stream);
+  }
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;
   dim3 grid(ceil_div(HW, kBlock), d->B);

@@ -861,17 +861,29 @@ __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rows
 // ---------------------------------------------------------------------------------------------------------------
 // Backward: one workgroup per target row; 64-lane segments of the row; gather-form adjoint.
 // ---------------------------------------------------------------------------------------------------------------
-// Segment-boundary records live in LDS, zero-filled at kernel start: bnd[(seg*N + n)*6 + tensor*3 + j] with
-// j = 0: to global slot T0-1, j = 1: to slot Tlast+1, j = 2: to slot Tlast+2 (the row is a ring of W slots).
+// Segment-boundary records.  A 64-lane segment's contributions reach three slots outside it: T0-1 (only when the first
+// lane's left tap sits one column left of its slot), Tlast+1 (always: the last lane's right tap) and Tlast+2 (only when
+// the last lane's taps sit one column right).  The common record lives in LDS, bnd1[(seg*N + n)*2 + tensor], zero-filled
+// at kernel start; the two rare ones (fp32 coordinate noise, `regular` false) go to a per-workgroup global spill,
+// side[((seg*N + n)*2 + tensor)*2 + {0: T0-1, 1: Tlast+2}], flagged in the LDS bitmap irr[] so that nothing has to be
+// zero-filled there.  (All six records in LDS cost 23 KB at 384x1280x49 and one resident workgroup per CU.)
 //
 // Route lane contributions (c0 -> slot lane+dl, c1 -> slot lane+dl+1) to their slots inside the wave and return this
-// lane's slot total.  `last` = last active lane of the segment; `bp` = this (segment, plane, tensor)'s 3 records.
+// lane's slot total.  `last` = last active lane of the segment.
+struct Boundary {   // where a workgroup parks what leaves its segments (see route())
+  float* rec;       // LDS  [nseg*N][2 tensors]
+  unsigned* irr;    // LDS  bitmap over (seg, plane): the two rare records were written to `side`
+  float* side;      // HBM  [nseg*N][2 tensors][2], this workgroup's slice
+};
+
 __device__ __forceinline__ float route(float c0, float c1, int dl, bool regular, int lane, int last,
-                                       float* __restrict__ bp) {
+                                       const Boundary& bnd, int sn, int tns) {
+  float* b1 = bnd.rec + sn * 2 + tns;
   if (regular) {  // every lane's left tap is exactly its own slot: one wave-wide shift
-    if (lane == last) bp[1] = c1;  // leaves the segment on the right
+    if (lane == last) *b1 = c1;  // leaves the segment on the right
     return c0 + wave_shift_up1(c1);
   }
+  float* side2 = bnd.side + sn * 4 + tns * 2;
   float out = 0.0f;
 #pragma unroll
   for (int r = -2; r <= 1; ++r) {
@@ -891,10 +903,11 @@ __device__ __forceinline__ float route(float c0, float c1, int dl, bool regular,
   const float c1_prev = __shfl(c1, lp, kWave);
   const int d_prev = __shfl(dl, lp, kWave);
   if (lane == 0) {
-    bp[0] = (d_first == -1) ? c0_first : 0.0f;                                      // slot -1
-    bp[1] = ((d_last == 1) ? c0_last : 0.0f) + ((d_last == 0) ? c1_last : 0.0f) +
-            ((last >= 1 && d_prev == 1) ? c1_prev : 0.0f);                          // slot last+1
-    bp[2] = (d_last == 1) ? c1_last : 0.0f;                                         // slot last+2
+    side2[0] = (d_first == -1) ? c0_first : 0.0f;                                   // slot -1
+    *b1 = ((d_last == 1) ? c0_last : 0.0f) + ((d_last == 0) ? c1_last : 0.0f) +
+          ((last >= 1 && d_prev == 1) ? c1_prev : 0.0f);                            // slot last+1
+    side2[1] = (d_last == 1) ? c1_last : 0.0f;                                      // slot last+2
+    atomicOr(bnd.irr + (sn >> 5), 1u << (sn & 31));
   }
   return out;
 }
@@ -908,7 +921,7 @@ template <bool MIX, bool HASMASK, int NROWS, int U>
 __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const SweepArgs& a, const BwdOut& o,
                                             const RowSel& row, const char* __restrict__ lrgb,
                                             const int* __restrict__ kshift, float* __restrict__ red,
-                                            float* __restrict__ bnd, int b, int y, int n0, const SegCtx& sc,
+                                            const Boundary& bnd, int b, int y, int n0, const SegCtx& sc,
                                             const PixelCtx& c, int HW, float gix_scale, int want_plane,
                                             int gl_bytes, int gs_bytes, uint32_t& bits) {
   const int W = a.W, N = a.N;
@@ -961,11 +974,11 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     const unsigned xs4 = (unsigned)(sc.xt + k) << 2, W4 = (unsigned)W << 2;
     const unsigned xw4 = (xs4 < W4) ? xs4 : xs4 + ((k > 0) ? 0u - W4 : W4);
     const unsigned xoff = sc.active ? xw4 : 0xFFFFFFF0u;
-    float* bp = bnd + (sc.seg * N + n) * 6;
-    const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bp);
+    const int sn = sc.seg * N + n;
+    const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bnd, sn, 0);
     buf_store(row_rsrc_bytes(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), gl_bytes), xoff, out_l);
     if (MIX) {
-      const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bp + 3);
+      const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bnd, sn, 1);
       buf_store(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), gs_bytes), xoff, out_s);
     }
     gds[u] = gd;
@@ -989,7 +1002,7 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
 
 template <bool MIX, bool HASMASK, int NROWS>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
-                                                  float* sdisp, int* kshift, float* red, float* bnd, float4* lrgb) {
+                                                  float* sdisp, int* kshift, float* red, const Boundary& bnd, float4* lrgb) {
   constexpr int U = PD_BWD_U;
   const int y = block_row(bwd_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
   const int HW = a.H * a.W, W = a.W, N = a.N;
@@ -1001,7 +1014,8 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);  // 0: the stores become no-ops
   const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
   stage_row_constants<NROWS>(a, b, row, lrgb, sdisp, y);
-  for (int i = threadIdx.x; i < nseg * N * 6; i += blockDim.x) bnd[i] = 0.0f;
+  for (int i = threadIdx.x; i < nseg * N * 2; i += blockDim.x) bnd.rec[i] = 0.0f;
+  for (int i = threadIdx.x; i < (nseg * N + 31) / 32; i += blockDim.x) bnd.irr[i] = 0u;
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     red[i] = 0.0f;
@@ -1072,20 +1086,30 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   __syncthreads();
   // Deferred segment-boundary contributions: record (seg, n, j) targets global slot g (ring), i.e. source (g+k) mod W.
   const int ntens = MIX ? 2 : 1;
-  const int nrec = nseg * N * 3 * ntens;
+  const int nrec = nseg * N * ntens;
   for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
-    const int j = i % 3, tns = (i / 3) % ntens, n = (i / (3 * ntens)) % N, seg = i / (3 * ntens * N);
-    const float v = bnd[((long)seg * N + n) * 6 + tns * 3 + j];
-    if (v == 0.0f) continue;
+    const int tns = i % ntens, sn = i / ntens, n = sn % N, seg = sn / N;
     float* dst = (tns == 0) ? o.g_logits : o.g_sigma;
     if (!dst) continue;
+    float v[3];
+    v[1] = bnd.rec[sn * 2 + tns];
+    v[0] = v[2] = 0.0f;
+    if ((bnd.irr[sn >> 5] >> (sn & 31)) & 1u) {   // rare: the wave that handled (seg, n) took the general routing path
+      v[0] = bnd.side[sn * 4 + tns * 2];
+      v[2] = bnd.side[sn * 4 + tns * 2 + 1];
+    }
     const int T0 = seg * kWave, last = min(kWave - 1, W - 1 - T0);
-    int g = (j == 0) ? T0 - 1 : T0 + last + j;   // j=1 -> last+1, j=2 -> last+2
-    g = ((g % W) + W) % W;
     const int k = kshift[n];
-    int xs = g + k;
-    xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
-    unsafeAtomicAdd(dst + ((long)b * N + n) * HW + (long)y * W + xs, v);
+    float* drow = dst + ((long)b * N + n) * HW + (long)y * W;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (v[j] == 0.0f) continue;
+      int g = (j == 0) ? T0 - 1 : T0 + last + j;   // j=1 -> last+1, j=2 -> last+2
+      g = ((g % W) + W) % W;
+      int xs = g + k;
+      xs = (xs >= W) ? xs - W : ((xs < 0) ? xs + W : xs);
+      unsafeAtomicAdd(drow + xs, v[j]);
+    }
   }
   if (want_plane) {
     if (a.flags & PD_DISP_ROWS) {  // one disparity per (plane, row): this workgroup owns the whole sum
@@ -1100,11 +1124,15 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
 template <bool MIX, bool HASMASK>
 __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
-  // LDS: colour rows float4[2*(W+4)] | sdisp[N] | kshift[N] | red[N] | bnd[nseg][N][6] (3 records x {logits, sigma})
+  // LDS: colour rows float4[2*(W+4)] | sdisp[N] | kshift[N] | red[N] | rec[nseg][N][2] | irr[ceil(nseg*N/32)]
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);
   float* red = sdisp + 2 * a.N;
-  float* bnd = red + a.N;
+  const int nsn = ((a.W + kWave - 1) / kWave) * a.N;
+  Boundary bnd;
+  bnd.rec = red + a.N;
+  bnd.irr = reinterpret_cast<unsigned*>(bnd.rec + 2 * nsn);
+  bnd.side = o.side + ((long)wg_image(a.B, a.H) * a.H + bwd_rowid(a.B, a.H)) * (4L * nsn);
   const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
@@ -1153,10 +1181,12 @@ static int row_threads(int W) {
 bool rowshift_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
          (long)d->N * d->H * d->W < (1L << 31) &&
-         (size_t)(d->W + 4) * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 6) * 4 <= 160 * 1024;
+         (size_t)(d->W + 4) * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 3) * 4 <= 160 * 1024;
 }
 
-size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
+size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) {
+  return (size_t)d->B * d->H * d->N * (1 + 4 * (size_t)ceil_div(d->W, kWave));   // partial sums + boundary spill
+}
 
 template <typename K>
 static void allow_lds(K kernel, size_t shmem) {
@@ -1178,8 +1208,11 @@ static void allow_lds(K kernel, size_t shmem) {
 int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
                  hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
-  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + (size_t)d->N * sizeof(float) +
-                       (size_t)(block.x / kWave) * 2 * 8 * kWave * sizeof(float) * (a.pairs ? 2 : 1);
+  // parked partial softmax states exist only when segments are left over after the whole rounds (W=640: 10 segments on
+  // 4 waves; W=1280: none — 32 KB less, which is a third resident workgroup per CU there)
+  const int nwaves = block.x / kWave, nseg = ceil_div(d->W, kWave);
+  const size_t park = (nseg % nwaves) ? (size_t)nwaves * 2 * 8 * kWave * (a.pairs ? 2 : 1) : (size_t)kWave;
+  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)d->N + park) * sizeof(float);
   const bool mix = (d->flags & PD_MIXTURE) != 0, hasmask = a.has_mask != 0, am = (d->flags & PD_AUTOMASK) != 0;
 #define PD_FWD_LAUNCH(M, K, A)                                                              \
   do {                                                                                      \
@@ -1196,10 +1229,13 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
   return check_launch("rowshift_fwd_kernel");
 }
 
-int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
+int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o_in, hipStream_t stream) {
   dim3 grid(d->H, d->B), block(row_threads(d->W));
   const int nseg = ceil_div(d->W, kWave);
-  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)3 * d->N + (size_t)nseg * d->N * 6) * sizeof(float);
+  const size_t nsn = (size_t)nseg * d->N;
+  const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)3 * d->N + nsn * 2 + (nsn + 31) / 32) * sizeof(float);
+  BwdOut o = o_in;
+  o.side = o_in.partials + (size_t)d->B * d->H * d->N;   // workspace: [B][H][N] partial sums | [B][H][nseg*N][4] spill
   PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
   int rc = check_launch("rowshift_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;

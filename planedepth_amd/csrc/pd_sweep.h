@@ -44,6 +44,7 @@ struct BwdOut {
   float* g_plane;   // dense disp: written directly; otherwise via partials
   float* g_dists;   // PD_RENDER_PROB only (may be NULL)
   float* partials;  // per-block partial sums of the plane-parameter gradient
+  float* side;      // row-shift backward: global spill of the rare out-of-segment records (see route())
   const float* rgb_rec;
   const float* stash;
   const float* g_rgb_rec;

@@ -97,10 +97,9 @@ class _PlaneSweep(torch.autograd.Function):
         g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
         g_plane = torch.empty_like(plane) if need_plane else None
         g_dists = torch.empty_like(dists) if (dists is not None and ctx.needs_input_grad[8]) else None
-        ws = None
-        if need_plane and not (flags & (C.PD_DISP_DENSE | C.PD_DISP_ROWS)):
-            ws = torch.empty(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)), device=logits.device,
-                             dtype=torch.float32)
+        # scratch: partial sums of the plane-parameter gradient and the row-shift kernels' boundary spill
+        ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device,
+                         dtype=torch.float32)
         g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
         if g_ph_mean is not None:
             g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()

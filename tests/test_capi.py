@@ -34,7 +34,8 @@ def test_desc_layout_and_host_queries():
     lib = C.load()
     d = C.SweepDesc(2, 49, 192, 640, C.PD_WARP_DISP, C.PD_MIXTURE, 1.0, 0)
     assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == (4 + 2) * 192 * 640
-    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49
+    # row-shift backward: [B][H][N] partial sums + [B][H][nseg*N][4] boundary spill (nseg = 10 at W = 640)
+    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 192 * 49 * (1 + 4 * 10)
     d.mode = C.PD_WARP_HOMOGRAPHY
     assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == 4 * 192 * 640
     assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49 * 9
