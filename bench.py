@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--warp_type", default="disp_warp", choices=["disp_warp", "homography_warp"])
+    ap.add_argument("--mono_pose", action="store_true",
+                    help="homography_warp only: a small random rotation + translation per image (a pose_net output, "
+                         "BASELINE configs[3]) instead of the rectified stereo baseline; every sample then has 4 live taps")
     ap.add_argument("--no_mixture", action="store_true")
     ap.add_argument("--automask", action="store_true")
     ap.add_argument("--xz_levels", type=int, default=0,
@@ -71,6 +74,9 @@ def build_step(args, c, device):
     sigma = c["sigma"].clone().requires_grad_(True)
     disp_pp = c["disp_pp"].clone().requires_grad_(not args.no_plane_grad)  # per-plane disparities incl. the learnt residual
     Rt = c["Rt"].clone()
+    if args.mono_pose:
+        from planedepth_amd.synthetic import small_pose
+        Rt = small_pose(torch.Generator().manual_seed(77), B, stereo=False).to(device)
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
                                 render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
                                 gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
@@ -312,9 +318,10 @@ def main():
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %s, stereo target r, %s loss, batch %d/GPU, %dx%d, %d planes, "
+        "config": {"workload": "BASELINE configs[1]: %s, %s, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
-                               % (args.warp_type, "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
+                               % (args.warp_type, "mono pose (random small rotation + translation)" if args.mono_pose
+                                  else "stereo target r", "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
                                   args.height, args.width, args.planes + args.xz_levels),
                    "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
                    "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
