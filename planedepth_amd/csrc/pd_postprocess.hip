@@ -7,6 +7,8 @@
 // zeros padding) reproduced through pd_common.h's normalise_roundtrip, and PD_PP_FLIP_SRC reading the source planes
 // mirrored along x (the `.flip(-1)` of trainer.py:451) without materialising the flipped tensor.  Forward only: the
 // reference runs this under the fixed (no-grad) networks and detaches the result (:466).
+#include <math.h>
+#include <stdlib.h>
 #include "pd_common.h"
 
 namespace pd {
@@ -15,60 +17,147 @@ struct WarpArgs {
   int N, H, W;
   int dense, flip;
   float sign;
+  float Wm1, rcpWm1;   // W - 1 and its correctly rounded reciprocal (host-computed: 1/(W-1) in double, rounded once)
   const float* planes;
   const float* disp;
 };
 
-// bilinear sample of one [H,W] plane with optionally mirrored columns
+typedef float v2f_u4 __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load at 4-byte alignment
+
+// These kernels are latency-bound gathers (no reuse, one thread per pixel), so the loop is shaped for loads in flight:
+// everything that depends on the row only is hoisted (the vertical taps are the same for all planes), the two column
+// taps of a row come as ONE 8-byte load from a clamped, always-valid position with the out-of-image cases folded into
+// the weights (no branches around loads), planes go in groups of kGroup with all loads issued before the first use,
+// and a wave whose pixels all have a zero second vertical weight (three rows of four: the reference's
+// y -> [-1,1] -> y round trip is exact there) runs a one-row loop that never reads the second row.  (With finite
+// inputs skipping a zero-weighted row gives the same number.)
+constexpr int kGroup = 4;
+
+struct RowTaps {        // per pixel, plane-independent
+  int ra, rb;           // clamped source rows
+  float wa, wb;         // their weights (0 when the row is outside the image)
+};
+__device__ __forceinline__ RowTaps row_taps(int y, int H) {
+  const float iy = normalise_roundtrip((float)y, (float)(H - 1));
+  const float yf = floorf(iy), yf1 = yf + 1.0f;
+  const bool va = (yf >= 0.0f) && (yf <= (float)(H - 1)), vb = (yf1 >= 0.0f) && (yf1 <= (float)(H - 1));
+  const int y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H);
+  RowTaps r;
+  r.ra = min(max(y0, 0), H - 1);
+  r.rb = min(max(y0 + 1, 0), H - 1);
+  r.wa = va ? yf1 - iy : 0.0f;
+  r.wb = vb ? iy - yf : 0.0f;
+  return r;
+}
+
+struct ColPair {        // per pixel and plane: where to load the column pair and how to weight its two values
+  int off;              // first column of the pair, in [0, W-2]
+  float e0, e1;
+};
 template <bool FLIP>
-__device__ __forceinline__ float sample(const float* __restrict__ p, const Tap& t, int W) {
-  const int c0 = FLIP ? (W - 1 - t.x0) : t.x0, c1 = FLIP ? (W - 2 - t.x0) : (t.x0 + 1);
-  const float* r0 = p + (long)t.y0 * W;
-  const float* r1 = r0 + W;
-  const float nw = (t.vx0 && t.vy0) ? r0[c0] : 0.0f;
-  const float ne = (t.vx1 && t.vy0) ? r0[c1] : 0.0f;
-  const float sw = (t.vx0 && t.vy1) ? r1[c0] : 0.0f;
-  const float se = (t.vx1 && t.vy1) ? r1[c1] : 0.0f;
-  return nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
+__device__ __forceinline__ ColPair col_pair(float ix, int W) {
+  const float xf = floorf(ix), xf1 = xf + 1.0f;
+  const float wx0 = xf1 - ix, wx1 = ix - xf;
+  const bool v0 = (xf >= 0.0f) && (xf <= (float)(W - 1)), v1 = (xf1 >= 0.0f) && (xf1 <= (float)(W - 1));
+  const int x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W);
+  const int c = min(max(x0, 0), W - 2);
+  const float g0 = v0 ? wx0 : 0.0f, g1 = v1 ? wx1 : 0.0f;   // weights of columns x0 and x0+1
+  // the loaded pair is columns (c, c+1); x0 == c in the interior, c-1 at the left border, c+1 at the right one
+  const float e0 = (x0 == c) ? g0 : ((x0 == c - 1) ? g1 : 0.0f);
+  const float e1 = (x0 == c) ? g1 : ((x0 == c + 1) ? g0 : 0.0f);
+  ColPair p;
+  if (FLIP) { p.off = W - 2 - c; p.e0 = e1; p.e1 = e0; }    // mirrored columns: the pair is read in reverse order
+  else      { p.off = c;         p.e0 = e0; p.e1 = e1; }
+  return p;
 }
 
-__device__ __forceinline__ Tap plane_tap(const WarpArgs& a, int b, int n, int x, int y, float iy) {
+__device__ __forceinline__ float plane_ix(const WarpArgs& a, int b, int n, int x, int y) {
   const float d = a.dense ? a.disp[(((long)b * a.N + n) * a.H + y) * a.W + x] : a.disp[b * a.N + n];
-  const float ix = normalise_roundtrip((float)x + a.sign * d, (float)(a.W - 1));
-  return make_tap(ix, iy, a.W, a.H);
+  // the division by W-1 through its refined reciprocal: the same bits as IEEE division (pd_common.h), a third of the cost
+  return normalise_roundtrip_rcp((float)x + a.sign * d, a.Wm1, a.rcpWm1);
 }
 
+// Samples of planes n0 .. n0+U-1 at this pixel (all loads first).
+template <bool FLIP, int NR, int U>
+__device__ __forceinline__ void sample_group(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b,
+                                             int n0, int x, int y, int HW, float (&out)[U]) {
+  ColPair cp[U];
+  v2f_u4 va[U], vb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    cp[u] = col_pair<FLIP>(plane_ix(a, b, n0 + u, x, y), a.W);
+    const float* pl = pb + (long)(n0 + u) * HW;
+    va[u] = *reinterpret_cast<const v2f_u4*>(pl + (long)r.ra * a.W + cp[u].off);
+    if (NR == 2) vb[u] = *reinterpret_cast<const v2f_u4*>(pl + (long)r.rb * a.W + cp[u].off);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float v = (va[u].x * cp[u].e0 + va[u].y * cp[u].e1) * r.wa;
+    if (NR == 2) v += (vb[u].x * cp[u].e0 + vb[u].y * cp[u].e1) * r.wb;
+    out[u] = v;
+  }
+}
+
+// f(n, value) for every plane of this pixel, in plane order
+template <bool FLIP, int NR, typename F>
+__device__ __forceinline__ void for_each_sample(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b,
+                                                int x, int y, int HW, F f) {
+  int n = 0;
+  for (; n + kGroup <= a.N; n += kGroup) {
+    float v[kGroup];
+    sample_group<FLIP, NR, kGroup>(a, pb, r, b, n, x, y, HW, v);
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) f(n + u, v[u]);
+  }
+  for (; n < a.N; ++n) {
+    float v[1];
+    sample_group<FLIP, NR, 1>(a, pb, r, b, n, x, y, HW, v);
+    f(n, v[0]);
+  }
+}
+
+// Softmax over the planes of the warped logits.  Pass 1 finds max and sum, pass 2 samples again and writes the
+// probabilities: N writes and (cache permitting) N reads per pixel.  Measured at 4x49x192x640: 92-100 us; parking the
+// sampled logits in `out` between the passes (2N writes + 2N reads) 118 us; parking them in LDS (128-thread workgroups,
+// 25 KB each) 120 us — the kernel is VALU-bound (coordinate chain + tap set-up per plane), LDS costs it occupancy.
 template <bool FLIP>
 __global__ __launch_bounds__(kBlock) void warp_softmax_kernel(WarpArgs a, float* __restrict__ out) {
   const int HW = a.H * a.W;
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
-  if (pix >= HW) return;
-  const int y = pix / a.W, x = pix - y * a.W;
-  const float iy = normalise_roundtrip((float)y, (float)(a.H - 1));
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const bool active = pix < HW;
+  const int y = active ? pix / a.W : 0, x = active ? pix - y * a.W : 0;
+  const RowTaps r = row_taps(y, a.H);
+  const bool two_rows = __any(active && r.wb != 0.0f);   // wave-uniform
+  if (!active) return;
   const float* pb = a.planes + (long)b * a.N * HW;
   float* ob = out + (long)b * a.N * HW + pix;
-  // pass 1: sampled logits to `out`, running max / sum; pass 2: normalise this pixel's own N values in place
   float m = -INFINITY, Z = 0.0f;
-  for (int n = 0; n < a.N; ++n) {
-    const float l = sample<FLIP>(pb + (long)n * HW, plane_tap(a, b, n, x, y, iy), a.W);
-    ob[(long)n * HW] = l;
+  auto stat = [&](int, float l) {
     if (l > m) { Z *= __expf(m - l); m = l; }
     Z += __expf(l - m);
-  }
+  };
+  if (two_rows) for_each_sample<FLIP, 2>(a, pb, r, b, x, y, HW, stat);
+  else          for_each_sample<FLIP, 1>(a, pb, r, b, x, y, HW, stat);
   const float invZ = 1.0f / Z;
-  for (int n = 0; n < a.N; ++n) ob[(long)n * HW] = __expf(ob[(long)n * HW] - m) * invZ;
+  auto emit = [&](int n, float l) { ob[(long)n * HW] = __expf(l - m) * invZ; };
+  if (two_rows) for_each_sample<FLIP, 2>(a, pb, r, b, x, y, HW, emit);
+  else          for_each_sample<FLIP, 1>(a, pb, r, b, x, y, HW, emit);
 }
 
 template <bool FLIP>
 __global__ __launch_bounds__(kBlock) void warp_sum_kernel(WarpArgs a, float cap, float* __restrict__ out) {
   const int HW = a.H * a.W;
-  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
-  if (pix >= HW) return;
-  const int y = pix / a.W, x = pix - y * a.W;
-  const float iy = normalise_roundtrip((float)y, (float)(a.H - 1));
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const bool active = pix < HW;
+  const int y = active ? pix / a.W : 0, x = active ? pix - y * a.W : 0;
+  const RowTaps r = row_taps(y, a.H);
+  const bool two_rows = __any(active && r.wb != 0.0f);
+  if (!active) return;
   const float* pb = a.planes + (long)b * a.N * HW;
   float acc = 0.0f;
-  for (int n = 0; n < a.N; ++n) acc += sample<FLIP>(pb + (long)n * HW, plane_tap(a, b, n, x, y, iy), a.W);
+  auto add = [&](int, float v) { acc += v; };
+  if (two_rows) for_each_sample<FLIP, 2>(a, pb, r, b, x, y, HW, add);
+  else          for_each_sample<FLIP, 1>(a, pb, r, b, x, y, HW, add);
   out[(long)b * HW + pix] = fminf(acc, cap);   // o[o > 1] = 1
 }
 
@@ -82,6 +171,15 @@ static int warp_args(WarpArgs& a, int B, int N, int H, int W, float sign, int fl
   a.dense = (flags & PD_PP_DISP_DENSE) != 0;
   a.flip = (flags & PD_PP_FLIP_SRC) != 0;
   a.sign = sign; a.planes = planes; a.disp = disp;
+  a.Wm1 = (float)(W - 1);
+  {  // the correctly rounded fp32 reciprocal of W-1: candidates around the double quotient, |r * d - 1| exact in double
+    const double dd = (double)(W - 1);
+    float best = (float)(1.0 / dd);
+    const float cand[2] = {nextafterf(best, 0.0f), nextafterf(best, 2.0f)};
+    for (float c : cand)
+      if (fabs((double)c * dd - 1.0) < fabs((double)best * dd - 1.0)) best = c;
+    a.rcpWm1 = best;
+  }
   return 0;
 }
 
