@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "pd_common.h"
+#include "pd_rowgeom.h"
 
 namespace pd {
 
@@ -161,6 +162,124 @@ __global__ __launch_bounds__(kBlock) void warp_sum_kernel(WarpArgs a, float cap,
   out[(long)b * HW + pix] = fminf(acc, cap);   // o[o > 1] = 1
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-plane scalar disparities (the decoder's expanded [B,N,1,1] levels, the usual case): along a target row every pixel
+// samples plane n at x + s*d_n, so the row-shift machinery of the sweep applies — one wave per 64-pixel segment of a
+// row, the vertical taps are wave-uniform scalars, each (plane, row) gets a buffer descriptor whose hardware range
+// check IS padding_mode="zeros", the two column taps come in one 8-byte load (column -1 fixed up through the
+// weights), and the sampling position costs make_col_tap's 7 operations instead of the general chain — half the
+// instructions of the gather kernels above in a VALU-bound loop.  FLIP reads the pair at the mirrored columns.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t PRsrc;
+typedef float v2f_b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ PRsrc pp_row_rsrc(const float* row, int W) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, W * 4, 0x00020000);
+}
+__device__ __forceinline__ v2f_b pp_load2(PRsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(v2f_b, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+
+struct RowPair {   // where the pair load goes and how its two dwords are weighted
+  unsigned off;
+  float e0, e1;
+};
+template <bool FLIP>
+__device__ __forceinline__ RowPair row_pair(const ColTap& t, int W) {
+  // columns x0 / x0+1 carry weights w0 / w1; mirrored, they are columns W-1-x0 / W-2-x0, read as the pair at W-2-x0
+  const int c = FLIP ? W - 2 - t.x0 : t.x0;
+  const bool edge = (c == -1);   // the pair starts one column left of the row: load at column 0, its first dword is the second tap
+  RowPair p;
+  p.off = edge ? 0u : ((unsigned)c << 2);   // any other out-of-row position is range-checked to zeros by the hardware
+  const float first = FLIP ? t.w1 : t.w0, second = FLIP ? t.w0 : t.w1;
+  p.e0 = edge ? second : first;
+  p.e1 = edge ? 0.0f : second;
+  return p;
+}
+
+// the shift s*d_n, clamped like the sweep's staged shifts (beyond +-(W+1) nothing is in view; keeps x0*4 from aliasing)
+__device__ __forceinline__ float plane_shift(const WarpArgs& a, int b, int n) {
+  const float sd = a.sign * a.disp[b * a.N + n], lim = (float)(a.W + 2);
+  return (sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f) ? -lim : lim);   // NaN -> +lim
+}
+
+template <bool FLIP, int NR, int U>
+__device__ __forceinline__ void rows_group(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b,
+                                           int n0, int x, int HW, float (&out)[U]) {
+  RowPair rp[U];
+  v2f_b va[U], vb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    rp[u] = row_pair<FLIP>(make_col_tap((float)x + plane_shift(a, b, n0 + u), a.Wm1, a.rcpWm1), a.W);
+    const float* pl = pb + (long)(n0 + u) * HW;   // wave-uniform
+    va[u] = pp_load2(pp_row_rsrc(pl + (long)r.ra * a.W, a.W), rp[u].off);
+    if (NR == 2) vb[u] = pp_load2(pp_row_rsrc(pl + (long)r.rb * a.W, a.W), rp[u].off);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float v = (va[u].x * rp[u].e0 + va[u].y * rp[u].e1) * r.wa;
+    if (NR == 2) v += (vb[u].x * rp[u].e0 + vb[u].y * rp[u].e1) * r.wb;
+    out[u] = v;
+  }
+}
+
+template <bool FLIP, int NR, typename F>
+__device__ __forceinline__ void rows_for_each(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b,
+                                              int x, int HW, F f) {
+  int n = 0;
+  for (; n + kGroup <= a.N; n += kGroup) {
+    float v[kGroup];
+    rows_group<FLIP, NR, kGroup>(a, pb, r, b, n, x, HW, v);
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) f(n + u, v[u]);
+  }
+  for (; n < a.N; ++n) {
+    float v[1];
+    rows_group<FLIP, NR, 1>(a, pb, r, b, n, x, HW, v);
+    f(n, v[0]);
+  }
+}
+
+// grid (segments of 64 pixels, H, B), one wave per workgroup
+template <bool FLIP>
+__global__ __launch_bounds__(kWave) void warp_softmax_rows_kernel(WarpArgs a, float* __restrict__ out) {
+  const int HW = a.H * a.W, y = blockIdx.y, b = blockIdx.z;
+  const int x = blockIdx.x * kWave + threadIdx.x;
+  const RowTaps r = row_taps(y, a.H);   // wave-uniform
+  const float* pb = a.planes + (long)b * a.N * HW;
+  const bool active = x < a.W;
+  float* ob = out + (long)b * a.N * HW + (long)y * a.W + (active ? x : 0);
+  float m = -INFINITY, Z = 0.0f;
+  auto stat = [&](int, float l) {
+    if (l > m) { Z *= __expf(m - l); m = l; }
+    Z += __expf(l - m);
+  };
+  if (r.wb != 0.0f) rows_for_each<FLIP, 2>(a, pb, r, b, x, HW, stat);
+  else              rows_for_each<FLIP, 1>(a, pb, r, b, x, HW, stat);
+  const float invZ = 1.0f / Z;
+  auto emit = [&](int n, float l) { if (active) ob[(long)n * HW] = __expf(l - m) * invZ; };
+  if (r.wb != 0.0f) rows_for_each<FLIP, 2>(a, pb, r, b, x, HW, emit);
+  else              rows_for_each<FLIP, 1>(a, pb, r, b, x, HW, emit);
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(kWave) void warp_sum_rows_kernel(WarpArgs a, float cap, float* __restrict__ out) {
+  const int HW = a.H * a.W, y = blockIdx.y, b = blockIdx.z;
+  const int x = blockIdx.x * kWave + threadIdx.x;
+  const RowTaps r = row_taps(y, a.H);
+  const float* pb = a.planes + (long)b * a.N * HW;
+  float acc = 0.0f;
+  auto add = [&](int, float v) { acc += v; };
+  if (r.wb != 0.0f) rows_for_each<FLIP, 2>(a, pb, r, b, x, HW, add);
+  else              rows_for_each<FLIP, 1>(a, pb, r, b, x, HW, add);
+  if (x < a.W) out[(long)b * HW + (long)y * a.W + x] = fminf(acc, cap);
+}
+
+// the row kernels need 32-bit byte offsets inside a row and grid dimensions within the launch limits
+static bool rows_applicable(const WarpArgs& a, int B) {
+  static const bool off = getenv("PD_PP_ROWS") && atoi(getenv("PD_PP_ROWS")) == 0;   // A/B hook
+  return !off && !a.dense && a.H <= 65535 && B <= 65535 && a.W <= (1 << 24);
+}
+
 static int warp_args(WarpArgs& a, int B, int N, int H, int W, float sign, int flags, const float* planes,
                      const float* disp) {
   PD_REQUIRE(B > 0 && B <= 65535 && N > 0 && H > 0 && W > 1, "bad shape");
@@ -192,6 +311,12 @@ extern "C" int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags
   WarpArgs a;
   if (int rc = warp_args(a, B, N, H, W, sign, flags, planes, disp)) return rc;
   PD_REQUIRE(out && out != planes, "out must be a distinct buffer");
+  if (rows_applicable(a, B)) {
+    dim3 g(ceil_div(W, kWave), H, B);
+    if (a.flip) warp_softmax_rows_kernel<true><<<g, kWave, 0, (hipStream_t)stream>>>(a, out);
+    else        warp_softmax_rows_kernel<false><<<g, kWave, 0, (hipStream_t)stream>>>(a, out);
+    return check_launch("warp_softmax_rows_kernel");
+  }
   dim3 grid(ceil_div(H * W, kBlock), B);
   if (a.flip) warp_softmax_kernel<true><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, out);
   else        warp_softmax_kernel<false><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, out);
@@ -203,6 +328,12 @@ extern "C" int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, co
   WarpArgs a;
   if (int rc = warp_args(a, B, N, H, W, sign, flags, planes, disp)) return rc;
   PD_REQUIRE(out, "NULL output");
+  if (rows_applicable(a, B)) {
+    dim3 g(ceil_div(W, kWave), H, B);
+    if (a.flip) warp_sum_rows_kernel<true><<<g, kWave, 0, (hipStream_t)stream>>>(a, cap, out);
+    else        warp_sum_rows_kernel<false><<<g, kWave, 0, (hipStream_t)stream>>>(a, cap, out);
+    return check_launch("warp_sum_rows_kernel");
+  }
   dim3 grid(ceil_div(H * W, kBlock), B);
   if (a.flip) warp_sum_kernel<true><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, cap, out);
   else        warp_sum_kernel<false><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, cap, out);

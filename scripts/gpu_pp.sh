@@ -1,9 +1,9 @@
-# post-process kernels: parity tests, then per-kernel times with and without LDS staging of the softmax
+# post-process kernels: parity tests, then per-kernel times of the row kernels (default) and the general gathers (PD_PP_ROWS=0)
 timeout 600 python -m pytest tests -m gpu -q -k "post_process" 2>&1 | tail -2
-PD_PP_LDS=0 timeout 600 python -m pytest tests -m gpu -q -k "post_process" 2>&1 | tail -1
+PD_PP_ROWS=0 timeout 600 python -m pytest tests -m gpu -q -k "post_process" 2>&1 | tail -1
 for l in 1 0; do
-  PD_PP_LDS=$l bash scripts/gpu_prof_next.sh > /dev/null
-  echo "PD_PP_LDS=$l"
+  PD_PP_ROWS=$l bash scripts/gpu_prof_next.sh > /dev/null
+  echo "PD_PP_ROWS=$l"
   python - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/prof_next/k_kernel_stats.csv")))

@@ -544,6 +544,32 @@ def test_post_process_fullsize_vs_oracle():
     assert rel_err(got[1].cpu(), want[1]) < TOL
 
 
+@pytest.mark.parametrize("H,W,N,dmax", [(2, 2, 1, 0.9), (3, 5, 2, 9.0), (7, 63, 5, 40.0), (9, 65, 4, 70.0), (5, 130, 9, 300.0)])
+def test_post_process_row_kernels_on_ragged_shapes(H, W, N, dmax):
+    """The row-shift form of the post-process warps (per-plane scalar disparities) on widths below / just above one
+    64-lane segment, one plane, disparities beyond the row (every tap out of view), integer disparities (taps exactly on
+    columns, the x0 = -1 / mirrored-edge fix-ups) — against the oracle; the mirrored (flip) read is half of every call."""
+    from oracle import planedepth_oracle as orc
+    from planedepth_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(1000 + W)
+    logits = torch.randn(2 * B, N, H, W, generator=g) * 2
+    sigma = torch.rand(2 * B, N, H, W, generator=g) * 0.9 + 0.05
+    w = torch.softmax(logits, 1) / sigma
+    prob = w / w.sum(1, True)
+    lv = torch.rand(2 * B, N, 1, 1, generator=g) * dmax
+    lv[:, 0] = torch.round(lv[:, 0])                       # an integer disparity per image
+    dl = lv.expand(-1, -1, H, W)
+    disp = (prob * dl).sum(1, True)
+    want = orc.post_process_disp(logits, prob, disp, dl)
+    got = ops.post_process_disp(logits.cuda(), prob.cuda(), disp.cuda(), dl.cuda())
+    for a_, b_ in zip(got, want):
+        if float(b_.abs().max()) == 0.0:
+            assert float(a_.abs().max()) < 1e-6
+        else:
+            assert rel_err(a_.cpu(), b_) < TOL
+
+
 def test_add_flip_right_inputs_is_bit_exact():
     """the batch-doubling kernel against the oracle's cat/flip restatement of trainer.py:252-276."""
     import types
