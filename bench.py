@@ -222,7 +222,15 @@ def next_rows_times(args, device, iters=10):
     def post():
         ops.post_process_disp(pl, pp, pdisp, pdl)
 
+    pred_leaf = torch.rand(B, 3, H, W, generator=g).to(device).requires_grad_(True)
+    g_rl = mk(B, 1, H, W)
+
+    def reproj_fwd_bwd():   # 0.85 * SSIM(3x3) + 0.15 * L1, the non-mixture photometric loss (layers.py:276-306)
+        ops.reprojection_loss(pred_leaf, img, True).backward(g_rl)
+        pred_leaf.grad = None
+
     t_f, t_fb, t_s, t_p = timed(tail_fwd), timed(tail_fwd_bwd), timed(smooth_fwd_bwd), timed(post)
+    t_r = timed(reproj_fwd_bwd)
     hw4 = H * W * 4
     tail_f_bytes, tail_b_bytes = (3 * N + 4) * hw4 * B, (6 * N + 4) * hw4 * B
     post_bytes = (2 * (2 * N) + 2 * N + N + 3) * hw4 * Bp   # 2 warp-softmax (read N, write N) + 3 warp-sums (read N)
@@ -232,6 +240,7 @@ def next_rows_times(args, device, iters=10):
                          "fwd_bwd_GBs": round((tail_f_bytes + tail_b_bytes) / (t_fb * 1e-3) / 1e9, 1),
                          "shape": [B, N, H, W]},
         "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "shape": [B, 1, H, W - x0]},
+        "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
                          "shape": [2 * Bp, N, H, W]},
         "note": "CUDA-event time around the public operators (includes their Python launch overhead)",

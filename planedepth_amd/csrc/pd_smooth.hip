@@ -24,7 +24,13 @@ __device__ __forceinline__ float edge_weight(const SmoothArgs& a, const float* _
   return __expf(-a.gamma * (s / (float)a.C));
 }
 
-constexpr int kSmoothRows = 8;  // image rows per block of the forward: few blocks, few atomics on the single output
+#ifndef PD_SMOOTH_ROWS
+#define PD_SMOOTH_ROWS 4
+#endif
+constexpr int kSmoothRows = PD_SMOOTH_ROWS;  // image rows per block of the forward; one atomic on the single output each
+// (measured at 8x192x512: 8 rows per block with a flattened (row, column) index and its integer division per pixel
+// 31 us; row loops with 1 / 2 / 4 / 8 / 16 rows per block 24.5 / 18.4 / 18.3 / 29.9 / 55 us — fewer rows means more
+// atomics on the one output word, more rows fewer workgroups than CUs)
 
 __global__ __launch_bounds__(kBlock) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ out) {
   __shared__ float red[kBlock / kWave];
@@ -32,12 +38,15 @@ __global__ __launch_bounds__(kBlock) void smooth_fwd_kernel(SmoothArgs a, float*
   const float* db = a.disp + b * a.d_sb;
   const float* ib = a.img + b * a.i_sb;
   float v = 0.0f;
-  for (int i = threadIdx.x; i < (y1 - y0) * a.W; i += kBlock) {
-    const int y = y0 + i / a.W, x = i % a.W;
-    const float d = db[y * a.d_sh + x];
-    const long ip = y * a.i_sh + x;
-    if (x + 1 < a.W) v += fabsf(d - db[y * a.d_sh + x + 1]) * edge_weight(a, ib, ip, ip + 1) * a.inv_nx;
-    if (y + 1 < a.H) v += fabsf(d - db[(y + 1) * a.d_sh + x]) * edge_weight(a, ib, ip, ip + a.i_sh) * a.inv_ny;
+  for (int y = y0; y < y1; ++y) {
+    const float* dr = db + y * a.d_sh;
+    const long ir = y * a.i_sh;
+    const bool down = y + 1 < a.H;
+    for (int x = threadIdx.x; x < a.W; x += kBlock) {
+      const float d = dr[x];
+      if (x + 1 < a.W) v += fabsf(d - dr[x + 1]) * edge_weight(a, ib, ir + x, ir + x + 1) * a.inv_nx;
+      if (down) v += fabsf(d - dr[a.d_sh + x]) * edge_weight(a, ib, ir + x, ir + x + a.i_sh) * a.inv_ny;
+    }
   }
   v = wave_sum(v);
   if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
