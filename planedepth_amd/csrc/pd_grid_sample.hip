@@ -38,9 +38,9 @@ __global__ __launch_bounds__(kBlock) void grid_sample_bwd_kernel(int C, int Hi, 
                                                                  const float* __restrict__ g_out,
                                                                  float* __restrict__ g_in, float* __restrict__ g_grid) {
   const int pix = blockIdx.x * kBlock + threadIdx.x;
-  if (pix >= HWo) return;
+  const bool live = pix < HWo;   // no early return: the wave-cooperative scatter needs all 64 lanes
   const int m = blockIdx.y;
-  const float2 g = reinterpret_cast<const float2*>(grid)[(long)m * HWo + pix];
+  const float2 g = live ? reinterpret_cast<const float2*>(grid)[(long)m * HWo + pix] : make_float2(0.0f, 0.0f);
   float mx = (float)(Wi - 1) / 2, my = (float)(Hi - 1) / 2;
   float ix = unnormalise(g.x, (float)(Wi - 1)), iy = unnormalise(g.y, (float)(Hi - 1));
   if (border) {
@@ -51,19 +51,24 @@ __global__ __launch_bounds__(kBlock) void grid_sample_bwd_kernel(int C, int Hi, 
     my *= dmy;
   }
   const Tap t = make_tap(ix, iy, Wi, Hi);
+  // neighbouring output pixels usually sample neighbouring input pixels: lanes whose left column is the previous lane's
+  // right column hand their left taps over (pd_common.h) — two atomics per lane and channel instead of four
+  const ScatterPlan sp = plan_scatter(t, Wi, live);
   float gix = 0.0f, giy = 0.0f;
   for (int c = 0; c < C; ++c) {
     const long plane = ((long)m * C + c) * Hi * Wi;
-    const float go = g_out[((long)m * C + c) * HWo + pix];
-    if (g_in) bilinear_scatter(g_in + plane, t, Wi, go);
-    if (g_grid) {
+    const float go = live ? g_out[((long)m * C + c) * HWo + pix] : 0.0f;
+#ifndef PD_GS_NOSCATTER  // diagnostics: the kernel without its atomics
+    if (g_in) bilinear_scatter_wave(g_in + plane, t, Wi, go, live, sp);
+#endif
+    if (g_grid && live) {
       float dx, dy;
       bilinear_grad(in + plane, t, Wi, dx, dy);
       gix += go * dx;
       giy += go * dy;
     }
   }
-  if (g_grid) reinterpret_cast<float2*>(g_grid)[(long)m * HWo + pix] = make_float2(mx * gix, my * giy);
+  if (g_grid && live) reinterpret_cast<float2*>(g_grid)[(long)m * HWo + pix] = make_float2(mx * gix, my * giy);
 }
 
 }  // namespace pd
