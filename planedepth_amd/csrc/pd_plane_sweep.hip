@@ -180,7 +180,14 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
   extern __shared__ float red[];  // [N*K] block accumulators of the plane-parameter gradient
   constexpr int K = (MODE == PD_WARP_DISP) ? 1 : 9;
   const int HW = a.H * a.W;
-  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  // A wave covers 63 consecutive pixels; its lane 0 is a GHOST that repeats the previous wave's last pixel with all its
+  // gradients forced to zero.  The wave-cooperative scatter hands every lane's left taps to the previous lane's right
+  // taps — lane 1's now go to the ghost, so a coherent wave issues no second, nearly empty atomic instruction per row
+  // for its first pixel's left taps.  That instruction cost as much as a full one: the L2's atomic unit is busy per
+  // (instruction, cache line), not per lane (measured: dropping the left-over atomics halved the scatter time).
+  const int lane_id = threadIdx.x & (kWave - 1);
+  const bool ghost = (lane_id == 0);
+  const int pix = (int)((blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * (kWave - 1)) + lane_id - 1;
   const int b = blockIdx.y;
   const bool want_plane = (o.g_plane != nullptr);
   const bool dense = (MODE == PD_WARP_DISP) && (a.flags & PD_DISP_DENSE);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
     for (int i = threadIdx.x; i < a.N * K; i += kBlock) red[i] = 0.0f;
     __syncthreads();
   }
-  const bool active = pix < HW;
+  const bool active = pix >= 0 && pix < HW;
   const int y = active ? pix / a.W : 0, x = active ? pix - y * a.W : 0;
   const bool has_mask = (MODE == PD_WARP_DISP) && a.has_mask;
   const float* srcb = a.src + (long)b * 3 * HW;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
           const float g_alpha = pg.g_l * T - (Rtot - prefix) / keep;
           const float da = (1.0f - alpha);  // d alpha / d (relu(l) * dist)
           pg.g_l = (!last && l > 0.0f) ? g_alpha * dist * da : 0.0f;
-          if (o.g_dists && !last) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = g_alpha * fmaxf(l, 0.0f) * da;
+          if (o.g_dists && !last && !ghost) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = g_alpha * fmaxf(l, 0.0f) * da;
           T *= keep;
         } else {
           pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
@@ -275,8 +282,13 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
           }
         }
       }
-      if (render && !mk && o.g_dists && n < a.N - 1) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = 0.0f;
-      if (dense && want_plane) o.g_plane[pl + pix] = gd_dense;
+      if (render && !mk && o.g_dists && n < a.N - 1 && !ghost) o.g_dists[((long)b * (a.N - 1) + n) * HW + pix] = 0.0f;
+      if (dense && want_plane && !ghost) o.g_plane[pl + pix] = gd_dense;
+    }
+    if (ghost) {  // the ghost only lends its right-tap slots to lane 1
+      sg_l = sg_s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk[k] = 0.0f;
     }
     {  // adjoint of the bilinear gather, all 64 lanes together (pd_common.h: neighbours share their atomics)
       const long pl = ((long)b * a.N + n) * HW;
@@ -491,10 +503,13 @@ extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
   return (size_t)(kStashBase + words) * d->H * d->W;
 }
 
+// workgroups of the general backward: four waves of 63 pixels + 1 ghost lane each
+static int bwd_blocks(int HW) { return ceil_div(HW, (kBlock / kWave) * (kWave - 1)); }
+
 extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   if (!d) return 0;
   const size_t K = (d->mode == PD_WARP_DISP) ? 1 : 9;
-  const size_t general = (size_t)d->B * ceil_div(d->H * d->W, kBlock) * d->N * K;
+  const size_t general = (size_t)d->B * bwd_blocks(d->H * d->W) * d->N * K;
   const size_t rows = rowshift_applicable(d) ? rowshift_bwd_workspace_floats(d) : 0;
   return general > rows ? general : rows;
 }
@@ -558,7 +573,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   }
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;
-  dim3 grid(ceil_div(HW, kBlock), d->B);
+  dim3 grid(bwd_blocks(HW), d->B);
   const int K = (d->mode == PD_WARP_DISP) ? 1 : 9;
   // general path: the bilinear adjoint is an atomic scatter into zero-filled gradients
   if (g_logits) (void)hipMemsetAsync(g_logits, 0, plane_bytes, stream);

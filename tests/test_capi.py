@@ -38,7 +38,8 @@ def test_desc_layout_and_host_queries():
     assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 192 * 49 * (1 + 4 * 10)
     d.mode = C.PD_WARP_HOMOGRAPHY
     assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == 4 * 192 * 640
-    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49 * 9
+    # general backward: workgroups of four 63-pixel waves (ceil(192*640 / 252) = 488), nine sums per plane
+    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 488 * 49 * 9
 
 
 def test_argument_validation_needs_no_gpu():
