@@ -63,6 +63,9 @@ constexpr int kMaxRowThreads = 1024;
 #ifndef PD_BWD_REVERSE
 #define PD_BWD_REVERSE 0  // experiment: backward walks the rows in reverse (measured 1.4 % slower per step)
 #endif
+#ifndef PD_BWD_HANDOVER
+#define PD_BWD_HANDOVER 1  // lane 0 takes its left neighbour's hand-over out of LDS when it is already there
+#endif
 #ifndef PD_BWD_PF
 #define PD_BWD_PF 1
 #endif
@@ -913,7 +916,7 @@ __device__ __forceinline__ float route(float c0, float c1, int dl, bool regular,
 }
 
 struct SegCtx {
-  int seg, T0, xt, last, lane, pix;
+  int seg, seg_prev, T0, xt, last, lane, pix;   // seg_prev: the left neighbour on the ring
   bool active;
 };
 
@@ -932,7 +935,8 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
 #pragma unroll
   for (int u = 0; u < U; ++u) tc[u] = load_colour_taps<NROWS>(lrgb, W, colour_off(g.ct[u].x0, W));
 #endif
-  float gds[U];
+  float gds[U], outl[U], outs[U];
+  unsigned xoffs[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = n0 + u;
@@ -975,13 +979,33 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     const unsigned xw4 = (xs4 < W4) ? xs4 : xs4 + ((k > 0) ? 0u - W4 : W4);
     const unsigned xoff = sc.active ? xw4 : 0xFFFFFFF0u;
     const int sn = sc.seg * N + n;
-    const float out_l = route(cl0, cl1, dl, regular, sc.lane, sc.last, bnd, sn, 0);
-    buf_store(row_rsrc_bytes(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), gl_bytes), xoff, out_l);
-    if (MIX) {
-      const float out_s = route(cs0, cs1, dl, regular, sc.lane, sc.last, bnd, sn, 1);
-      buf_store(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), gs_bytes), xoff, out_s);
-    }
+    outl[u] = route(cl0, cl1, dl, regular, sc.lane, sc.last, bnd, sn, 0);
+    if (MIX) outs[u] = route(cs0, cs1, dl, regular, sc.lane, sc.last, bnd, sn, 1);
+    xoffs[u] = xoff;
     gds[u] = gd;
+  }
+  // Stores of the group, as late as possible: the first slot of the segment (lane 0) also receives what the last lane of
+  // the left neighbour segment hands over (route()).  If that wave has already been here — the waves of a workgroup
+  // run the same planes at about the same time — lane 0 takes the value out of LDS now (exchange with 0, so that it
+  // is added exactly once) and it never becomes a deferred global atomic; otherwise the epilogue adds it as before.
+  {
+    float hl[U], hs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      hl[u] = hs[u] = 0.0f;
+      if (PD_BWD_HANDOVER && sc.lane == 0) {
+        float* rp = bnd.rec + (sc.seg_prev * N + n0 + u) * 2;
+        hl[u] = atomicExch(rp, 0.0f);
+        if (MIX) hs[u] = atomicExch(rp + 1, 0.0f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + u;
+      buf_store(row_rsrc_bytes(plane_ptr(o.g_logits + (long)b * N * HW + (long)y * W, n, HW), gl_bytes), xoffs[u], outl[u] + hl[u]);
+      if (MIX)
+        buf_store(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)b * N * HW + (long)y * W, n, HW), gs_bytes), xoffs[u], outs[u] + hs[u]);
+    }
   }
   // Disparity gradient: wave totals into the row's LDS accumulators.  Two planes share one reduction: after
   // v_permlane32_swap the lower half-wave holds plane u's two half sums and the upper half plane u+1's, so five DPP
@@ -1036,6 +1060,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     if (!work_item(rw, it, wave, nwaves, N, G, seg, n_lo, n_hi, piece)) break;
     SegCtx sc;
     sc.seg = seg;
+    sc.seg_prev = (seg == 0) ? nseg - 1 : seg - 1;
     sc.T0 = seg * kWave;
     sc.xt = sc.T0 + lane;
     sc.lane = lane;
