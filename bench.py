@@ -42,8 +42,11 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--warp_type", default="disp_warp", choices=["disp_warp", "homography_warp"])
     ap.add_argument("--mono_pose", action="store_true",
-                    help="homography_warp only: a small random rotation + translation per image (a pose_net output, "
-                         "BASELINE configs[3]) instead of the rectified stereo baseline; every sample then has 4 live taps")
+                    help="homography_warp only: the pose of a novel frame as Trainer.predict_poses produces it without "
+                         "COLMAP (BASELINE configs[3]: pose_net): small rotation, zero translation, Rt[3,3] = 0")
+    ap.add_argument("--colmap_pose", action="store_true",
+                    help="homography_warp only: small rotation + translation per image (--use_colmap poses): a "
+                         "different homography per plane, every sample with 4 live taps")
     ap.add_argument("--no_mixture", action="store_true")
     ap.add_argument("--automask", action="store_true")
     ap.add_argument("--xz_levels", type=int, default=0,
@@ -65,6 +68,22 @@ def make_batch(args, device, seed):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in c.items()}
 
 
+def bench_pose(args, c, device):
+    """[B,4,4] pose of the target view: the rectified stereo baseline (inputs[("Rt","r")], mono_dataset.py:203-211), or
+    --mono_pose: what Trainer.predict_poses hands over for a novel frame WITHOUT COLMAP (trainer.py:386-400):
+    a small rotation conjugated by the crop matrix, ZERO translation and Rt[3,3] = 0 — the homography is then the same
+    for every plane; --colmap_pose: rotation + translation (trainer.py:397-398), a different homography per plane."""
+    B = c["logits"].shape[0]
+    if not (args.mono_pose or args.colmap_pose):
+        return c["Rt"].clone()
+    from planedepth_amd.synthetic import small_pose
+    Rt = small_pose(torch.Generator().manual_seed(77), B, stereo=False).to(device)
+    if args.mono_pose:
+        Rt[:, :3, 3] = 0.0
+        Rt[:, 3, 3] = 0.0
+    return Rt
+
+
 def build_step(args, c, device):
     """Returns step() running the product path exactly as a patched Trainer would (dict contract of trainer.py)."""
     import planedepth_amd
@@ -73,10 +92,7 @@ def build_step(args, c, device):
     logits = c["logits"].clone().requires_grad_(True)
     sigma = c["sigma"].clone().requires_grad_(True)
     disp_pp = c["disp_pp"].clone().requires_grad_(not args.no_plane_grad)  # per-plane disparities incl. the learnt residual
-    Rt = c["Rt"].clone()
-    if args.mono_pose:
-        from planedepth_amd.synthetic import small_pose
-        Rt = small_pose(torch.Generator().manual_seed(77), B, stereo=False).to(device)
+    Rt = bench_pose(args, c, device)
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
                                 render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
                                 gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
@@ -129,12 +145,23 @@ def kernel_times(args, c, device, iters):
     lib = C.load()
     B, N, H, W = c["logits"].shape
     mix = not args.no_mixture
-    if args.warp_type != "disp_warp" or args.xz_levels:
-        return None  # direct-launch timing is wired for the headline configuration only
+    if args.xz_levels:
+        return None  # direct-launch timing is wired for the xy-plane configurations only
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
-    d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, 0)
-    plane = c["disp_pp"][:, :, 0, 0].contiguous()
-    pm = None if (args.no_padding_mask or args.xz_levels == 0) else c["padding_mask"]
+    pm = None
+    aux = k3 = None
+    if args.warp_type == "disp_warp":
+        mode, sign = C.PD_WARP_DISP, 1.0
+        plane = c["disp_pp"][:, :, 0, 0].contiguous()
+    else:  # the [B*N,3,3] algebra of HomographyWarp stays in torch (ops.homography_matrices); the kernels take H_t2s
+        from planedepth_amd import ops
+        mode, sign = C.PD_WARP_HOMOGRAPHY, 0.0
+        ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+        norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
+        plane, aux = ops.homography_matrices(0.1 * 0.58 * W / c["disp_pp"][:, :, 0, 0], norm, ex(bench_pose(args, c, device)),
+                                             ex(c["K"]), ex(c["inv_K"]))
+        plane, aux, k3 = plane.contiguous(), aux.contiguous(), c["inv_K"][:, :3, :3].contiguous()
+    d = C.SweepDesc(B, N, H, W, mode, flags, sign, int(os.environ.get("PD_SWEEP_IMPL", 0)))
     k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
     rgb = torch.empty(B, 3, H, W, device=device)
     ph = torch.empty(B, 1, H, W, device=device)
@@ -148,14 +175,15 @@ def kernel_times(args, c, device, iters):
 
     def fwd():
         C.check(lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
-                                       C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(ph),
-                                       C.ptr(phm), C.ptr(stash), st), "fwd")
+                                       C.ptr(sig), C.ptr(plane), C.ptr(aux), C.ptr(k3), C.ptr(pm), None, C.ptr(rgb),
+                                       C.ptr(ph), C.ptr(phm), C.ptr(stash), st), "fwd")
 
     def bwd():
         C.check(lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(c["color_l"]), C.ptr(c["color_r"]), C.ptr(c["logits"]),
-                                       C.ptr(sig), C.ptr(plane), None, None, C.ptr(pm), None, C.ptr(rgb), C.ptr(stash),
-                                       C.ptr(c["g_rgb_rec"]), None, C.ptr(gphm), C.ptr(gl), C.ptr(gs if mix else None),
-                                       C.ptr(None if args.no_plane_grad else gp), None, C.ptr(ws), st), "bwd")
+                                       C.ptr(sig), C.ptr(plane), C.ptr(aux), C.ptr(k3), C.ptr(pm), None, C.ptr(rgb),
+                                       C.ptr(stash), C.ptr(c["g_rgb_rec"]), None, C.ptr(gphm), C.ptr(gl),
+                                       C.ptr(gs if mix else None), C.ptr(None if args.no_plane_grad else gp), None,
+                                       C.ptr(ws), st), "bwd")
 
     out = {}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):
@@ -297,14 +325,43 @@ def cpu_baseline(args, budget_s):
             "ms_per_image": round(med * 1e3, 2)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU over RCCL
+    (what the reference's `torchrun --nproc_per_node=K train.py` does, train_ResNet.sh:1 / trainer.py:50-55).  On a box
+    with fewer than N devices the ranks only start with PD_BENCH_SHARE_GPU=1 (functional check: all ranks on cuda:0,
+    gloo for the timing collectives since RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < args.gpus:
+        if not env.get("PD_BENCH_SHARE_GPU"):
+            raise SystemExit("bench.py --gpus %d: only %d device(s) visible (set PD_BENCH_SHARE_GPU=1 to run all ranks "
+                             "on cuda:0 as a functional check)" % (args.gpus, ndev))
+        env.setdefault("PD_BENCH_BACKEND", "gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] spawning %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
     from planedepth_amd import parallel
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     # RCCL ("nccl"); used for the timing barrier / max reduction only.  PD_BENCH_BACKEND=gloo + PD_BENCH_SHARE_GPU=1 is
     # a functional check of the multi-process flow on a one-GPU box (all ranks on cuda:0).
     rank, world, local_rank = parallel.init_process_group_from_env(os.environ.get("PD_BENCH_BACKEND", "nccl"))
+    if world != args.gpus:
+        print("[bench] note: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d"
+              % (args.gpus, world, world), file=sys.stderr, flush=True)
     device = torch.device("cuda", 0 if os.environ.get("PD_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
     import __graft_entry__ as entry
@@ -329,14 +386,19 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %s, %s, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
-                               % (args.warp_type, "mono pose (random small rotation + translation)" if args.mono_pose
-                                  else "stereo target r", "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
+                               % (args.warp_type, "mono pose (pose_net: rotation only, F8)" if args.mono_pose
+                                  else ("colmap pose (rotation + translation)" if args.colmap_pose else "stereo target r"), "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
                                   args.height, args.width, args.planes + args.xz_levels),
                    "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
                    "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
                    "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
                    if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask"},
     }
+    if world > 1:
+        import torch.distributed as dist
+        result["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "devices": "shared cuda:0 (PD_BENCH_SHARE_GPU)" if os.environ.get("PD_BENCH_SHARE_GPU")
+                          else "one per rank"}
     if rank == 0:
         kt = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))
         if kt:

@@ -62,6 +62,15 @@ enum pd_sweep_impl {
   PD_IMPL_FAST_ROWS = 2  /* as AUTO, but a second source row whose bilinear weight is below 2^-16 (fp32 noise of the
                             reference's y round trip, <= 6e-6) is dropped: ~11% faster, results within 1e-4 of the
                             tensors' range on random inputs instead of 1e-6 (opt-in) */
+  ,
+  PD_IMPL_TILE = 3       /* as GENERAL, and homography_warp's backward runs the owned-tile kernel (pd_plane_sweep_tile.hip:
+                            LDS accumulators per source tile, plain stores, no zero-fill) instead of the atomic scatter.
+                            Exact and atomic-free in HBM, but 2-2.5x SLOWER on gfx950 (ds_add_f32 costs ~110 cycles per
+                            wave instruction: DESIGN.md 3.4.6) - kept as an in-suite cross-check and as the record of
+                            that measurement */
+  ,
+  PD_IMPL_ROWS1 = 4      /* as AUTO, but the row kernels with ONE pixel per lane (pd_plane_sweep_rowshift.hip, the round-1
+                            headline kernels) instead of the four-pixels-per-lane ones: cross-check and A/B runs */
 };
 
 typedef struct pd_sweep_desc {

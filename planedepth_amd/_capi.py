@@ -16,7 +16,7 @@ PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_RO
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
-PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS = 0, 1, 2
+PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1 = 0, 1, 2, 3, 4
 
 
 class SweepDesc(ctypes.Structure):

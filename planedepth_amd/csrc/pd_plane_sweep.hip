@@ -16,78 +16,9 @@
 #include <stdlib.h>
 
 #include "pd_sweep.h"
+#include "pd_sweep_geom.h"
 
 namespace pd {
-
-// ---------------------------------------------------------------------------------------------------------------
-// Sampling position of target pixel (x,y) on plane n of image b, plus the padding mask.
-// DISP:        trainer.py:540-554   (x + sign*d, y) normalised by (W-1, H-1)
-// HOMOGRAPHY:  layers.py:221-233    p = H_t2s [x,y,1]; mask = ((K^-1 p_t).(R n) > 0) & (z > 1e-7); z<1e-7 -> 1e-7
-// ---------------------------------------------------------------------------------------------------------------
-struct PlaneGeom {   // per (pixel, plane) state needed again for the grid gradient
-  float ix, iy;
-  float p0, p1, zc;  // homography only
-  bool z_clamped;
-};
-
-// Sizes the coordinates are normalised by, with their refined reciprocals (uniform; computed once per thread).
-struct CoordNorm {
-  float Wm1, Hm1, rcpW, rcpH;
-  bool fast;  // sizes >= 2: the reciprocal form is exact (a size of 1 divides by zero; keep IEEE semantics there)
-};
-__device__ __forceinline__ CoordNorm make_coord_norm(int W, int H) {
-  CoordNorm c;
-  c.Wm1 = (float)(W - 1); c.Hm1 = (float)(H - 1);
-  c.fast = (W >= 2) && (H >= 2);
-  c.rcpW = c.fast ? refined_rcp(c.Wm1) : 0.0f;
-  c.rcpH = c.fast ? refined_rcp(c.Hm1) : 0.0f;
-  return c;
-}
-
-template <int MODE>
-__device__ __forceinline__ PlaneGeom plane_coords(const SweepArgs& a, const CoordNorm& cn, int b, int n, int x, int y,
-                                                  float iy_disp, bool& mask) {
-  PlaneGeom g;
-  if (MODE == PD_WARP_DISP) {
-    float d;
-    if (a.flags & PD_DISP_DENSE)
-      d = a.plane[(((long)b * a.N + n) * a.H + y) * a.W + x];
-    else
-      d = a.plane[b * a.N + n];
-    g.ix = normalise_roundtrip((float)x + a.sign * d, (float)(a.W - 1));
-    g.iy = iy_disp;
-    g.p0 = g.p1 = g.zc = 0.0f;
-    g.z_clamped = false;
-    mask = true;  // caller applies the padding_mask tensor
-  } else {
-    const float* Hm = a.plane + ((long)b * a.N + n) * 9;
-    const float* Rn = a.plane_aux + ((long)b * a.N + n) * 3;
-    const float* Ki = a.inv_K3 + (long)b * 9;
-    const float fx = (float)x, fy = (float)y;
-    g.p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
-    g.p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
-    const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
-    const float r0 = Ki[0] * fx + Ki[1] * fy + Ki[2];
-    const float r1 = Ki[3] * fx + Ki[4] * fy + Ki[5];
-    const float r2 = Ki[6] * fx + Ki[7] * fy + Ki[8];
-    const float facing = r0 * Rn[0] + r1 * Rn[1] + r2 * Rn[2];
-    mask = (facing > 0.0f) && (z > kZMin);
-    g.z_clamped = (z < kZMin);
-    g.zc = g.z_clamped ? kZMin : z;
-    if (cn.fast) {  // uniform
-      g.ix = normalise_roundtrip_rcp(g.p0 / g.zc, cn.Wm1, cn.rcpW);
-      g.iy = normalise_roundtrip_rcp(g.p1 / g.zc, cn.Hm1, cn.rcpH);
-    } else {
-      g.ix = normalise_roundtrip(g.p0 / g.zc, cn.Wm1);
-      g.iy = normalise_roundtrip(g.p1 / g.zc, cn.Hm1);
-    }
-  }
-  return g;
-}
-
-__device__ __forceinline__ bool read_mask(const SweepArgs& a, int b, int n, int x, int y) {
-  return a.padding_mask[(((long)b * a.N + n) * a.H + y) * a.W + x] != 0.0f;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
@@ -330,6 +261,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, float
   if (threadIdx.x == 0) out[(long)b * M + j] = acc;
 }
 
+int reduce_partials(const float* partials, float* out, int nblk, int M, int B, hipStream_t stream) {
+  reduce_partials_kernel<<<dim3(M, B), kWave, 0, stream>>>(partials, out, nblk, M);
+  return check_launch("reduce_partials_kernel");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Per-plane tensors of trainer.py:582-602 (forward values only)
 // ---------------------------------------------------------------------------------------------------------------
@@ -491,10 +427,12 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   return a;
 }
 
-int pd_sweep_uses_rowshift(const pd_sweep_desc* d);
+static bool wants_rowshift(const pd_sweep_desc* d) {
+  return d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_ROWS1;
+}
 
 extern "C" int pd_sweep_uses_rowshift(const pd_sweep_desc* d) {
-  return (d && d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) ? 1 : 0;
+  return (d && wants_rowshift(d) && rowshift_applicable(d)) ? 1 : 0;
 }
 
 extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
@@ -511,7 +449,9 @@ extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   const size_t K = (d->mode == PD_WARP_DISP) ? 1 : 9;
   const size_t general = (size_t)d->B * bwd_blocks(d->H * d->W) * d->N * K;
   const size_t rows = rowshift_applicable(d) ? rowshift_bwd_workspace_floats(d) : 0;
-  return general > rows ? general : rows;
+  const size_t tiles = tile_bwd_applicable(d) ? tile_bwd_workspace_floats(d) : 0;
+  const size_t m = general > rows ? general : rows;
+  return m > tiles ? m : tiles;
 }
 
 #define PD_DISPATCH(KERNEL, mode, mix, grid, block, shmem, stream, ...)                                   \
@@ -539,8 +479,10 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
     a.ph_mean = ph_mean;
     if (hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
   }
-  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d))
+  if (wants_rowshift(d) && rowshift_applicable(d)) {
+    if (rowquad_applicable(d, a.has_mask != 0)) return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
+  }
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
   PD_DISPATCH(sweep_fwd_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,
               rgb_rec, ph_map, stash);
@@ -559,6 +501,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   const bool dense = (d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)) != 0;
   PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
+  PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_ROWS1, "unknown impl %d", d->impl);
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
@@ -567,9 +510,16 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   o.side = nullptr;
   o.g_dists = (d->flags & PD_RENDER_PROB) ? g_dists : nullptr;
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
-  if (d->impl != PD_IMPL_GENERAL && rowshift_applicable(d)) {
+  if (wants_rowshift(d) && rowshift_applicable(d)) {
     PD_REQUIRE(workspace, "the row-shift backward needs workspace (pd_sweep_bwd_workspace_floats)");
+    // the wide-access backward is correct (tests/test_gpu_parity.py::test_rowquad_*) but not yet faster than the
+    // one-pixel-per-lane one: opt-in
+    if (rowquad_applicable(d, ak.has_mask != 0) && getenv("PD_QUAD_BWD")) return rowquad_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
+  }
+  if (tile_bwd_applicable(d)) {   // PD_IMPL_TILE: source tiles owned by workgroups, no atomics, no zero-fill
+    PD_REQUIRE(workspace, "the tile backward needs workspace (pd_sweep_bwd_workspace_floats)");
+    return tile_bwd(d, ak, o, workspace, stream);
   }
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;

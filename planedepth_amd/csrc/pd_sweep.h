@@ -257,4 +257,18 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d);
 
+// Four-pixels-per-lane row kernels (pd_plane_sweep_rowquad.hip): same contract as the row-shift ones, wide memory accesses.
+bool rowquad_applicable(const pd_sweep_desc* d, bool dense_mask);
+int rowquad_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
+                hipStream_t stream);
+int rowquad_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
+size_t rowquad_bwd_workspace_floats(const pd_sweep_desc* d);
+
+// Scatter-free general backward (pd_plane_sweep_tile.hip): homography mode, source tiles owned by workgroups.
+bool tile_bwd_applicable(const pd_sweep_desc* d);
+size_t tile_bwd_workspace_floats(const pd_sweep_desc* d);
+int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+// partials [B][nblk][M] -> out [B][M], fixed summation order (pd_plane_sweep.hip)
+int reduce_partials(const float* partials, float* out, int nblk, int M, int B, hipStream_t stream);
+
 }  // namespace pd

@@ -180,13 +180,10 @@ def generate_post_process_disp(self, inputs):
     exactly as the reference does (:405-419 — the networks are the reference's own, untouched), then the occlusion-aware
     blend of the two predictions through the fused warp kernels instead of five grid_samples."""
     opt = self.opt
-    input_images = torch.cat([inputs[("color_aug", "l")], inputs[("color_aug", "l")].flip(-1)], dim=0)
-    input_grids = None
-    if opt.num_ep > 0:
-        grid_fliped = inputs["grid"].clone()
-        grid_fliped[:, 0, :, :] *= -1.
-        grid_fliped = grid_fliped.flip(-1)
-        input_grids = torch.cat([inputs["grid"], grid_fliped], dim=0)
+    image = inputs[("color_aug", "l")]
+    input_images = ops.cat_flip(image, image)                                  # [image ; mirrored image]
+    # the mirrored crop sees the scene with x negated (trainer.py:406-419): the batch-doubling kernel does both at once
+    input_grids = ops.cat_flip(inputs["grid"], inputs["grid"], negate_c0=True) if opt.num_ep > 0 else None
     if opt.net_type == "ResNet":
         features = self.fixed_models["encoder"](input_images)
         outputs = self.fixed_models["depth"](features, input_grids)
@@ -222,6 +219,13 @@ def pred_self_images(self, inputs, outputs):
 def add_flip_right_inputs(self, inputs):
     """Batch doubling with the mirrored other view (reference trainer.py:252-276): the same dict, one kernel per image
     tensor instead of a flip copy plus a cat copy.  Inputs are data: no gradients."""
+    # The reference calls this on the DataLoader's CPU batch, BEFORE process_batch moves it to the device
+    # (trainer.py:294-295 vs 328-329): take the tensors to the trainer's device first (a no-op when they already are
+    # there; process_batch's own .to(device) then is one as well).
+    dev = getattr(self, "device", None)
+    if dev is None:
+        dev = next((v.device for v in inputs.values() if torch.is_tensor(v) and v.is_cuda), torch.device("cuda"))
+    inputs = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in inputs.items()}
     new_inputs = {}
     for key in ("color", "color_aug", "depth_gt"):
         if (key, "l") in inputs and (key, "r") in inputs:
@@ -230,7 +234,7 @@ def add_flip_right_inputs(self, inputs):
     new_inputs["grid"] = ops.cat_flip(inputs["grid"], inputs["grid"], negate_c0=True)   # :258-261
     for key in ("K", "inv_K", ("Rt", "l"), ("Rt", "r")):
         new_inputs[key] = inputs[key].repeat(2, 1, 1)
-    # the left +1/-1 frame becomes the right side, but it should not affect the training (reference comment, :271)
+    # frames -1 / +1 are doubled with their own mirror image (:271-274)
     for f in self.opt.novel_frame_ids:
         for key in ("color", "color_aug"):
             new_inputs[(key, f)] = ops.cat_flip(inputs[(key, f)], inputs[(key, f)])

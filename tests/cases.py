@@ -60,3 +60,60 @@ def rel_err(a, b):
     """max |a-b| / max(|b|, tiny): the normalised max error used for every fp32 parity check."""
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] as the trainer runs it: all target sides, decoder-made xz planes (tests/golden/trainer_mono.npz)
+# ---------------------------------------------------------------------------------------------------------------------
+TRAINER_MONO = ["homo3", "homo_nostereo_l1", "disp_xz"]
+
+
+def load_trainer_fixture(tag):
+    z = np.load(os.path.join(GOLDEN, "trainer_mono.npz"))
+    meta = json.loads(bytes(z[tag + "/meta"]).decode())
+    t = {k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/") and not k.endswith("/meta")}
+    return t, meta
+
+
+def side_key(s):
+    return s if isinstance(s, str) else int(s)
+
+
+def run_oracle_trainer(z, meta, dtype=torch.float32):
+    """pred_novel_images + compute_losses over every target side, restated with the oracle's building blocks
+    (trainer.py:532, 717, 765-771: the loss dict is divided by len(target_sides) BEFORE the smoothness term)."""
+    c = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in z.items()}
+    sides = [side_key(s) for s in meta["target_sides"]]
+    mix, homo = meta["use_mixture_loss"], meta["warp_type"] == "homography_warp"
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    logits = leaf(c["logits"])
+    sigma = leaf(c["sigma"]) if mix else None
+    distance, disp_layered = leaf(c["distance"]), leaf(c["disp_layered"])
+    Rts = {s: leaf(c["Rt_%s" % s]) for s in sides}
+    B, N, H, W = logits.shape
+    res, total, ph_total = {}, 0.0, 0.0
+    for s in sides:
+        r = orc.warp_and_loss(c["color_l"], c["color_%s" % s], logits, sigma,
+                              warp_type=meta["warp_type"], target_side=s, disp_layered=disp_layered,
+                              padding_mask=c["padding_mask"], distance=distance, norm=c["norm"], T=Rts[s], K=c["K"],
+                              inv_K=c["inv_K"], use_mixture_loss=mix, automask=meta["automask"])
+        res["rgb_rec_%s" % s] = r["rgb_rec"]
+        ph_total = ph_total + r["ph_loss"]
+        total = total + r["ph_loss"] + (r["rgb_rec"] * c["gw_%s" % s]).sum() * len(sides)  # the test objective adds it undivided
+    ph_loss = ph_total / len(sides)
+    x0 = int(0.2 * W)
+    smooth = orc.smooth_loss_disp(c["disp"][..., x0:], c["color_l"][..., x0:], 2.0)
+    total_loss = ph_loss + 0.04 * smooth
+    obj = total / len(sides) + 0.04 * smooth
+    obj.backward()
+    zz = torch.zeros_like
+    res.update(ph_loss=ph_loss, total_loss=total_loss, smooth_loss=smooth, g_logits=logits.grad)
+    if mix:
+        res["g_sigma"] = sigma.grad
+    if homo:
+        res["g_distance"] = distance.grad if distance.grad is not None else zz(distance)
+    else:
+        res["g_disp_layered"] = disp_layered.grad
+    for s in sides:
+        res["g_Rt_%s" % s] = Rts[s].grad if Rts[s].grad is not None else zz(Rts[s])
+    return {k: v.detach() for k, v in res.items()}

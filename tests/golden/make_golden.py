@@ -227,6 +227,110 @@ def post_process_vectors(ref):
     return out
 
 
+def trainer_mono_vectors(ref):
+    """BASELINE configs[3] as the trainer runs it (trainer.py:325-356): the reference DepthDecoder WITH xz planes
+    (non-frontal normals, horizon mask, per-plane distances: networks/depth_decoder.py:158-207) -> Trainer.predict_poses
+    (:358-402, pose nets replaced by a stub that returns seeded axis-angles: F8 zero translation, Rt[3,3] = 0) ->
+    Trainer.pred_novel_images over ALL target sides -> Trainer.compute_losses (incl. `losses /= len(target_sides)` before
+    the smoothness term, :765-771).  Stored: the decoder outputs / poses the hot path consumes, every rgb_rec, the loss
+    dict and the gradients w.r.t. logits, sigma, distance / disp_layered and every Rt."""
+    import types
+    from planedepth_amd.synthetic import crop_grid, dataset_intrinsics
+    out = {}
+    H, W, B = 64, 64, 2
+    configs = (
+        ("homo3", dict(warp_type="homography_warp", target_sides=["r", -1, 1], automask=True, use_mixture_loss=True)),
+        ("homo_nostereo_l1", dict(warp_type="homography_warp", target_sides=[-1, 1], automask=True, use_mixture_loss=False)),
+        ("disp_xz", dict(warp_type="disp_warp", target_sides=["r"], automask=False, use_mixture_loss=True)),
+    )
+    for ci, (tag, cfg) in enumerate(configs):
+        g = torch.Generator().manual_seed(5150 + ci)
+        mix = cfg["use_mixture_loss"]
+        no_levels, xz_levels = 4, 3
+        N = no_levels + xz_levels
+        torch.manual_seed(23 + ci)
+        dec = ref.networks.DepthDecoder([64, 64, 128, 256, 512], use_denseaspp=False, no_levels=no_levels,
+                                        xz_levels=xz_levels, disp_min=0.5, disp_max=0.3 * W, use_mixture_loss=mix,
+                                        plane_residual=True)
+        feats = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), generator=g) * 0.5
+                 for i, c in enumerate([64, 64, 128, 256, 512])]
+        raw_logits = (torch.randn(B, N, H, W, generator=g) * 2).requires_grad_(True)
+        raw_sigma = (torch.randn(B, N, H, W, generator=g) * 2.0 - 0.5).requires_grad_(True)
+        dec.convs["dispconv"].register_forward_hook(lambda m, i, o, t=raw_logits: t)
+        if mix:
+            dec.convs["sigmaconv"].register_forward_hook(lambda m, i, o, t=raw_sigma: t)
+        # two different random crops of a resized KITTI-like frame: the principal point is off-centre, so the xz planes'
+        # normal [0, 1, py_cy_fys] / |.| is not frontal and the horizon row differs per sample
+        grid = torch.stack([crop_grid(H, W, 96, 150, 20, 50), crop_grid(H, W, 110, 170, 6, 90)], 0)
+        o = dec(feats, grid)
+        outputs = dict(o)
+        for k in ("logits", "sigma", "distance", "disp_layered"):
+            if k in outputs and outputs[k].requires_grad:
+                outputs[k].retain_grad()
+        outputs["disp"] = o["disp"].detach()   # the smoothness term's path into the decoder tail is not part of this fixture
+        K, inv_K = dataset_intrinsics(B, H, W)
+        Rt_r = torch.eye(4)[None].repeat(B, 1, 1)
+        Rt_r[:, 0, 3] = -0.1
+        Rt_r.requires_grad_(True)
+        inputs = {"grid": grid, "K": K, "inv_K": inv_K, ("Rt", "r"): Rt_r}
+        for s in ("l", "r", -1, 1):
+            inputs[("color", s)] = torch.rand(B, 3, H, W, generator=g)
+            inputs[("color_aug", s)] = inputs[("color", s)]
+        novel = [s for s in cfg["target_sides"] if s != "r"]
+        ns = make_trainer_namespace(ref, H, W, warp_type=cfg["warp_type"], use_mixture_loss=mix, automask=cfg["automask"],
+                                    target_sides=cfg["target_sides"], novel_frame_ids=novel, use_colmap=False)
+        pose_leafs = {}
+
+        class PoseStub:
+            def __init__(self):
+                self.calls = 0
+
+            def __call__(self, feats_, grid_):
+                f = novel[self.calls]
+                self.calls += 1
+                aa = (torch.randn(B, 1, 1, 3, generator=g) * 0.02).requires_grad_(True)
+                tr = (torch.randn(B, 1, 1, 3, generator=g) * 0.05).requires_grad_(True)
+                pose_leafs[f] = (aa, tr)
+                return aa, tr
+
+        ns.models = {"pose_encoder": lambda x: x, "pose": PoseStub()}
+        Trainer = ref.trainer.Trainer
+        outputs.update(Trainer.predict_poses(ns, inputs))
+        for f in novel:
+            outputs[("Rt", f)].retain_grad()
+        Trainer.pred_novel_images(ns, inputs, outputs)
+        losses = Trainer.compute_losses(ns, inputs, outputs)
+        gw = {s: torch.randn(B, 3, H, W, generator=g) * 1e-3 for s in cfg["target_sides"]}
+        obj = losses["loss/total_loss"] + sum((outputs[("rgb_rec", s)] * gw[s]).sum() for s in cfg["target_sides"])
+        obj.backward()
+        blob = dict(grid=grid, K=K, inv_K=inv_K, logits=outputs["logits"], disp_layered=outputs["disp_layered"],
+                    padding_mask=outputs["padding_mask"].float(), distance=outputs["distance"], norm=outputs["norm"],
+                    disp=outputs["disp"], ph_loss=losses["loss/ph_loss"], total_loss=losses["loss/total_loss"],
+                    smooth_loss=losses["loss/smooth_loss"], g_logits=outputs["logits"].grad)
+        if mix:
+            blob.update(sigma=outputs["sigma"], g_sigma=outputs["sigma"].grad)
+        if cfg["warp_type"] == "homography_warp":
+            blob.update(g_distance=outputs["distance"].grad)
+        else:
+            blob.update(g_disp_layered=outputs["disp_layered"].grad)
+        for s in ("l", "r", -1, 1):
+            blob["color_%s" % s] = inputs[("color", s)]
+        for s in cfg["target_sides"]:
+            Rt = outputs[("Rt", s)]
+            blob["Rt_%s" % s] = Rt
+            gR = Rt.grad if Rt.grad is not None else torch.zeros_like(Rt)
+            blob["g_Rt_%s" % s] = gR
+            blob["gw_%s" % s] = gw[s]
+            blob["rgb_rec_%s" % s] = outputs[("rgb_rec", s)]
+        out.update({"%s/%s" % (tag, k): v.detach().numpy() for k, v in blob.items()})
+        out["%s/meta" % tag] = np.frombuffer(json.dumps(dict(cfg, no_levels=no_levels, xz_levels=xz_levels)).encode(),
+                                             dtype=np.uint8)
+        print("trainer_mono %-18s ph=%.8f total=%.8f masked=%.3f norm_xz=%s" % (
+            tag, float(losses["loss/ph_loss"]), float(losses["loss/total_loss"]),
+            float(1 - outputs["padding_mask"].float().mean()), outputs["norm"][0, -1].tolist()))
+    return out
+
+
 def scalars(res):
     f = lambda t: float(t.double().sum())  # noqa: E731
     a = lambda t: float(t.double().abs().sum())  # noqa: E731
@@ -238,6 +342,9 @@ def scalars(res):
 def main():
     ref = load_reference()
     torch.manual_seed(0)
+    if "--only-trainer-mono" in sys.argv:   # add the configs[3] fixtures without touching the others
+        np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
+        return
     for name, bkw, rkw in SMALL_CASES:
         case = build_case(**bkw)
         res = run_reference(ref, case, **rkw)
@@ -249,6 +356,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "decoder_tail.npz"), **decoder_tail_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "post_process.npz"), **post_process_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
     kat = {}
     for name, _, rkw in FULL_CASES:
         case = survey_fullsize_case()

@@ -57,3 +57,69 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
         if (k, side) in outputs:
             res[k] = outputs[(k, side)]
     return {k: v.detach().cpu() for k, v in res.items()}
+
+
+def make_stub_trainer(opt, target_sides, device="cuda"):
+    """A reference-shaped Trainer class with nothing but what the hot path reads, adopted through ``patch_trainer``
+    exactly as INTEGRATION.md tells a maintainer to do with the real one."""
+    class StubTrainer:
+        def __init__(self):
+            self.opt = opt
+            self.target_sides = target_sides
+            self.device = torch.device(device)
+
+        def perceptual_loss(self, *a, **k):
+            return torch.zeros((), device=device)
+
+    planedepth_amd.patch_trainer(StubTrainer)
+    return StubTrainer()
+
+
+def run_product_trainer(z, meta, device="cuda", impl=None):
+    """tests/golden/trainer_mono.npz through the patched Trainer methods (pred_novel_images + compute_losses over every
+    target side).  Same keys as cases.run_oracle_trainer."""
+    from cases import side_key
+    c = {k: v.to(device) for k, v in z.items()}
+    sides = [side_key(s) for s in meta["target_sides"]]
+    mix, homo = meta["use_mixture_loss"], meta["warp_type"] == "homography_warp"
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    logits = leaf(c["logits"])
+    sigma = leaf(c["sigma"]) if mix else None
+    distance, disp_layered = leaf(c["distance"]), leaf(c["disp_layered"])
+    B, N, H, W = logits.shape
+    inputs = {("color", "l"): c["color_l"], "K": c["K"], "inv_K": c["inv_K"], "grid": c["grid"]}
+    outputs = {"probability": torch.empty(B, N, H, W, device="meta"), "logits": logits, "disp_layered": disp_layered,
+               "padding_mask": c["padding_mask"], "distance": distance, "norm": c["norm"], "disp": c["disp"]}
+    if mix:
+        outputs["sigma"] = sigma
+    Rts = {}
+    for s in sides:
+        inputs[("color", s)] = c["color_%s" % s]
+        Rts[s] = outputs[("Rt", s)] = leaf(c["Rt_%s" % s])
+    opt = types.SimpleNamespace(warp_type=meta["warp_type"], match_aug=False, use_mixture_loss=mix,
+                                automask=meta["automask"], render_probability=False, alpha_pc=0.0, alpha_self=0.0,
+                                self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=True,
+                                xz_levels=meta["xz_levels"], yz_levels=0, novel_frame_ids=[s for s in sides if s != "r"])
+    trainer = make_stub_trainer(opt, sides, device)
+    if impl is not None:
+        ops.SWEEP_IMPL = impl
+    try:
+        trainer.pred_novel_images(inputs, outputs)
+        losses = trainer.compute_losses(inputs, outputs)
+        obj = losses["loss/total_loss"] + sum((outputs[("rgb_rec", s)] * c["gw_%s" % s]).sum() for s in sides)
+        obj.backward()
+    finally:
+        ops.SWEEP_IMPL = 0
+    zz = torch.zeros_like
+    res = {"rgb_rec_%s" % s: outputs[("rgb_rec", s)] for s in sides}
+    res.update(ph_loss=losses["loss/ph_loss"], total_loss=losses["loss/total_loss"],
+               smooth_loss=losses["loss/smooth_loss"], g_logits=logits.grad)
+    if mix:
+        res["g_sigma"] = sigma.grad
+    if homo:
+        res["g_distance"] = distance.grad if distance.grad is not None else zz(distance)
+    else:
+        res["g_disp_layered"] = disp_layered.grad
+    for s in sides:
+        res["g_Rt_%s" % s] = Rts[s].grad if Rts[s].grad is not None else zz(Rts[s])
+    return {k: v.detach().cpu() for k, v in res.items()}

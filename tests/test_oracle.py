@@ -136,3 +136,18 @@ def test_post_process_against_reference_vectors(tag):
     disp_pp, mask_novel = orc.post_process_disp(z["logits"], z["probability"], z["disp"], z["disp_layered"])
     assert rel_err(disp_pp, z["disp_pp"]) < TOL
     assert rel_err(mask_novel, z["mask_novel"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["homo3", "homo_nostereo_l1", "disp_xz"])
+def test_trainer_mono_fixture(tag):
+    """BASELINE configs[3] as the trainer runs it (all target sides, decoder-made xz planes with non-frontal normals,
+    predict_poses-shaped Rt): the oracle against what the reference's Trainer produced (tests/golden/trainer_mono.npz)."""
+    from cases import load_trainer_fixture, run_oracle_trainer
+    z, meta = load_trainer_fixture(tag)
+    got = run_oracle_trainer(z, meta)
+    for k, v in got.items():
+        w = z[k]
+        if float(w.abs().max()) == 0.0:
+            assert float(v.abs().max()) == 0.0, k
+        else:
+            assert rel_err(v, w) < TOL, (tag, k, rel_err(v, w))
