@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no_plane_grad", action="store_true", help="diagnostics: disparities do not require grad")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_next_rows", action="store_true", help="skip the timings of the SURVEY 8f operators")
+    ap.add_argument("--no_ddp_step", action="store_true", help="skip the end-to-end DDP training-step block")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -110,11 +111,19 @@ def build_step(args, c, device):
     else:
         pm_arg = pm
 
+    dense_disp = None
+    if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182): that is
+        # decoder work, so it is built ONCE here and handed to the path as the decoder would hand it over (a dense
+        # tensor that wants a gradient), not re-materialised inside the timed step
+        dense_disp = (disp_pp.detach().expand(-1, -1, H, W) * c["row_gain"]).contiguous().requires_grad_(not args.no_plane_grad)
+
     def step():
         logits.grad = sigma.grad = disp_pp.grad = None
-        disp_layered = disp_pp.expand(-1, -1, H, W)
-        if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182)
-            disp_layered = disp_layered * c["row_gain"]
+        if dense_disp is not None:
+            dense_disp.grad = None
+            disp_layered = dense_disp
+        else:
+            disp_layered = disp_pp.expand(-1, -1, H, W)
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
                    "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm, ("Rt", "r"): Rt}
         if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
@@ -199,6 +208,24 @@ def kernel_times(args, c, device, iters):
     return out
 
 
+def in_step_kernel_times(step, device, iters):
+    """Average duration of the sweep's forward / backward launches INSIDE the training step (CUDA events recorded on the
+    launch stream around the C-ABI calls, planedepth_amd.ops.KERNEL_EVENTS): what the kernels take with the caches in
+    the state the step leaves them in, as opposed to an isolated launch loop."""
+    from planedepth_amd import ops
+    ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+    try:
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize(device)
+        ev = ops.KERNEL_EVENTS
+    finally:
+        ops.KERNEL_EVENTS = None
+    if not ev["fwd"] or not ev["bwd"]:
+        return None
+    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+
+
 def next_rows_times(args, device, iters=10):
     """SURVEY.md §8f rows (decoder tail, smoothness loss, post-process) at the headline shape: average ms per call from
     CUDA events around the public operators (the launches are on torch's current stream), with the algorithmic bytes
@@ -275,9 +302,142 @@ def next_rows_times(args, device, iters=10):
     }
 
 
+def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
+    """End-to-end training step with the reference's structure (trainer.py:278-323) on synthetic KITTI-like inputs made
+    ON the device: add_flip_right_inputs (B/2 -> B) -> a stand-in conv encoder/decoder wrapped in
+    DistributedDataParallel (stock DDP over RCCL; torchvision is not in the image, so the ResNet is replaced by a small
+    conv U-net that emits the decoder's conv outputs) -> fused decoder tail -> pred_novel_images -> compute_losses ->
+    backward (DDP all-reduces the network gradients while the autograd engine is still in the sweep's backward) -> Adam.
+    Reported next to the headline number; `value` stays the hot path alone."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    import planedepth_amd
+    from planedepth_amd import ops
+    from planedepth_amd.decoder_tail import fused_decoder_tail
+    from planedepth_amd.synthetic import kitti_like_inputs_on_device
+    N, H, W, B = args.planes, args.height, args.width, args.batch
+    if B % 2:
+        return {"skipped": "--flip_right doubling needs an even per-GPU batch"}
+
+    class StandInDepthNet(nn.Module):   # out of scope of the hot path: just something with parameters and convolutions
+        def __init__(self, n_planes, ch=24):
+            super().__init__()
+            act = nn.ELU(inplace=True)
+            self.down = nn.ModuleList([nn.Sequential(nn.Conv2d(ci, co, 3, 2, 1), act) for ci, co in
+                                       ((3, ch), (ch, 2 * ch), (2 * ch, 4 * ch), (4 * ch, 8 * ch))])
+            self.up = nn.ModuleList([nn.Sequential(nn.Conv2d(ci, co, 3, 1, 1), act) for ci, co in
+                                     ((8 * ch, 4 * ch), (4 * ch, 2 * ch), (2 * ch, ch), (ch, 16))])
+            self.dispconv = nn.Conv2d(16, n_planes, 3, 1, 1)
+            self.sigmaconv = nn.Conv2d(16, n_planes, 3, 1, 1)
+            self.residualconv = nn.Conv2d(16, n_planes, 1)
+
+        def forward(self, x):
+            x = (x - 0.45) / 0.225
+            for m in self.down:
+                x = m(x)
+            for m in self.up:
+                x = m(nn.functional.interpolate(x, scale_factor=2, mode="nearest"))
+            res = torch.sigmoid(self.residualconv(x).mean((2, 3), keepdim=True)) - 0.5      # depth_decoder.py:151
+            return self.dispconv(x), self.sigmaconv(x), res
+
+    torch.manual_seed(100 + rank)
+    model = StandInDepthNet(N).to(device)
+    own_group = False
+    if not dist.is_initialized():          # single GPU: a one-rank group, so that the step really runs under DDP
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(os.environ.get("PD_BENCH_BACKEND", "nccl"), rank=0, world_size=1,
+                                init_method="tcp://127.0.0.1:%d" % port)
+        own_group = True
+    ddp = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True)  # trainer.py:99
+    optim = torch.optim.Adam(ddp.parameters(), 1e-4, betas=(0.5, 0.999))                                       # :102
+    n_params = sum(p.numel() for p in model.parameters())
+    opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=False, xz_levels=0, yz_levels=0,
+                                novel_frame_ids=[], flip_right=True)
+    zero = torch.zeros((), device=device)
+
+    class Stub:
+        pass
+    planedepth_amd.patch_trainer(Stub)
+    trainer = Stub()
+    trainer.opt, trainer.target_sides, trainer.device = opt, ["r"], device
+    trainer.perceptual_loss = lambda *a, **k: zero
+    base = kitti_like_inputs_on_device(B // 2, H, W, seed=1000 + rank, device=device)
+    levels0 = torch.arange(N, device=device, dtype=torch.float32)[None, :, None, None]
+
+    def step(sync=True):
+        inputs = trainer.add_flip_right_inputs(base)                                    # trainer.py:294-295
+        ctx = ddp if sync else ddp.module
+        raw_l, raw_s, res = ctx(inputs[("color_aug", "l")])
+        disp_layered = (300.0 * (2.0 / 300.0) ** ((levels0 + res) / (N - 1))).expand(-1, -1, H, W)   # depth_decoder.py:148-156
+        outputs = {"disp_layered": disp_layered, "padding_mask": None}
+        fused_decoder_tail(outputs, raw_l, raw_s, use_mixture_loss=True, all_ones_mask=True)
+        trainer.pred_novel_images(inputs, outputs)                                      # :342
+        losses = trainer.compute_losses(inputs, outputs)                                # :354
+        optim.zero_grad(set_to_none=True)                                               # :299
+        losses["loss/total_loss"].backward()                                            # :300
+        optim.step()                                                                    # :301
+        return losses["loss/total_loss"]
+
+    def timed(fn, n):
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / n
+
+    for _ in range(warmup):
+        step()
+    t_step = timed(step, steps)
+    t_nosync = timed(lambda: step(False), steps)      # the same step without DDP's hooks: what the all-reduce adds
+    ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+    try:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(device)
+        hot = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ops.KERNEL_EVENTS.items()}
+    finally:
+        ops.KERNEL_EVENTS = None
+    flat = torch.empty(n_params, device=device)
+    t_allreduce = timed(lambda: dist.all_reduce(flat), 5) if world > 1 else 0.0
+    if world > 1:
+        t_step = parallel_max(t_step, device)
+    block = {"images_per_sec": round(B * world / t_step, 1), "ms_per_step": round(t_step * 1e3, 3),
+             "ms_per_step_without_gradient_sync": round(t_nosync * 1e3, 3),
+             "sweep_fwd_ms": round(hot["fwd"], 4), "sweep_bwd_ms": round(hot["bwd"], 4),
+             "hot_path_share_of_step": round((hot["fwd"] + hot["bwd"]) * 1e-3 / t_step, 4),
+             "network": "stand-in conv U-net, %d parameters (%.1f MB fp32 gradients), DistributedDataParallel(find_unused_parameters=True)"
+                        % (n_params, n_params * 4 / 1e6),
+             "batch_per_gpu": B, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+             "structure": "flip_right doubling -> DDP(conv net) -> fused decoder tail -> plane sweep -> losses -> backward -> Adam"}
+    if world > 1:
+        exposed = max(t_step - t_nosync, 0.0)
+        block.update(allreduce_alone_ms=round(t_allreduce * 1e3, 3), allreduce_exposed_ms=round(exposed * 1e3, 3),
+                     allreduce_hidden_share=round(1.0 - min(exposed / t_allreduce, 1.0), 3) if t_allreduce > 0 else None)
+    else:
+        block["allreduce_hidden_share"] = None   # one rank: nothing to overlap; measured from --gpus 2 upwards
+    del ddp
+    if own_group:
+        dist.destroy_process_group()
+    return block
+
+
+def parallel_max(v, device):
+    from planedepth_amd import parallel
+    return parallel.max_over_ranks(v, device)
+
+
 def measured_traffic(args, kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if they were taken on this
-    exact workload; None otherwise (bench.py cannot run the profiler around itself)."""
+    """(HBM bytes per launch, where the figure comes from).  bench.py cannot run the profiler around itself, so this is
+    NOT a measurement of this run: it is read from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    scripts/gpu_profile.sh on this exact workload) and labelled as such; (None, reason) for any other workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
@@ -285,9 +445,12 @@ def measured_traffic(args, kernel):
         same = (w["batch"] == args.batch and w["planes"] == args.planes and w["height"] == args.height and
                 w["width"] == args.width and w["mixture"] == (not args.no_mixture) and args.xz_levels == 0 and
                 not args.automask and args.warp_type == "disp_warp")
-        return int(t[kernel]) if same else None
+        if not same:
+            return None, "no PMC pass committed for this workload"
+        return int(t[kernel]), "profiles/traffic.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of %s (%s), not of this run" % (
+            t.get("taken", "round 1"), t.get("note", "see profiles/"))
     except Exception:
-        return None
+        return None, "profiles/traffic.json unreadable"
 
 
 def cpu_baseline(args, budget_s):
@@ -400,27 +563,44 @@ def main():
                           "devices": "shared cuda:0 (PD_BENCH_SHARE_GPU)" if os.environ.get("PD_BENCH_SHARE_GPU")
                           else "one per rank"}
     if rank == 0:
-        kt = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))
+        iso = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))
+        kt = in_step_kernel_times(step, device, iters=max(10, min(args.steps, 50)))   # the figure the roofline uses
         if kt:
             fwd_b, bwd_b = algorithmic_bytes(args)
             dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
             per_launch = (bwd_b if dom == "bwd" else fwd_b) * args.batch
             ach = per_launch / (kt[dom] * 1e-3) / 1e9
-            traffic = measured_traffic(args, "pd_plane_sweep_" + dom)
-            result["roofline"] = {"bound": "hbm", "kernel": "pd_plane_sweep_" + dom, "achieved": round(ach, 1),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                  "traffic": traffic, "algorithmic_bytes_per_launch": per_launch,
-                                  "avg_launch_ms": round(kt[dom], 4)}
+            traffic, traffic_src = measured_traffic(args, "pd_plane_sweep_" + dom)
+            block = {"bound": "hbm", "kernel": "pd_plane_sweep_" + dom, "achieved": round(ach, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_launch,
+                     "avg_launch_ms": round(kt[dom], 4),
+                     "timing": "HIP events on the launch stream around the C-ABI call, inside the training step"}
+            # headline workload -> "roofline"; the general (homography) kernels report the same block under their own key
+            result["roofline" if args.warp_type == "disp_warp" else "roofline_general"] = block
+            if args.warp_type != "disp_warp":
+                result["roofline"] = dict(block, note="general kernels (homography_warp); the headline disp_warp "
+                                                      "kernels are measured by the default invocation")
             result["kernels"] = {
                 "fwd_ms": round(kt["fwd"], 4), "bwd_ms": round(kt["bwd"], 4),
                 "fwd_GBs": round(fwd_b * args.batch / (kt["fwd"] * 1e-3) / 1e9, 1),
                 "bwd_GBs": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9, 1),
                 "whole_path_frac_of_peak": round((fwd_b + bwd_b) * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+            if iso:
+                result["kernels"].update(isolated_fwd_ms=round(iso["fwd"], 4), isolated_bwd_ms=round(iso["bwd"], 4))
         if world == 1 and not args.no_next_rows:
             result["next_rows"] = next_rows_times(args, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
+    if not args.no_ddp_step and args.warp_type == "disp_warp" and not args.xz_levels:
+        try:   # every rank takes part (DDP's collectives); rank 0 reports
+            blk = ddp_step_block(args, device, rank, world)
+        except Exception as e:  # the headline line must not die with the secondary block
+            blk = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if rank == 0:
+            result["ddp_step"] = blk
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist

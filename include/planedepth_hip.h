@@ -236,6 +236,14 @@ int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other
                 pd_stream_t stream);
 
 /*
+ * inputs["grid"] of the data pipeline on the device: RandomResizeCrop / Resize of
+ * datasets/pair_transforms.py:27-37, 63-68.  params [B][4] int32 on the device = (full_w, full_h, w0, h0): the resized
+ * frame's size and the crop window's origin; grid [B,2,H,W] receives torch.linspace(-1, 1, full_w)[w0 + x] and
+ * torch.linspace(-1, 1, full_h)[h0 + y] (scalar formula; within one ulp of ATen's vectorised CPU kernel).
+ */
+int pd_crop_grid(int B, int H, int W, const int32_t* params, float* grid, pd_stream_t stream);
+
+/*
  * Geometry modules.
  *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
  *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pd_warp_softmax": (_I, [_I] * 4 + [_F, _I, _P, _P, _P, _P]),
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
+    "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
     "pd_backproject": (_I, [_I] * 3 + [_P] * 4),
     "pd_backproject_bwd": (_I, [_I] * 3 + [_P] * 4),
     "pd_project3d": (_I, [_I] * 3 + [_F] + [_P] * 4),

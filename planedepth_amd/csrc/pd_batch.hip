@@ -26,9 +26,42 @@ __global__ __launch_bounds__(kBlock) void cat_flip_kernel(int C, int H, int W, c
   out[(long)b * n + i] = v;
 }
 
+// inputs["grid"] of the reference's data pipeline, generated on the device:
+// RandomResizeCrop (datasets/pair_transforms.py:27-37) builds torch.linspace(-1, 1, full_w) x torch.linspace(-1, 1, full_h)
+// over the RESIZED frame and crops the H x W window at (h0, w0); Resize (:63-68) is full = (H, W), h0 = w0 = 0.
+// torch.linspace's scalar formula (ATen RangeFactories: step = (end - start) / (steps - 1) in the tensor's dtype;
+// start + step * i below the midpoint, end - step * (steps - 1 - i) from it on).  ATen's CPU kernel evaluates it per
+// vector of 8 / 16 lanes (base + j * step), so the reference's own grid differs in the last bit between host CPUs;
+// this kernel is within one ulp of either (tests/test_gpu_parity.py).
+__device__ __forceinline__ float linspace_m1_1(int i, int steps) {
+#pragma clang fp contract(off)
+  if (steps <= 1) return -1.0f;
+  const float step = (1.0f - (-1.0f)) / (float)(steps - 1);
+  const int half = steps / 2;
+  return (i < half) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(steps - i - 1));
+}
+
+__global__ __launch_bounds__(kBlock) void crop_grid_kernel(int H, int W, const int* __restrict__ params,
+                                                           float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  const int full_w = params[b * 4 + 0], full_h = params[b * 4 + 1], w0 = params[b * 4 + 2], h0 = params[b * 4 + 3];
+  float* o = out + (long)b * 2 * H * W;
+  o[i] = linspace_m1_1(w0 + x, full_w);
+  o[(long)H * W + i] = linspace_m1_1(h0 + y, full_h);
+}
+
 }  // namespace pd
 
 using namespace pd;
+
+extern "C" int pd_crop_grid(int B, int H, int W, const int* params, float* grid, pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long)H * W < (1L << 31), "bad shape");
+  PD_REQUIRE(params && grid, "NULL pointer");
+  crop_grid_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(H, W, params, grid);
+  return check_launch("crop_grid_kernel");
+}
 
 extern "C" int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other, int negate_c0, float* out,
                            pd_stream_t stream) {

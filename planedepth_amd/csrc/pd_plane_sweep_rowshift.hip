@@ -868,7 +868,7 @@ static int row_threads(int W) {
   const int nseg = ceil_div(W, kWave);
   if (const char* e = getenv("PD_ROW_WAVES")) {  // tuning hook
     const int w = atoi(e);
-    if (w >= 1 && w <= 16) return (w < nseg ? w : nseg) * kWave;
+    if (w >= 1 && w <= kRowThreadsMax / kWave) return (w < nseg ? w : nseg) * kWave;   // the kernels' launch bound
   }
   // Measured on MI355X (W=640, 10 segments): 4, 5, 8 and 10 waves per workgroup are within 3% of each other, 1-2
   // waves are 1.5-2.5x slower (too few waves in flight).  Take the largest divisor of nseg up to 8 for equal work
@@ -881,9 +881,13 @@ static int row_threads(int W) {
 }
 
 bool rowshift_applicable(const pd_sweep_desc* d) {
+  // LDS of the larger of the two kernels: the backward's boundary records, the forward's parked partial sums (row pairs
+  // double them) — a shape that fits neither falls back to the general kernels instead of failing at launch
+  const size_t colour = (size_t)(d->W + 4) * 2 * sizeof(float4);
+  const size_t bwd = colour + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 3) * 4;
+  const size_t fwd = colour + ((size_t)d->N + (size_t)(kRowThreadsMax / kWave) * 2 * 8 * kWave * 2) * 4;
   return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
-         (long)d->N * d->H * d->W < (1L << 31) &&
-         (size_t)(d->W + 4) * 32 + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 3) * 4 <= 160 * 1024;
+         (long)d->N * d->H * d->W < (1L << 31) && bwd <= 160 * 1024 && fwd <= 160 * 1024;
 }
 
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d) {

@@ -96,7 +96,9 @@ __device__ __forceinline__ int block_row(int r, int H) {
 // weight on the same row, which the two-row bodies handle in full generality.
 // Vertical round-trip noise.  The reference's y -> normalise -> un-normalise chain returns y + e with |e| <= 6e-6 for a
 // quarter of the rows (fp32 rounding; exact arithmetic gives y), which makes grid_sample blend in the NEXT source row
-// with weight e.  Serving that second row exactly doubles the loads of those rows (measured at 8x49x192x640: forward
+// with weight e.  (Forward values and per-pixel gradients always use that second row; only the ADJOINT's e-weighted
+// term into the neighbouring row is dropped: pd_plane_sweep_rowshift.hip's header.)  Serving that second row exactly
+// doubles the loads of those rows (measured at 8x49x192x640: forward
 // 0.137 -> 0.104 ms, backward 0.31 -> 0.30 ms, HBM reads -20% without it).  It is served by default all the same:
 // dropping it moves results by up to e * (range of the logits), measured 4e-5 (rgb_rec) .. 1e-4 (g_sigma) of the
 // tensors' range on random inputs — the whole 1e-4 parity budget.  PD_IMPL_FAST_ROWS opts into dropping a second row

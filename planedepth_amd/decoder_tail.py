@@ -24,17 +24,31 @@ class LazyLayers:
     """``outputs["probability"]`` / ``outputs["pi"]`` stand-in: has ``.shape`` (all the training loop reads,
     trainer.py:528, 610, 704) and materialises the tensor on first real use."""
 
-    def __init__(self, shape, make):
+    def __init__(self, shape, make, device=None, dtype=None):
         self.shape = tuple(shape)
+        self.device = device
+        self.dtype = dtype
         self._make = make
         self._value = None
 
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
     def tensor(self):
+        """The materialised [B,N,H,W] tensor.  It carries NO gradient (nothing in the reference's losses back-propagates
+        through ``probability`` / ``pi``: trainer.py reads them for their shape, the post-process under no_grad)."""
         if self._value is None:
             self._value = self._make()
         return self._value
 
-    def __getattr__(self, name):          # anything beyond .shape: behave like the tensor
+    def __getattr__(self, name):          # anything beyond shape / device / dtype: behave like the tensor
+        # private and dunder names are never forwarded: copy / pickle look them up on objects created without __init__,
+        # where forwarding would recurse through `_value` for ever
+        if name.startswith("_"):
+            raise AttributeError(name)
         return getattr(self.tensor(), name)
 
     def __getitem__(self, idx):
@@ -59,9 +73,10 @@ def fused_decoder_tail(outputs, dispconv_out, sigmaconv_out=None, *, use_mixture
         if use_mixture_loss:
             outputs["pi"] = pi
     else:
-        outputs["probability"] = LazyLayers(shape, lambda: layers(False, True)[1])
+        dev, dt = dispconv_out.device, dispconv_out.dtype
+        outputs["probability"] = LazyLayers(shape, lambda: layers(False, True)[1], dev, dt)
         if use_mixture_loss:
-            outputs["pi"] = LazyLayers(shape, lambda: layers(True, False)[0])
+            outputs["pi"] = LazyLayers(shape, lambda: layers(True, False)[0], dev, dt)
     outputs["disp"] = disp
     outputs["depth"] = depth
     return outputs

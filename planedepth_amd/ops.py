@@ -16,6 +16,28 @@ from . import _capi as C
 SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
+KERNEL_EVENTS = None     # measurement (bench.py): set to a dict {"fwd": [], "bwd": []} to collect (start, end) CUDA events
+                         # recorded on the launch stream around the sweep's C-ABI calls INSIDE a training step
+
+
+class _timed:
+    """Record a pair of events around a launch when ops.KERNEL_EVENTS is set (no cost otherwise)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.b.record()
+            KERNEL_EVENTS[self.kind].append((self.a, self.b))
+        return False
 
 
 def _desc(B, N, H, W, mode, flags, sign):
@@ -71,7 +93,7 @@ class _PlaneSweep(torch.autograd.Function):
         ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
         ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
         stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
-        with torch.cuda.device(logits.device):
+        with torch.cuda.device(logits.device), _timed("fwd"):
             rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                         C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                         C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(ph_mean), C.ptr(stash),
@@ -103,7 +125,7 @@ class _PlaneSweep(torch.autograd.Function):
         g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
         if g_ph_mean is not None:
             g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
-        with torch.cuda.device(logits.device):
+        with torch.cuda.device(logits.device), _timed("bwd"):
             rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                         C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                         C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
@@ -445,6 +467,23 @@ def cat_flip(own, other, negate_c0=False):
             C.check(lib.pd_cat_flip(B, Cn, H, W, C.ptr(own), C.ptr(other), int(bool(negate_c0)), C.ptr(out),
                                     C.stream_handle(own.device)), "pd_cat_flip")
     return out
+
+
+def crop_grid(params, height, width):
+    """``inputs["grid"]`` [B,2,H,W] on the device from per-sample crop parameters [B,4] int32 = (full_w, full_h, w0, h0)
+    (datasets/pair_transforms.py:27-37: the RandomResizeCrop grid; Resize is full = (W, H), origin 0) — bit-identical to
+    the reference's ``torch.linspace`` / ``meshgrid`` / crop."""
+    lib = C.load()
+    C.require_gpu_tensor("params", params, dtype=torch.int32)
+    if params.dim() != 2 or params.shape[1] != 4:
+        raise ValueError("params must be [B,4] int32 (full_w, full_h, w0, h0), got %s" % (tuple(params.shape),))
+    B = params.shape[0]
+    params = params.contiguous()
+    grid = torch.empty(B, 2, int(height), int(width), device=params.device, dtype=torch.float32)
+    with torch.cuda.device(params.device):
+        C.check(lib.pd_crop_grid(B, int(height), int(width), C.ptr(params), C.ptr(grid), C.stream_handle(params.device)),
+                "pd_crop_grid")
+    return grid
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -116,6 +116,44 @@ def crop_grid(H, W, full_h, full_w, h0, w0):
     return torch.stack([gx, gy], 0)[:, h0:h0 + H, w0:w0 + W].clone()
 
 
+def crop_params(B, H, W, seed=0, crop=True, full=(375, 1242)):
+    """[B,4] int32 (full_w, full_h, w0, h0) as RandomResizeCrop draws them (pair_transforms.py:27-32) for a KITTI-sized
+    frame; ``crop=False``: the plain Resize grid."""
+    rng = np.random.RandomState(seed)
+    rows = []
+    for _ in range(B):
+        if crop:
+            full_h0, full_w0 = full
+            fmin = max((H + 1) / full_h0, (W + 1) / full_w0)                   # pair_transforms.py:29
+            factor = rng.uniform(fmin, max(fmin, 1.0))
+            fh, fw = int(full_h0 * factor), int(full_w0 * factor)
+            h0, w0 = rng.randint(0, fh - H + 1), rng.randint(0, fw - W + 1)
+            rows.append((fw, fh, w0, h0))
+        else:
+            rows.append((W, H, 0, 0))
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def kitti_like_inputs_on_device(B, H, W, seed=0, *, crop=True, novel_frame_ids=(), device="cuda"):
+    """``kitti_like_inputs`` produced ON the device: images from a device generator, ``grid`` by
+    the ``pd_crop_grid`` kernel (bit-identical to the reference's linspace/meshgrid/crop), K / inv_K / Rt constants
+    uploaded once.  What a data-loader-free end-to-end step (bench.py --ddp_step) feeds the networks."""
+    from . import ops
+    g = torch.Generator(device=device).manual_seed(seed)
+    inputs = {}
+    for s in ("l", "r") + tuple(novel_frame_ids):
+        img = torch.rand(B, 3, H, W, generator=g, device=device)
+        inputs[("color", s)] = img
+        inputs[("color_aug", s)] = img.clone()
+    inputs["grid"] = ops.crop_grid(crop_params(B, H, W, seed, crop).to(device), H, W)
+    K, inv_K = dataset_intrinsics(B, H, W)
+    inputs["K"], inputs["inv_K"] = K.to(device), inv_K.to(device)
+    Tl, Tr = torch.eye(4)[None].repeat(B, 1, 1), torch.eye(4)[None].repeat(B, 1, 1)
+    Tl[:, 0, 3], Tr[:, 0, 3] = 0.1, -0.1
+    inputs[("Rt", "l")], inputs[("Rt", "r")] = Tl.to(device), Tr.to(device)
+    return inputs
+
+
 def kitti_like_inputs(B, H, W, seed=0, *, crop=True, novel_frame_ids=(), device="cpu"):
     """A minibatch with the keys, shapes and conventions of the reference's KITTI pipeline (datasets/mono_dataset.py:
     193-211 + pair_transforms.py), from a seeded generator instead of image files:

@@ -20,6 +20,8 @@ What differs from the reference (all documented in DESIGN.md):
   * ``depth_warp`` (broken in the reference) is routed through BackprojectDepth/Project3D + the
     decoder's padding mask and is evaluated with the unfused operators.
 """
+import os
+
 import torch
 
 from . import ops
@@ -68,6 +70,17 @@ def pred_novel_images(self, inputs, outputs):
         padding_mask = None
     # xy and xz planes have disparities that are constant along x (depth_decoder.py:153-181); yz planes do not (:221-236)
     row_uniform = getattr(opt, "yz_levels", None) == 0
+    if getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT"):
+        # The two shortcuts above are taken from the OPTIONS (what the reference's three networks guarantee), not from
+        # the tensors: a custom decoder whose outputs disagree with opt would get silently wrong warps.  This opt-in
+        # check (one reduction + a host sync per call: debugging, not training) verifies them on the data.
+        pm, dl = outputs.get("padding_mask"), outputs["disp_layered"]
+        if padding_mask is None and pm is not None and not bool((pm == 1).all()):
+            raise ValueError("opt.xz_levels == opt.yz_levels == 0 promises an all-ones padding_mask, but it has zeros")
+        if row_uniform and dl.dim() == 4 and dl.shape[-1] > 1 and not bool((dl == dl[..., :1]).all()):
+            raise ValueError("opt.yz_levels == 0 promises disparities that are constant along x, but disp_layered is not")
+        if row_uniform and pm is not None and pm.dim() == 4 and pm.shape[-1] > 1 and not bool((pm == pm[..., :1]).all()):
+            raise ValueError("opt.yz_levels == 0 promises a padding_mask that is constant along x, but it is not")
     for target_side in self.target_sides:
         tgt = inputs[(cname, target_side)]
         sigma = outputs["sigma"] if mix else None

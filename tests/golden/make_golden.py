@@ -331,6 +331,35 @@ def trainer_mono_vectors(ref):
     return out
 
 
+def pipeline_vectors(ref):
+    """inputs["grid"] as the reference's own transforms make it (datasets/pair_transforms.py: RandomResizeCrop :27-37,
+    Resize :63-68), with the crop parameters recovered by replaying the transform's random draws.  Fixture for the
+    on-device grid kernel."""
+    import importlib
+    import random
+    pt = importlib.import_module("datasets.pair_transforms")
+    out = {}
+    cases = [("kitti_192x640", (192, 640), (375, 1242), (0.75, 1.5), 11), ("small_24x80", (24, 80), (60, 200), (0.75, 1.5), 5),
+             ("hr_384x1280", (384, 1280), (375, 1242), (1.05, 1.5), 3), ("odd_17x33", (17, 33), (41, 97), (0.5, 2.0), 9)]
+    for tag, (H, W), (FH, FW), fac, seed in cases:
+        np.random.seed(seed); random.seed(seed)
+        src = {("color", "r", -1): torch.rand(3, FH, FW), ("color", "l", -1): torch.rand(3, FH, FW)}
+        res = pt.RandomResizeCrop((H, W), factor=fac)(dict(src))
+        np.random.seed(seed); random.seed(seed)
+        fmin = max(max((H + 1) / FH, (W + 1) / FW), fac[0])
+        factor = np.random.uniform(low=fmin, high=fac[1])
+        h0 = random.randint(0, int(FH * factor - H)); w0 = random.randint(0, int(FW * factor - W))
+        out[tag + "/params"] = np.asarray([int(FW * factor), int(FH * factor), w0, h0], dtype=np.int32)
+        out[tag + "/grid"] = res["grid"].numpy()
+        out[tag + "/hw"] = np.asarray([H, W], dtype=np.int32)
+    H, W = 24, 80
+    res = pt.Resize((H, W))({("color", "r", -1): torch.rand(3, 37, 123), ("color", "l", -1): torch.rand(3, 37, 123)})
+    out["resize_24x80/params"] = np.asarray([W, H, 0, 0], dtype=np.int32)
+    out["resize_24x80/grid"] = res["grid"].numpy()
+    out["resize_24x80/hw"] = np.asarray([H, W], dtype=np.int32)
+    return out
+
+
 def scalars(res):
     f = lambda t: float(t.double().sum())  # noqa: E731
     a = lambda t: float(t.double().abs().sum())  # noqa: E731
@@ -345,6 +374,9 @@ def main():
     if "--only-trainer-mono" in sys.argv:   # add the configs[3] fixtures without touching the others
         np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
         return
+    if "--only-pipeline" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **pipeline_vectors(ref))
+        return
     for name, bkw, rkw in SMALL_CASES:
         case = build_case(**bkw)
         res = run_reference(ref, case, **rkw)
@@ -357,6 +389,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "decoder_tail.npz"), **decoder_tail_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "post_process.npz"), **post_process_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **pipeline_vectors(ref))
     kat = {}
     for name, _, rkw in FULL_CASES:
         case = survey_fullsize_case()

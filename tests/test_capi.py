@@ -97,3 +97,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("oracle container", ""), f
+
+
+def test_lazy_layers_is_safe_to_copy_and_reports_metadata_without_materialising():
+    """LazyLayers must not recurse on copy / pickle (private names are not forwarded) and must answer
+    shape / device / dtype / dim() without building the [B,N,H,W] tensor."""
+    import copy
+    import torch
+    from planedepth_amd.decoder_tail import LazyLayers
+    calls = []
+    lz = LazyLayers((2, 3, 4, 5), lambda: calls.append(1) or torch.ones(2, 3, 4, 5), torch.device("cpu"), torch.float32)
+    assert lz.shape == (2, 3, 4, 5) and lz.dim() == 4 and lz.size(1) == 3 and lz.dtype == torch.float32
+    assert str(lz.device) == "cpu" and not calls
+    dup = copy.copy(lz)
+    assert dup.shape == lz.shape and not calls
+    assert float(lz.sum()) == 120.0 and calls == [1]      # first real use materialises, once
+    assert float(lz[0, 0, 0, 0]) == 1.0 and calls == [1]
+    try:
+        lz._no_such_private
+    except AttributeError:
+        pass
+    else:
+        raise AssertionError("private names must not be forwarded")

@@ -151,3 +151,16 @@ def test_trainer_mono_fixture(tag):
             assert float(v.abs().max()) == 0.0, k
         else:
             assert rel_err(v, w) < TOL, (tag, k, rel_err(v, w))
+
+
+def test_crop_grid_restatement_against_reference_grids():
+    """synthetic.crop_grid (the CPU restatement of RandomResizeCrop's / Resize's grid) against the grids
+    the reference's transforms produced (tests/golden/pipeline.npz), bit for bit."""
+    from planedepth_amd.synthetic import crop_grid
+    z = np.load(os.path.join(GOLDEN, "pipeline.npz"))
+    tags = sorted({k.split("/")[0] for k in z.files})
+    assert len(tags) >= 5
+    for tag in tags:
+        fw, fh, w0, h0 = (int(v) for v in z[tag + "/params"])
+        H, W = (int(v) for v in z[tag + "/hw"])
+        assert torch.equal(crop_grid(H, W, fh, fw, h0, w0), torch.from_numpy(z[tag + "/grid"])), tag
