@@ -99,8 +99,12 @@ def build_step(args, c, device):
                                 gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
                                 xz_levels=args.xz_levels, yz_levels=0)
     zero = torch.zeros((), device=device)
-    ns = types.SimpleNamespace(opt=opt, target_sides=["r"], perceptual_loss=lambda *a, **k: zero)
-    inputs = {("color", "l"): c["color_l"], ("color", "r"): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
+    # --mono_pose: the target is a novel frame (-1), whose pose predict_poses builds without translation -> the
+    # plane-uniform kernels; --colmap_pose: a novel frame with a translation (opt.use_colmap) -> the general kernels
+    side = -1 if (args.mono_pose or args.colmap_pose) else "r"
+    opt.use_colmap = bool(args.colmap_pose)
+    ns = types.SimpleNamespace(opt=opt, target_sides=[side], perceptual_loss=lambda *a, **k: zero)
+    inputs = {("color", "l"): c["color_l"], ("color", side): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
     norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
     shape_probe = torch.empty(B, N, H, W, device="meta")
     g_rgb = c["g_rgb_rec"]
@@ -125,13 +129,13 @@ def build_step(args, c, device):
         else:
             disp_layered = disp_pp.expand(-1, -1, H, W)
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
-                   "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm, ("Rt", "r"): Rt}
+                   "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm, ("Rt", side): Rt}
         if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
             outputs["distance"] = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
-        ph = outputs[("ph_mean", "r")]  # = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
-        rgb_rec = outputs[("rgb_rec", "r")]
+        ph = outputs[("ph_mean", side)]  # = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
+        rgb_rec = outputs[("rgb_rec", side)]
         torch.autograd.backward([ph, rgb_rec], [one, g_rgb])
         return ph
 
@@ -167,8 +171,14 @@ def kernel_times(args, c, device, iters):
         mode, sign = C.PD_WARP_HOMOGRAPHY, 0.0
         ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
         norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
-        plane, aux = ops.homography_matrices(0.1 * 0.58 * W / c["disp_pp"][:, :, 0, 0], norm, ex(bench_pose(args, c, device)),
-                                             ex(c["K"]), ex(c["inv_K"]))
+        Tp = bench_pose(args, c, device)
+        dist_ = 0.1 * 0.58 * W / c["disp_pp"][:, :, 0, 0]
+        plane, aux = ops.homography_matrices(dist_, norm, ex(Tp), ex(c["K"]), ex(c["inv_K"]))
+        if args.mono_pose:   # zero translation: one homography per image, the plane-uniform kernels ([B,4,3,3] layout)
+            h1, _ = ops.homography_matrices(dist_[:, :1], norm[:, :1], Tp, c["K"], c["inv_K"])
+            plane = h1[:, None].expand(-1, 4, -1, -1)
+            pm = (norm / dist_[..., None]).contiguous()   # translation weights n/d
+            flags |= C.PD_HOMO_UNIFORM
         plane, aux, k3 = plane.contiguous(), aux.contiguous(), c["inv_K"][:, :3, :3].contiguous()
     d = C.SweepDesc(B, N, H, W, mode, flags, sign, int(os.environ.get("PD_SWEEP_IMPL", 0)))
     k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)

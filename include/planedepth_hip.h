@@ -50,6 +50,16 @@ enum pd_sweep_flags {
   PD_MASK_ROWS = 32   /* disp mode: `padding_mask` is [B,N,H], one value per plane and row (the xz horizon mask is
                          constant along x, depth_decoder.py:166).  Only where pd_sweep_uses_rowshift(): a masked plane
                          row is treated as shifted out of view, so the mask costs no per-pixel traffic at all */
+  ,
+  PD_HOMO_UNIFORM = 64 /* homography mode: every plane of an image shares ONE homography.  What Trainer.predict_poses hands
+                         over for the novel frames without COLMAP: zero translation (trainer.py:386-400), hence
+                         K (R + t n^T/d) K^-1 = K R K^-1 for every plane.  `plane` is [B,4,3,3]: slice 0 = H_t2s, slices
+                         1..3 = the homographies of virtual planes with n/d = e_0, e_1, e_2 (same values at t = 0);
+                         `plane_aux` stays [B*N,3] (the facing test depends on the plane's normal); `padding_mask` carries
+                         the [B,N,3] weights n_n/d_n or NULL.  g_plane [B,4,3,3] = (sum_n G_n, sum_n G_n n_n[j]/d_n):
+                         back-propagated through f(R + t e_j^T) it gives the exact translation gradient of the per-plane
+                         formulation.  Served by pd_plane_sweep_uniform.hip: geometry once per pixel, atomic-free
+                         two-pass backward */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };

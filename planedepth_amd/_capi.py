@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth_hip.so")  # PD_LIB: diagnostics builds
 
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
-PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_ROWS = 1, 2, 4, 8, 16, 32
+PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_ROWS, PD_HOMO_UNIFORM = 1, 2, 4, 8, 16, 32, 64
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2

@@ -384,8 +384,12 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
   PD_REQUIRE(!(d->flags & PD_MIXTURE) || sigma, "PD_MIXTURE needs sigma");
   if (d->mode == PD_WARP_HOMOGRAPHY) {
     PD_REQUIRE(plane_aux && inv_K3, "homography mode needs plane_aux (R n) and inv_K3");
-    PD_REQUIRE(padding_mask == nullptr, "homography mode computes its own padding mask; pass NULL");
+    PD_REQUIRE(padding_mask == nullptr || (d->flags & PD_HOMO_UNIFORM),
+               "homography mode computes its own padding mask; pass NULL (PD_HOMO_UNIFORM: the [B,N,3] translation weights)");
     PD_REQUIRE(!(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)), "PD_DISP_DENSE / PD_DISP_ROWS are disp-mode flags");
+    PD_REQUIRE(!((d->flags & PD_HOMO_UNIFORM) && (d->flags & PD_RENDER_PROB)), "PD_HOMO_UNIFORM does not serve PD_RENDER_PROB");
+  } else {
+    PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM), "PD_HOMO_UNIFORM is a homography-mode flag");
   }
   PD_REQUIRE(!((d->flags & PD_DISP_DENSE) && (d->flags & PD_DISP_ROWS)), "PD_DISP_DENSE and PD_DISP_ROWS exclude each other");
   if ((d->flags & PD_DISP_ROWS) && !pd_sweep_uses_rowshift(d)) {
@@ -450,8 +454,10 @@ extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   const size_t general = (size_t)d->B * bwd_blocks(d->H * d->W) * d->N * K;
   const size_t rows = rowshift_applicable(d) ? rowshift_bwd_workspace_floats(d) : 0;
   const size_t tiles = tile_bwd_applicable(d) ? tile_bwd_workspace_floats(d) : 0;
-  const size_t m = general > rows ? general : rows;
-  return m > tiles ? m : tiles;
+  const size_t uni = (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) ? uniform_bwd_workspace_floats(d) : 0;
+  size_t m = general > rows ? general : rows;
+  m = m > tiles ? m : tiles;
+  return m > uni ? m : uni;
 }
 
 #define PD_DISPATCH(KERNEL, mode, mix, grid, block, shmem, stream, ...)                                   \
@@ -483,6 +489,8 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
     if (rowquad_applicable(d, a.has_mask != 0)) return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   }
+  if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM))
+    return uniform_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
   PD_DISPATCH(sweep_fwd_kernel, d->mode, (d->flags & PD_MIXTURE) != 0, grid, dim3(kBlock), 0, (hipStream_t)stream, a,
               rgb_rec, ph_map, stash);
@@ -517,6 +525,10 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     if (rowquad_applicable(d, ak.has_mask != 0) && getenv("PD_QUAD_BWD")) return rowquad_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
   }
+  if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) {
+    PD_REQUIRE(workspace, "the plane-uniform backward needs workspace (pd_sweep_bwd_workspace_floats)");
+    return uniform_bwd(d, ak, o, workspace, stream);
+  }
   if (tile_bwd_applicable(d)) {   // PD_IMPL_TILE: source tiles owned by workgroups, no atomics, no zero-fill
     PD_REQUIRE(workspace, "the tile backward needs workspace (pd_sweep_bwd_workspace_floats)");
     return tile_bwd(d, ak, o, workspace, stream);
@@ -548,6 +560,7 @@ extern "C" int pd_plane_sweep_layers(const pd_sweep_desc* d, const float* src, c
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
+  PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM), "pd_plane_sweep_layers takes one homography per plane (expand the matrix)");
   SweepArgs a = make_args(d, src, nullptr, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   LayersOut o{rgb_rec_layered, logit_rec, probability_rec, sigma_rec, pi_rec};
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);

@@ -1,0 +1,435 @@
+// Plane-uniform homography sweep: homography_warp when EVERY plane of an image shares one homography.
+//
+// That is what BASELINE configs[3] feeds the path for the novel frames -1 / +1: Trainer.predict_poses without COLMAP
+// builds Rt with the pose net's rotation (conjugated by the crop matrix) and ZERO translation (reference
+// trainer.py:386-400), so Rtnd = R + t n^T / d = R for every plane (layers.py:216) and
+// H_t2s = inverse(K R K^-1) does not depend on the plane.  Only the facing test (K^-1 p).(R n) > 0 (layers.py:223) still
+// does, through the plane normal.  PD_HOMO_UNIFORM: `plane` is [B,3,3] (one H_t2s per image), `plane_aux` is [B*N,3].
+//
+// Forward: the sampling position, the four tap offsets / weights and the three colour samples are computed ONCE per
+// target pixel; the plane loop is 8 loads + 8 FMAs + the online softmax (the general kernel spends ~190 VALU per pixel
+// and plane on the geometry it re-derives 49 times).
+//
+// Backward without atomics, in two passes per image (the scatter pattern is the same for all planes, so it can be
+// inverted once per SOURCE pixel and reused 49 times):
+//   pass 1 (target-anchored): per pixel and plane the closed-form gradients w.r.t. the sampled logit / sigma
+//           (pd_sweep.h) go to a per-image scratch [2][N][H][W] with coalesced stores (zeros for masked planes); the
+//           homography gradient is accumulated per thread over ALL planes and reduced once per workgroup;
+//   pass 2 (source-anchored): every source pixel finds the target pixels whose bilinear footprint covers it — the
+//           integer points in the pre-image of its 2x2 neighbourhood, located with the forward homography (fp64
+//           adjugate) and its local Jacobian, each CONFIRMED with the bit-exact forward coordinate chain, which also
+//           yields the exact bilinear weight — keeps up to 12 (index, weight) pairs in registers, and then gathers
+//           g[n][s] = sum_k w_k * scratch[n][t_k] for all planes with plain coalesced stores.  Every element of
+//           g_logits / g_sigma is written exactly once: no zero-fill, no read-modify-write.  A source pixel with more
+//           than 12 contributors (strong minification) is left to a follow-up kernel that re-scans per plane.
+// The scratch of one image (2 x 24 MB at 49 x 192 x 640) is produced and consumed back to back, so it lives in the
+// 256 MB memory-side cache rather than in HBM.
+#include "pd_sweep_geom.h"
+
+namespace pd {
+
+constexpr int kUniK = 12;  // gather entries kept in registers per source pixel (a near-isometric map gives 4, up to 9 where
+                           // a perspective term makes the lattices beat)
+constexpr int kUniH = 4 * 9;   // floats per image in `plane` ([B,4,3,3], see uniform_bwd_pass1_kernel)
+
+// Per-pixel geometry shared by all planes
+struct UniGeom {
+  PlaneGeom g;
+  float r0, r1, r2;   // K^-1 [x, y, 1]: the facing test's left-hand side
+  bool z_ok;
+};
+__device__ __forceinline__ UniGeom uni_geom(const float* __restrict__ Hm, const float* __restrict__ Ki, const CoordNorm& cn,
+                                            int x, int y) {
+  UniGeom u;
+  const float fx = (float)x, fy = (float)y;
+  u.g.p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
+  u.g.p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
+  const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
+  u.r0 = Ki[0] * fx + Ki[1] * fy + Ki[2];
+  u.r1 = Ki[3] * fx + Ki[4] * fy + Ki[5];
+  u.r2 = Ki[6] * fx + Ki[7] * fy + Ki[8];
+  u.z_ok = (z > kZMin);
+  u.g.z_clamped = (z < kZMin);
+  u.g.zc = u.g.z_clamped ? kZMin : z;
+  if (cn.fast) {
+    u.g.ix = normalise_roundtrip_rcp(u.g.p0 / u.g.zc, cn.Wm1, cn.rcpW);
+    u.g.iy = normalise_roundtrip_rcp(u.g.p1 / u.g.zc, cn.Hm1, cn.rcpH);
+  } else {
+    u.g.ix = normalise_roundtrip(u.g.p0 / u.g.zc, cn.Wm1);
+    u.g.iy = normalise_roundtrip(u.g.p1 / u.g.zc, cn.Hm1);
+  }
+  return u;
+}
+__device__ __forceinline__ bool uni_mask(const UniGeom& u, const float* __restrict__ Rn) {
+  return ((u.r0 * Rn[0] + u.r1 * Rn[1] + u.r2 * Rn[2]) > 0.0f) && u.z_ok;   // layers.py:223-225, same operation order
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------------------------------
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+                                                             float* __restrict__ ph_map, float* __restrict__ stash) {
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  float ph_val = 0.0f;
+  if (pix < HW) {
+    const int y = pix / a.W, x = pix - y * a.W;
+    const bool automask = a.flags & PD_AUTOMASK;
+    const float* srcb = a.src + (long)b * 3 * HW;
+    const float t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
+    const float t1 = a.tgt[((long)b * 3 + 1) * HW + pix];
+    const float t2 = a.tgt[((long)b * 3 + 2) * HW + pix];
+    float ea = 0.0f;
+    if (automask) ea = fabsf(srcb[pix] - t0) + fabsf(srcb[HW + pix] - t1) + fabsf(srcb[2 * HW + pix] - t2);
+    const CoordNorm cn = make_coord_norm(a.W, a.H);
+    const UniGeom u = uni_geom(a.plane + (long)b * kUniH, a.inv_K3 + (long)b * 9, cn, x, y);
+    const TapK t = tap_kernel(make_tap(u.g.ix, u.g.iy, a.W, a.H), a.W, a.H);
+    const float s0 = sample_k(srcb, t), s1 = sample_k(srcb + HW, t), s2 = sample_k(srcb + 2 * HW, t);
+    FwdAcc acc;
+    const float* Rn = a.plane_aux + (long)b * a.N * 3;
+    for (int n = 0; n < a.N; ++n) {
+      const bool mk = uni_mask(u, Rn + n * 3);
+      float l = 0.0f, s = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+      if (mk) {   // a masked plane samples as all-zero features (trainer.py:580)
+        const long pl = ((long)b * a.N + n) * HW;
+        l = sample_k(a.logits + pl, t);
+        if (MIX) s = sample_k(a.sigma + pl, t);
+        c0 = s0; c1 = s1; c2 = s2;
+      }
+      fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+    }
+    const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask, true);
+    float* st = stash + (long)b * a.stash_k * HW + pix;
+    st[0] = r.lse2; st[HW] = r.Sn; st[2 * HW] = r.mx; st[3 * HW] = r.sel;
+    rgb_rec[((long)b * 3 + 0) * HW + pix] = r.r0;
+    rgb_rec[((long)b * 3 + 1) * HW + pix] = r.r1;
+    rgb_rec[((long)b * 3 + 2) * HW + pix] = r.r2;
+    ph_map[(long)b * HW + pix] = r.ph;
+    ph_val = r.ph;
+  }
+  if (a.ph_mean) {
+    __shared__ float wsum[kBlock / kWave];
+    const float v = wave_sum(ph_val);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tt = 0.0f;
+      for (int w = 0; w < kBlock / kWave; ++w) tt += wsum[w];
+      unsafeAtomicAdd(a.ph_mean, tt * a.inv_numel);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, pass 1: per-plane gradients of the SAMPLED logit / sigma at every target pixel of image b
+// ---------------------------------------------------------------------------------------------------------------
+// Homography gradient.  `plane` is [B,4,3,3]: slice 0 is THE homography; slices 1..3 are the homographies of three
+// virtual planes with n/d = e_0, e_1, e_2 (equal to slice 0 in value when t = 0).  Their gradients are defined as the
+// plane sums weighted with tw[b][n][j] = n_n[j] / d_n:  g[0] = sum_n G_n,  g[1+j] = sum_n G_n tw[n][j].  Autograd through
+// f(R + t e_j^T) then yields exactly dL/dt = sum_n Q_n n_n / d_n of the per-plane formulation (layers.py:216) although
+// only one matrix per image is ever formed (pd_plane_sweep_uniform.hip header; ops.plane_sweep_homography).
+constexpr int kUniG = 4;
+
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, BwdOut o, int b0, float* __restrict__ tmp,
+                                                                   float* __restrict__ partials, const float* __restrict__ tw) {
+  __shared__ float red[kUniG * 9];
+  const int HW = a.H * a.W, N = a.N;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = b0 + blockIdx.y;
+  float* __restrict__ tmp_l = tmp + (long)blockIdx.y * 2 * N * HW;
+  float* __restrict__ tmp_s = tmp_l + (long)N * HW;
+  if (threadIdx.x < kUniG * 9) red[threadIdx.x] = 0.0f;
+  __syncthreads();
+  const bool want_plane = (o.g_plane != nullptr);
+  float gixw[kUniG], giyw[kUniG];
+#pragma unroll
+  for (int j = 0; j < kUniG; ++j) gixw[j] = giyw[j] = 0.0f;
+  float gp_scale0 = 0.0f, p0 = 0.0f, p1 = 0.0f, fxx = 0.0f, fyy = 0.0f;
+  bool zcl = false;
+  if (pix < HW) {
+    const int y = pix / a.W, x = pix - y * a.W;
+    const float* srcb = a.src + (long)b * 3 * HW;
+    const PixelCtx c = make_pixel_ctx<MIX>(a, o, b, pix, HW);
+    const CoordNorm cn = make_coord_norm(a.W, a.H);
+    const UniGeom u = uni_geom(a.plane + (long)b * kUniH, a.inv_K3 + (long)b * 9, cn, x, y);
+    const TapK t = tap_kernel(make_tap(u.g.ix, u.g.iy, a.W, a.H), a.W, a.H);
+    float d0x, d0y, d1x, d1y, d2x, d2y;
+    const float s0 = sample_vg_k(srcb, t, d0x, d0y), s1 = sample_vg_k(srcb + HW, t, d1x, d1y),
+                s2 = sample_vg_k(srcb + 2 * HW, t, d2x, d2y);
+    const float* Rn = a.plane_aux + (long)b * N * 3;
+    const float* twb = tw ? tw + (long)b * N * 3 : nullptr;
+    for (int n = 0; n < N; ++n) {
+      float g_l = 0.0f, g_s = 0.0f;
+      if (uni_mask(u, Rn + n * 3)) {
+        const long pl = ((long)b * N + n) * HW;
+        float dlx = 0.0f, dly = 0.0f, dsx = 0.0f, dsy = 0.0f;
+        float l, s = 0.0f;
+        if (want_plane) {
+          l = sample_vg_k(a.logits + pl, t, dlx, dly);
+          if (MIX) s = sample_vg_k(a.sigma + pl, t, dsx, dsy);
+        } else {
+          l = sample_k(a.logits + pl, t);
+          if (MIX) s = sample_k(a.sigma + pl, t);
+        }
+        const PlaneGrad pg = plane_grad<MIX>(c, l, s, s0, s1, s2);
+        g_l = pg.g_l; g_s = pg.g_s;
+        if (want_plane) {
+          const float gx = pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x;
+          const float gy = pg.g_l * dly + pg.g_s * dsy + pg.gc0 * d0y + pg.gc1 * d1y + pg.gc2 * d2y;
+          gixw[0] += gx; giyw[0] += gy;
+          if (twb) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const float w = twb[n * 3 + j]; gixw[1 + j] += gx * w; giyw[1 + j] += gy * w; }
+          }
+        }
+      }
+      tmp_l[(long)n * HW + pix] = g_l;
+      if (MIX) tmp_s[(long)n * HW + pix] = g_s;
+    }
+    float inv_z = fast_rcp(u.g.zc);
+    inv_z = fmaf(fmaf(-u.g.zc, inv_z, 1.0f), inv_z, inv_z);
+    gp_scale0 = inv_z; p0 = u.g.p0; p1 = u.g.p1; zcl = u.g.z_clamped; fxx = (float)x; fyy = (float)y;
+  }
+  if (want_plane) {   // every lane takes part in the reductions (lanes past the image carry zeros)
+    const float gscale_x = (float)(a.W - 1) / 2 * 2.0f / (float)(a.W - 1), gscale_y = (float)(a.H - 1) / 2 * 2.0f / (float)(a.H - 1);
+    const int ln = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kUniG; ++j) {
+      const float gp0 = gixw[j] * gscale_x * gp_scale0, gp1 = giyw[j] * gscale_y * gp_scale0;
+      const float gz = zcl ? 0.0f : -(gp0 * p0 + gp1 * p1) * gp_scale0;
+      const float gk[9] = {gp0 * fxx, gp0 * fyy, gp0, gp1 * fxx, gp1 * fyy, gp1, gz * fxx, gz * fyy, gz};
+#pragma unroll
+      for (int k = 0; k + 1 < 9; k += 2) {
+        const float v = half_wave_sums_hi(gk[k], gk[k + 1]);
+        if ((ln & 31) == 31) lds_add(&red[j * 9 + k + (ln >> 5)], v);
+      }
+      const float v8 = wave_sum_hi(gk[8]);
+      if (ln == kWave - 1) lds_add(&red[j * 9 + 8], v8);
+    }
+    __syncthreads();
+    if (threadIdx.x < kUniG * 9)
+      partials[((long)b * gridDim.x + blockIdx.x) * (kUniG * 9) + threadIdx.x] = red[threadIdx.x];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, pass 2: gather per SOURCE pixel
+// ---------------------------------------------------------------------------------------------------------------
+struct UniPrep {      // per image: forward homography (source -> target) from an fp64 adjugate
+  float Hs[9];
+  float ok;
+  float pad[2];
+};
+__global__ void uniform_prep_kernel(const float* __restrict__ H_t2s, UniPrep* __restrict__ prep, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float* h = H_t2s + (long)i * kUniH;
+  const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], k = h[7], l = h[8];
+  const double A = e * l - f * k, Bc = -(d * l - f * g), C = d * k - e * g;
+  const double det = a * A + b * Bc + c * C, inv = 1.0 / det;
+  UniPrep p;
+  p.Hs[0] = (float)(A * inv);  p.Hs[1] = (float)(-(b * l - c * k) * inv); p.Hs[2] = (float)((b * f - c * e) * inv);
+  p.Hs[3] = (float)(Bc * inv); p.Hs[4] = (float)((a * l - c * g) * inv);  p.Hs[5] = (float)(-(a * f - c * d) * inv);
+  p.Hs[6] = (float)(C * inv);  p.Hs[7] = (float)(-(a * k - b * g) * inv); p.Hs[8] = (float)((a * e - b * d) * inv);
+  bool ok = (det == det) && fabs(det) > 1e-30 && fabs(inv) < 1e30;
+  for (int j = 0; j < 9; ++j) ok = ok && (fabsf(p.Hs[j]) < 1e30f) && (p.Hs[j] == p.Hs[j]);
+  p.ok = ok ? 1.0f : 0.0f;
+  p.pad[0] = p.pad[1] = 0.0f;   // pad[0] of image 0 doubles as the overflow flag (an int 0)
+  prep[i] = p;
+}
+
+// bilinear weight with which target sample (ix, iy) reaches source pixel (sx, sy): torch's own expressions
+// (x1 - ix) / (ix - x0) for the tap that IS (sx, sy), zero when neither tap column / row is
+__device__ __forceinline__ float tap_weight_on(float ix, float iy, int sx, int sy) {
+  const float xf = floorf(ix), yf = floorf(iy);
+  const float fsx = (float)sx, fsy = (float)sy;
+  float wx = 0.0f, wy = 0.0f;
+  if (xf == fsx) wx = (xf + 1.0f) - ix; else if (xf + 1.0f == fsx) wx = ix - xf;
+  if (yf == fsy) wy = (yf + 1.0f) - iy; else if (yf + 1.0f == fsy) wy = iy - yf;
+  return wx * wy;
+}
+
+// Candidate window of source pixel (sx, sy) in the target view: bounding box of the pre-image of (sx-1, sx+1) x (sy-1, sy+1)
+struct UniWindow { int x0, x1, y0, y1; };
+__device__ __forceinline__ UniWindow uni_window(const UniPrep& p, int sx, int sy, int W, int H) {
+  UniWindow w;
+  w.x0 = 0; w.y0 = 0; w.x1 = W - 1; w.y1 = H - 1;
+  if (p.ok == 0.0f) return w;
+  float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f, wmin = 3.0e38f, wmax = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float x = (float)sx + ((k & 1) ? 1.125f : -1.125f), y = (float)sy + ((k & 2) ? 1.125f : -1.125f);
+    const float uu = p.Hs[0] * x + p.Hs[1] * y + p.Hs[2], vv = p.Hs[3] * x + p.Hs[4] * y + p.Hs[5];
+    const float ww = p.Hs[6] * x + p.Hs[7] * y + p.Hs[8];
+    wmin = fminf(wmin, ww); wmax = fmaxf(wmax, ww);
+    const float r = 1.0f / ww;
+    xmin = fminf(xmin, uu * r); xmax = fmaxf(xmax, uu * r);
+    ymin = fminf(ymin, vv * r); ymax = fmaxf(ymax, vv * r);
+  }
+  const float wabs = fmaxf(fabsf(wmin), fabsf(wmax));
+  if (!(wmin * wmax > 0.0f) || !(fminf(fabsf(wmin), fabsf(wmax)) > 1e-3f * wabs)) return w;   // near the line at infinity
+  if (!(xmin == xmin) || !(xmax == xmax) || !(ymin == ymin) || !(ymax == ymax)) return w;
+  w.x0 = (int)fminf(fmaxf(floorf(xmin - 0.125f), 0.0f), (float)W);
+  w.y0 = (int)fminf(fmaxf(floorf(ymin - 0.125f), 0.0f), (float)H);
+  w.x1 = (int)fminf(fmaxf(ceilf(xmax + 0.125f), -1.0f), (float)(W - 1));
+  w.y1 = (int)fminf(fmaxf(ceilf(ymax + 0.125f), -1.0f), (float)(H - 1));
+  return w;
+}
+
+// OVERFLOW = false: the main kernel; source pixels with more than kUniK contributors are left alone.
+// OVERFLOW = true:  the follow-up kernel; it repeats the scan, returns at once for everybody else and re-scans the
+//                   candidates per plane for those pixels (strong minification only).  Kept out of the main kernel: with the
+//                   re-scan loop inside it the main kernel ran 0.99 instead of 0.58 ms at 8x49x192x640.
+template <bool MIX, bool OVERFLOW>
+__global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
+                                                                   const UniPrep* __restrict__ prep,
+                                                                   float* __restrict__ g_logits, float* __restrict__ g_sigma,
+                                                                   int* __restrict__ overflow_flag) {
+  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
+  const int spix = blockIdx.x * kBlock + threadIdx.x;
+  const int b = b0 + blockIdx.y;
+  if (OVERFLOW && *overflow_flag == 0) return;   // nobody asked for the re-scan: the usual case, no second scan
+  const float* __restrict__ tmp_l = tmp + (long)blockIdx.y * 2 * N * HW;
+  const float* __restrict__ tmp_s = tmp_l + (long)N * HW;
+  if (spix >= HW) return;
+  const int sy = spix / W, sx = spix - sy * W;
+  const CoordNorm cn = make_coord_norm(W, H);
+  const float* Hm = a.plane + (long)b * kUniH;
+  const float* Ki = a.inv_K3 + (long)b * 9;
+  const UniWindow win = uni_window(prep[b], sx, sy, W, H);
+  int idx[kUniK];
+  float wgt[kUniK];
+#pragma unroll
+  for (int k = 0; k < kUniK; ++k) { idx[k] = 0; wgt[k] = 0.0f; }
+  int cnt = 0;
+  for (int ty = win.y0; ty <= win.y1; ++ty)
+    for (int tx = win.x0; tx <= win.x1; ++tx) {
+      const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
+      const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
+      if (w != 0.0f) {
+        // (static indices only: a dynamic index would move the arrays to scratch memory)
+#pragma unroll
+        for (int k = 0; k < kUniK; ++k)
+          if (k == cnt) { idx[k] = ty * W + tx; wgt[k] = w; }
+        ++cnt;
+      }
+    }
+  float* gl = g_logits ? g_logits + (long)b * N * HW + spix : nullptr;
+  float* gs = (MIX && g_sigma) ? g_sigma + (long)b * N * HW + spix : nullptr;
+  if (OVERFLOW) {
+    if (cnt <= kUniK) return;
+    for (int n = 0; n < N; ++n) {
+      const float* tl = tmp_l + (long)n * HW;
+      const float* ts = tmp_s + (long)n * HW;
+      float accl = 0.0f, accs = 0.0f;
+      for (int ty = win.y0; ty <= win.y1; ++ty)
+        for (int tx = win.x0; tx <= win.x1; ++tx) {
+          const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
+          const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
+          if (w != 0.0f) {
+            accl += w * tl[ty * W + tx];
+            if (MIX) accs += w * ts[ty * W + tx];
+          }
+        }
+      if (gl) gl[(long)n * HW] = accl;
+      if (gs) gs[(long)n * HW] = accs;
+    }
+    return;
+  }
+  if (cnt > kUniK) { atomicOr(overflow_flag, 1); return; }   // the follow-up kernel's
+  // Four entries for everybody (a near-isometric map gives four contributors), the rest under a wave-uniform bound:
+  // kmax = the largest list in the wave, so a wave pays for its longest lane only.  (Unused entries: weight 0, index 0.)
+  int kmax = cnt;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, kWave));
+  kmax = __builtin_amdgcn_readfirstlane(kmax);
+#pragma unroll 2
+  for (int n = 0; n < N; ++n) {
+    const float* tl = tmp_l + (long)n * HW;
+    const float* ts = tmp_s + (long)n * HW;
+    float accl = 0.0f, accs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      accl += wgt[k] * tl[idx[k]];
+      if (MIX) accs += wgt[k] * ts[idx[k]];
+    }
+#pragma unroll
+    for (int k = 4; k < kUniK; ++k) {
+      if (k < kmax) {   // wave-uniform
+        accl += wgt[k] * tl[idx[k]];
+        if (MIX) accs += wgt[k] * ts[idx[k]];
+      }
+    }
+    if (gl) gl[(long)n * HW] = accl;
+    if (gs) gs[(long)n * HW] = accs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static size_t ualign4(size_t floats) { return (floats + 3) & ~(size_t)3; }
+
+// images per launch of the two backward passes: enough workgroups to fill the chip, a scratch that still fits the
+// 256 MB memory-side cache (2 x N x H x W floats per image)
+static int uniform_chunk(const pd_sweep_desc* d) {
+  if (const char* e = getenv("PD_UNI_CHUNK")) {
+    const int c = atoi(e);
+    if (c >= 1) return c < d->B ? c : d->B;
+  }
+  const size_t per_image = (size_t)2 * d->N * d->H * d->W * sizeof(float);
+  (void)per_image;   // measured at 8x49x192x640: 1 / 2 / 4 / 8 images per launch -> 2.16 / 1.83 / 1.42 / 0.99 ms: parallelism
+  return d->B;        // beats cache residency, so the whole batch goes in one launch per pass
+}
+
+// workspace: [B][nblk][4*9] partial sums | UniPrep[B] | scratch [chunk][2][N][H][W]
+size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d) {
+  const size_t nblk = (size_t)ceil_div(d->H * d->W, kBlock);
+  return ualign4((size_t)d->B * nblk * kUniG * 9) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float))) +
+         (size_t)uniform_chunk(d) * 2 * d->N * d->H * d->W + 8;
+}
+
+int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
+  dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
+  if (d->flags & PD_MIXTURE) uniform_fwd_kernel<true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
+  else                       uniform_fwd_kernel<false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
+  return check_launch("uniform_fwd_kernel");
+}
+
+// `tw` = a.padding_mask slot: [B][N][3] translation weights n/d, or NULL (no translation gradient wanted)
+int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream) {
+  const int HW = d->H * d->W, nblk = ceil_div(HW, kBlock);
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+  float* partials = reinterpret_cast<float*>(base);
+  UniPrep* prep = reinterpret_cast<UniPrep*>(partials + ualign4((size_t)d->B * nblk * kUniG * 9));
+  float* tmp = reinterpret_cast<float*>(prep) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float)));
+  const float* tw = a.padding_mask;
+  SweepArgs ak = a;
+  ak.padding_mask = nullptr;
+  uniform_prep_kernel<<<ceil_div(d->B, 64), 64, 0, stream>>>(a.plane, prep, d->B);
+  int rc = check_launch("uniform_prep_kernel");
+  int* flag = reinterpret_cast<int*>(&prep[0].pad[0]);   // written 0 by uniform_prep_kernel, set by the main pass 2
+  const int chunk = uniform_chunk(d);
+  for (int b0 = 0; b0 < d->B && !rc; b0 += chunk) {
+    const int nb = (d->B - b0) < chunk ? (d->B - b0) : chunk;
+    dim3 grid(nblk, nb);
+    if (mix) {
+      uniform_bwd_pass1_kernel<true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, partials, tw);
+      uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, flag);
+      uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, flag);
+    } else {
+      uniform_bwd_pass1_kernel<false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, partials, tw);
+      uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, flag);
+      uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, flag);
+    }
+    rc = check_launch("uniform_bwd_pass kernels");
+  }
+  if (rc || !o.g_plane) return rc;
+  return reduce_partials(partials, o.g_plane, nblk, kUniG * 9, d->B, stream);
+}
+
+}  // namespace pd

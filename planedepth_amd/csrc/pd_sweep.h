@@ -268,6 +268,10 @@ size_t rowquad_bwd_workspace_floats(const pd_sweep_desc* d);
 bool tile_bwd_applicable(const pd_sweep_desc* d);
 size_t tile_bwd_workspace_floats(const pd_sweep_desc* d);
 int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+// Plane-uniform homography (pd_plane_sweep_uniform.hip, PD_HOMO_UNIFORM)
+int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
+int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d);
 // partials [B][nblk][M] -> out [B][M], fixed summation order (pd_plane_sweep.hip)
 int reduce_partials(const float* partials, float* out, int nblk, int M, int B, hipStream_t stream);
 

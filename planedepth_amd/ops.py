@@ -78,7 +78,9 @@ class _PlaneSweep(torch.autograd.Function):
             if padding_mask is not None:
                 C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H) if flags & C.PD_MASK_ROWS else (B, N, H, W))
         else:
-            C.require_gpu_tensor("H_t2s", plane, (B * N, 3, 3))
+            C.require_gpu_tensor("H_t2s", plane, (B, 4, 3, 3) if flags & C.PD_HOMO_UNIFORM else (B * N, 3, 3))
+            if flags & C.PD_HOMO_UNIFORM and padding_mask is not None:
+                C.require_gpu_tensor("translation weights", padding_mask, (B, N, 3))
             C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
             C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
         if flags & C.PD_RENDER_PROB:
@@ -220,18 +222,42 @@ def homography_matrices(d, n, T, K, inv_K):
 
 
 def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
-                           automask=False, render_probability=False, dists=None, return_mean=False):
+                           automask=False, render_probability=False, dists=None, return_mean=False, plane_uniform=False):
     """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
 
     distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
+
+    ``plane_uniform=True`` is the caller's promise that T has ZERO translation (what Trainer.predict_poses produces for
+    the novel frames without COLMAP, trainer.py:386-400): K (R + t n^T/d) K^-1 is then the same matrix for every plane,
+    so ONE homography per image is formed (from plane 0's d, n — they drop out) and the plane-uniform kernels run
+    (geometry once per pixel, atomic-free backward).  The facing test keeps its per-plane normals.
     """
     B, N, H, W = logits.shape
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
-    H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
     inv_K3 = inv_K[:, :3, :3]
-    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach(),
-                            inv_K3.detach(), None, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
-                            _flags(use_mixture_loss, automask, render=render_probability), 0.0)
+    flags = _flags(use_mixture_loss, automask, render=render_probability)
+    tw = None
+    if plane_uniform and not render_probability:
+        # One matrix per image (slice 0, layers.py:216-218 for plane 0 with the — zero — translation detached) plus the
+        # homographies of three virtual planes n/d = e_j that carry the translation's gradient (include/planedepth_hip.h,
+        # PD_HOMO_UNIFORM): dL/dt = sum_j <sum_n G_n n_n[j]/d_n, d f(R + t e_j^T)/dt> is the per-plane formulation's.
+        Rm, t = T[:, :3, :3], T[:, :3, 3:4]
+        K3 = K[:, :3, :3]
+        f = lambda M: torch.inverse(torch.matmul(K3, torch.matmul(M, inv_K3)))  # noqa: E731
+        n0 = norm[:, 0].reshape(B, 1, 3)
+        mats = [f(Rm + torch.matmul(t.detach(), n0) / distance[:, 0].reshape(B, 1, 1))]
+        eye = torch.eye(3, device=T.device, dtype=T.dtype)
+        mats += [f(Rm.detach() + torch.matmul(t, eye[j].reshape(1, 1, 3))) for j in range(3)]
+        H_t2s = torch.stack(mats, 1)                                                       # [B,4,3,3]
+        with torch.no_grad():
+            Rn = torch.matmul(Rm[:, None], norm.reshape(B, N, 3, 1))[..., 0].reshape(B * N, 3)
+            tw = (norm / distance[..., None]).contiguous()                                # [B,N,3]
+        flags |= C.PD_HOMO_UNIFORM
+    else:
+        H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
+    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach().contiguous(),
+                            inv_K3.detach(), tw, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
+                            flags, 0.0)
     return out if return_mean else out[:2]
 
 

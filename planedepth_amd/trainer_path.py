@@ -95,11 +95,18 @@ def pred_novel_images(self, inputs, outputs):
                                  render_probability=render, dists=dists)
         elif opt.warp_type == "homography_warp":
             T = outputs[("Rt", target_side)]
+            # Novel frames without COLMAP: predict_poses leaves the translation at zero (trainer.py:386-400, only
+            # `if self.opt.use_colmap` writes it), so one homography serves all planes of an image.
+            uniform = (target_side != "r" and not getattr(opt, "use_colmap", False) and not render
+                       and getattr(opt, "pd_uniform_homography", True))
+            if uniform and (getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT")):
+                if not bool((T[:, :3, 3] == 0).all()):
+                    raise ValueError("outputs[('Rt', %r)] has a translation although opt.use_colmap is off" % (target_side,))
             rgb_rec, ph_map, ph_mean = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma,
                                                                   outputs["distance"], outputs["norm"], T, inputs["K"],
                                                                   inputs["inv_K"], use_mixture_loss=mix,
                                                                   automask=automask, render_probability=render,
-                                                                  dists=dists, return_mean=True)
+                                                                  dists=dists, return_mean=True, plane_uniform=uniform)
             with torch.no_grad():
                 ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
                 H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),

@@ -1041,3 +1041,68 @@ def test_on_device_grid_is_bit_identical_to_the_reference_pipeline():
     for k in ("K", "inv_K", ("Rt", "l"), ("Rt", "r")):   # deterministic parts agree exactly with the CPU pipeline
         assert torch.equal(dev[k].cpu(), cpu[k]), k
     assert float((dev["grid"].cpu() - cpu["grid"]).abs().max()) <= 1.2e-7
+
+
+def _f8_pose(B, seed, rot=0.02, device="cpu"):
+    """Rt as Trainer.predict_poses leaves it for a novel frame without COLMAP (trainer.py:386-400): a rotation
+    conjugated by a crop matrix, ZERO translation, Rt[3,3] = 0."""
+    from planedepth_amd.synthetic import small_pose
+    g = torch.Generator().manual_seed(seed)
+    R = small_pose(g, B, rot=rot, trans=0.0)[:, :3, :3]
+    Rc = torch.eye(3)[None].repeat(B, 1, 1)
+    Rc[:, 0, 2] = torch.randn(B, generator=g) * 0.05
+    Rc[:, 1, 2] = torch.randn(B, generator=g) * 0.05
+    Rc[:, 2, 2] = 0.7 + 0.3 * torch.rand(B, generator=g)
+    Rt = torch.zeros(B, 4, 4)
+    Rt[:, :3, :3] = Rc @ R @ torch.inverse(Rc)
+    return Rt.to(device)
+
+
+@pytest.mark.parametrize("B,N,H,W,mix,automask,rot,zoom", [
+    (2, 7, 24, 80, True, True, 0.02, 1.0), (1, 9, 33, 70, True, False, 0.15, 1.0), (2, 5, 40, 150, False, True, 0.05, 1.0),
+    (1, 3, 5, 7, True, False, 0.3, 1.0), (1, 63, 192, 640, True, True, 0.01, 1.0),
+    (1, 4, 30, 90, True, False, 0.05, 2.6),     # target 2.6x denser than the source: ~27 contributors per source pixel
+    (1, 4, 30, 90, True, False, 0.05, 0.45)])   # the other way round: most source pixels get none
+def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix, automask, rot, zoom):
+    """PD_HOMO_UNIFORM (pd_plane_sweep_uniform.hip: geometry once per pixel, two-pass atomic-free backward) against the
+    general kernels on poses shaped like predict_poses' output (zero translation): one homography per image, planes with
+    two different normals (the facing test still differs per plane), rotations up to 17 degrees, ragged sizes, and
+    zooms that push the per-source-pixel gather list past its 8 register slots (the follow-up re-scan kernel)."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(900 + W + N)
+    dev = "cuda"
+    src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    logits = torch.randn(B, N, H, W, generator=g).to(dev)
+    sigma = (0.011 + 0.978 * torch.rand(B, N, H, W, generator=g)).to(dev)
+    gw = (torch.randn(B, 3, H, W, generator=g) * 0.1).to(dev)
+    distance = (0.5 + 5 * torch.rand(B, N, generator=g)).to(dev)
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1)
+    norm[:, N // 2:] = torch.nn.functional.normalize(torch.tensor([0.0, 1.0, 0.07]), dim=0)   # "xz planes"
+    norm = norm.to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    res = {}
+    for uniform in (True, False):
+        lg, sg = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+        Rt = _f8_pose(B, 31 + H, rot, dev)
+        Rt[:, :2, :3] *= zoom              # not a rotation any more: the kernels take whatever the 3x3 block holds
+        Rt.requires_grad_(True)
+        dd = distance.clone().requires_grad_(True)
+        rgb, ph, ph_mean = ops.plane_sweep_homography(src, tgt, lg, sg if mix else None, dd, norm, Rt, K, inv_K,
+                                                      use_mixture_loss=mix, automask=automask, return_mean=True,
+                                                      plane_uniform=uniform)
+        (ph_mean * 2.0 + (rgb * gw).sum()).backward()
+        res[uniform] = dict(rgb=rgb.detach().cpu(), ph=ph.detach().cpu(), g_logits=lg.grad.cpu(), g_Rt=Rt.grad.cpu(),
+                            g_sigma=sg.grad.cpu() if mix else torch.zeros(1),
+                            g_dist=(dd.grad if dd.grad is not None else torch.zeros_like(dd)).cpu())
+    u, gen = res[True], res[False]
+    assert float(gen["g_logits"].abs().max()) > 0
+    assert torch.equal(u["rgb"], gen["rgb"]) or rel_err(u["rgb"], gen["rgb"]) < 2e-6
+    assert rel_err(u["ph"], gen["ph"]) < 2e-6
+    assert rel_err(u["g_logits"], gen["g_logits"]) < 3e-6, rel_err(u["g_logits"], gen["g_logits"])
+    if mix:
+        assert rel_err(u["g_sigma"], gen["g_sigma"]) < 3e-6, rel_err(u["g_sigma"], gen["g_sigma"])
+    # rotation block AND translation column (the weighted plane sums of PD_HOMO_UNIFORM); sums in a different order
+    assert rel_err(u["g_Rt"][:, :3, :3], gen["g_Rt"][:, :3, :3]) < 2e-4, rel_err(u["g_Rt"][:, :3, :3], gen["g_Rt"][:, :3, :3])
+    assert rel_err(u["g_Rt"][:, :3, 3], gen["g_Rt"][:, :3, 3]) < 2e-4, rel_err(u["g_Rt"][:, :3, 3], gen["g_Rt"][:, :3, 3])
+    assert float(u["g_dist"].abs().max()) == 0.0 and float(gen["g_dist"].abs().max()) < 1e-6   # t = 0: exactly no gradient
