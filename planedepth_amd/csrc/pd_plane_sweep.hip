@@ -486,7 +486,12 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
     if (hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
   }
   if (wants_rowshift(d) && rowshift_applicable(d)) {
-    if (rowquad_applicable(d, a.has_mask != 0)) return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
+    // The wide-access kernels (2 / 4 pixels per lane) are correct (tests/test_gpu_parity.py::test_rowquad_*) and their
+    // forward is faster in an isolated launch loop (0.109 vs 0.127 ms), but INSIDE the training step it is slower
+    // (0.149 vs 0.132 ms, 300-step A/B on one box: 20.9 k vs 21.4 k images/s): without row pairs it re-reads 10 % more
+    // while the memory system is still draining the backward's gradient writes.  Opt-in: PD_QUAD_FWD / PD_QUAD_BWD.
+    if (rowquad_applicable(d, a.has_mask != 0) && getenv("PD_QUAD_FWD"))
+      return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   }
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM))
@@ -520,8 +525,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
   if (wants_rowshift(d) && rowshift_applicable(d)) {
     PD_REQUIRE(workspace, "the row-shift backward needs workspace (pd_sweep_bwd_workspace_floats)");
-    // the wide-access backward is correct (tests/test_gpu_parity.py::test_rowquad_*) but not yet faster than the
-    // one-pixel-per-lane one: opt-in
+    // same VALU work per pixel as the one-pixel-per-lane backward (which is VALU-bound), lower occupancy: slower. Opt-in.
     if (rowquad_applicable(d, ak.has_mask != 0) && getenv("PD_QUAD_BWD")) return rowquad_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
   }

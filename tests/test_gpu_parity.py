@@ -943,7 +943,8 @@ def test_rowquad_kernels_equal_rowshift_kernels(W, H, N, side, kw, mix, automask
     kw = dict(kw)
     kw.setdefault("disp_min", 0.5)
     kw.setdefault("disp_max", 9.0)
-    if quad_bwd:   # the wide-access backward is opt-in (PD_QUAD_BWD); the forward is the default one
+    monkeypatch.setenv("PD_QUAD_FWD", "1")     # the wide-access kernels are opt-in
+    if quad_bwd:
         monkeypatch.setenv("PD_QUAD_BWD", "1")
     else:
         monkeypatch.delenv("PD_QUAD_BWD", raising=False)
@@ -953,6 +954,8 @@ def test_rowquad_kernels_equal_rowshift_kernels(W, H, N, side, kw, mix, automask
     run = dict(target_side=side, use_mixture_loss=mix, automask=automask)
     extra = dict(yz_levels=0, xz_levels=kw.get("n_xz", 0))
     quad = run_product(case, run, opt_extra=extra)
+    monkeypatch.delenv("PD_QUAD_FWD", raising=False)
+    monkeypatch.delenv("PD_QUAD_BWD", raising=False)
     ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
     try:
         one = run_product(case, run, opt_extra=extra)
