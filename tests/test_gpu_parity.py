@@ -1066,13 +1066,18 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     (1, 3, 5, 7, True, False, 0.3, 1.0), (1, 63, 192, 640, True, True, 0.01, 1.0),
     (1, 4, 30, 90, True, False, 0.05, 2.6),     # target 2.6x denser than the source: ~27 contributors per source pixel
     (1, 4, 30, 90, True, False, 0.05, 0.45)])   # the other way round: most source pixels get none
-def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix, automask, rot, zoom):
+@pytest.mark.parametrize("fused", [False, True])
+def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix, automask, rot, zoom, fused, monkeypatch):
     """PD_HOMO_UNIFORM (pd_plane_sweep_uniform.hip: geometry once per pixel, two-pass atomic-free backward) against the
     general kernels on poses shaped like predict_poses' output (zero translation): one homography per image, planes with
     two different normals (the facing test still differs per plane), rotations up to 17 degrees, ragged sizes, and
     zooms that push the per-source-pixel gather list past its 8 register slots (the follow-up re-scan kernel)."""
     from planedepth_amd import ops
     from planedepth_amd.synthetic import intrinsics
+    if fused:   # the LDS hand-over form of the backward (opt-in); irregular launches fall through to the two-pass kernels
+        monkeypatch.setenv("PD_UNI_FUSED", "1")
+    else:
+        monkeypatch.delenv("PD_UNI_FUSED", raising=False)
     g = torch.Generator().manual_seed(900 + W + N)
     dev = "cuda"
     src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
