@@ -44,6 +44,12 @@ def parse():
     ap.add_argument("--mono_pose", action="store_true",
                     help="homography_warp only: the pose of a novel frame as Trainer.predict_poses produces it without "
                          "COLMAP (BASELINE configs[3]: pose_net): small rotation, zero translation, Rt[3,3] = 0")
+    ap.add_argument("--hip_graph", action="store_true",
+                    help="capture one step (forward + backward, every launch of it) in a HIP graph and time replays: "
+                         "takes the host-side launch cost of the small torch operators around the sweep out of the step")
+    ap.add_argument("--general_stereo", action="store_true",
+                    help="homography_warp, stereo target: keep the general per-plane-homography kernels instead of the "
+                         "per-row-shift form the stereo extrinsic allows (opt.pd_stereo_rows = False)")
     ap.add_argument("--colmap_pose", action="store_true",
                     help="homography_warp only: small rotation + translation per image (--use_colmap poses): a "
                          "different homography per plane, every sample with 4 live taps")
@@ -103,6 +109,7 @@ def build_step(args, c, device):
     # plane-uniform kernels; --colmap_pose: a novel frame with a translation (opt.use_colmap) -> the general kernels
     side = -1 if (args.mono_pose or args.colmap_pose) else "r"
     opt.use_colmap = bool(args.colmap_pose)
+    opt.pd_stereo_rows = not args.general_stereo
     ns = types.SimpleNamespace(opt=opt, target_sides=[side], perceptual_loss=lambda *a, **k: zero)
     inputs = {("color", "l"): c["color_l"], ("color", side): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
     norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
@@ -160,6 +167,8 @@ def kernel_times(args, c, device, iters):
     mix = not args.no_mixture
     if args.xz_levels:
         return None  # direct-launch timing is wired for the xy-plane configurations only
+    if args.warp_type == "homography_warp" and not (args.mono_pose or args.colmap_pose or args.general_stereo):
+        return None  # stereo target: runs as per-row shifts on the row-shift kernels; the in-step events time those
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
     pm = None
     aux = k3 = None
@@ -542,6 +551,22 @@ def main():
 
     c = make_batch(args, device, seed=rank)  # every rank draws its own shard: no data-path collective
     step, _ = build_step(args, c, device)
+    eager_step = step
+    if args.hip_graph:
+        # whole-step capture (the pattern torch documents for graphs with a backward): warm up on a side stream so every
+        # lazy initialisation (workspace sizes, kernel attributes, rocSOLVER handles) has happened, then record one
+        # step; the product's launches go to torch's current stream, which is the capturing one.
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        step = graph.replay
 
     for _ in range(args.warmup):
         step()
@@ -557,10 +582,12 @@ def main():
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
         "config": {"workload": "BASELINE configs[1]: %s, %s, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
                                % (args.warp_type, "mono pose (pose_net: rotation only, F8)" if args.mono_pose
-                                  else ("colmap pose (rotation + translation)" if args.colmap_pose else "stereo target r"), "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
+                                  else ("colmap pose (rotation + translation)" if args.colmap_pose else
+                                        ("stereo target r" + (" as per-row shifts (row-shift kernels)" if args.warp_type == "homography_warp" and not args.general_stereo else ""))), "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
                                   args.height, args.width, args.planes + args.xz_levels),
                    "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
                    "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
@@ -574,7 +601,7 @@ def main():
                           else "one per rank"}
     if rank == 0:
         iso = kernel_times(args, c, device, iters=max(10, min(args.steps, 50)))
-        kt = in_step_kernel_times(step, device, iters=max(10, min(args.steps, 50)))   # the figure the roofline uses
+        kt = in_step_kernel_times(eager_step, device, iters=max(10, min(args.steps, 50)))   # the figure the roofline uses
         if kt:
             fwd_b, bwd_b = algorithmic_bytes(args)
             dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"

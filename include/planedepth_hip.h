@@ -254,6 +254,31 @@ int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other
 int pd_crop_grid(int B, int H, int W, const int32_t* params, float* grid, pd_stream_t stream);
 
 /*
+ * The O(B*N) 3x3 algebra of HomographyWarp.forward (layers.py:206-219, 223-225) and its adjoint, one launch each:
+ *   M = R + t n^T / d;  H_t2s = inverse(K M K^-1);  Rn = R n          (R, t from T [B,4,4]; K, inv_K [B,4,4])
+ * evaluated in fp64 and rounded once to fp32.  distance [B,N], norm [B,N,3].
+ *   PD_HMAT_PLANES       H_t2s [B,N,3,3], Rn [B,N,3]
+ *   PD_HMAT_UNIFORM      zero-translation poses (trainer.py:386-400): H_t2s [B,4,3,3] in the PD_HOMO_UNIFORM layout
+ *                        (slice 0: plane 0 with the translation detached; slices 1..3: virtual planes n/d = e_j with the
+ *                        rotation detached), Rn [B,N,3]
+ *   PD_HMAT_STEREO_ROWS  identity rotation, x translation, normals without x component (mono_dataset.py:203-211,
+ *                        depth_decoder.py:153-207): shift [B,N,rows] = h01*y + h02 in pixels and mask [B,N,rows] =
+ *                        facing test && z > 1e-7 (layers.py:223-225) per (plane, row): the inputs of the disp_warp sweep
+ *                        with PD_DISP_ROWS | PD_MASK_ROWS.  H_t2s and Rn may be NULL.
+ * Backward: g_H in the forward's H_t2s layout (may be NULL in PD_HMAT_STEREO_ROWS) and/or g_shift [B,N,rows];
+ * g_distance [B,N], g_norm [B,N,3], g_T [B,4,4] (rows 0..2; row 3 zero) — each may be NULL.  K and inv_K get none (the
+ * reference's are dataset constants).  In PD_HMAT_STEREO_ROWS only g_distance is meaningful (h00 is not part of the
+ * shift, so the pose / normal derivatives are incomplete).
+ */
+enum pd_hmat_mode { PD_HMAT_PLANES = 0, PD_HMAT_UNIFORM = 1, PD_HMAT_STEREO_ROWS = 2 };
+int pd_homography_matrices_fwd(int B, int N, int mode, int rows, const float* distance, const float* norm, const float* T,
+                               const float* K, const float* inv_K, float* H_t2s, float* Rn, float* shift, float* mask,
+                               pd_stream_t stream);
+int pd_homography_matrices_bwd(int B, int N, int mode, int rows, const float* distance, const float* norm, const float* T,
+                               const float* K, const float* inv_K, const float* g_H, const float* g_shift,
+                               float* g_distance, float* g_norm, float* g_T, pd_stream_t stream);
+
+/*
  * Geometry modules.
  *   pd_backproject     BackprojectDepth.forward, layers.py:150-156: depth [B,1,H,W], inv_K [B,4,4] -> cam [B,4,H*W]
  *   pd_backproject_bwd g_cam [B,4,H*W] -> g_depth [B,1,H,W]

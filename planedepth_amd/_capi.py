@@ -16,6 +16,7 @@ PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_RO
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
+PD_HMAT_PLANES, PD_HMAT_UNIFORM, PD_HMAT_STEREO_ROWS = 0, 1, 2
 PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1 = 0, 1, 2, 3, 4
 
 
@@ -58,6 +59,8 @@ SIGNATURES = {
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
+    "pd_homography_matrices_fwd": (_I, [_I] * 4 + [_P] * 10),
+    "pd_homography_matrices_bwd": (_I, [_I] * 4 + [_P] * 11),
     "pd_backproject": (_I, [_I] * 3 + [_P] * 4),
     "pd_backproject_bwd": (_I, [_I] * 3 + [_P] * 4),
     "pd_project3d": (_I, [_I] * 3 + [_F] + [_P] * 4),

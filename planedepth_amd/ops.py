@@ -221,8 +221,78 @@ def homography_matrices(d, n, T, K, inv_K):
     return H_t2s, Rn
 
 
+class _HomographyMatrices(torch.autograd.Function):
+    """pd_homography_matrices_fwd/bwd: (distance [B,N], norm [B,N,3], T, K, inv_K [B,4,4]) -> per ``mode``
+    (H_t2s, Rn) or (shift, mask, Rn).  Gradients to distance, norm and T."""
+
+    @staticmethod
+    def forward(ctx, distance, norm, T, K, inv_K, mode, rows):
+        lib = C.load()
+        B, N = distance.shape
+        dev = distance.device
+        distance, norm, T, K, inv_K = (_contig(t.detach().float()) for t in (distance, norm, T, K, inv_K))
+        for name, t, shape in (("distance", distance, (B, N)), ("norm", norm, (B, N, 3)), ("T", T, (B, 4, 4)),
+                               ("K", K, (B, 4, 4)), ("inv_K", inv_K, (B, 4, 4))):
+            C.require_gpu_tensor(name, t, shape)
+        Rn = torch.empty(B, N, 3, device=dev)
+        Hm = shift = mask = None
+        if mode == C.PD_HMAT_STEREO_ROWS:
+            shift, mask = torch.empty(B, N, rows, device=dev), torch.empty(B, N, rows, device=dev)
+        else:
+            Hm = torch.empty(B, 4 if mode == C.PD_HMAT_UNIFORM else N, 3, 3, device=dev)
+        with torch.cuda.device(dev):
+            C.check(lib.pd_homography_matrices_fwd(B, N, mode, rows, C.ptr(distance), C.ptr(norm), C.ptr(T), C.ptr(K),
+                                                   C.ptr(inv_K), C.ptr(Hm), C.ptr(Rn), C.ptr(shift), C.ptr(mask),
+                                                   C.stream_handle(dev)), "pd_homography_matrices_fwd")
+        ctx.save_for_backward(distance, norm, T, K, inv_K)
+        ctx.mode, ctx.rows = mode, rows
+        ctx.mark_non_differentiable(Rn)
+        if mode == C.PD_HMAT_STEREO_ROWS:
+            ctx.mark_non_differentiable(mask)
+            return shift, mask, Rn
+        return Hm, Rn
+
+    @staticmethod
+    def backward(ctx, g_first, *_):
+        lib = C.load()
+        distance, norm, T, K, inv_K = ctx.saved_tensors
+        B, N = distance.shape
+        dev = distance.device
+        need_d, need_n, need_T = ctx.needs_input_grad[:3]
+        stereo = ctx.mode == C.PD_HMAT_STEREO_ROWS
+        if stereo and (need_n or need_T):
+            raise RuntimeError("PD_HMAT_STEREO_ROWS carries the gradient of `distance` only (h00 is not part of the "
+                               "per-row shift); use PD_HMAT_PLANES when the pose or the normals need gradients")
+        g_first = _contig(g_first.float())
+        gd = torch.empty(B, N, device=dev) if need_d else None
+        gn = torch.empty(B, N, 3, device=dev) if need_n else None
+        gT = torch.empty(B, 4, 4, device=dev) if need_T else None
+        with torch.cuda.device(dev):
+            C.check(lib.pd_homography_matrices_bwd(B, N, ctx.mode, ctx.rows, C.ptr(distance), C.ptr(norm), C.ptr(T),
+                                                   C.ptr(K), C.ptr(inv_K), C.ptr(None if stereo else g_first),
+                                                   C.ptr(g_first if stereo else None), C.ptr(gd), C.ptr(gn), C.ptr(gT),
+                                                   C.stream_handle(dev)), "pd_homography_matrices_bwd")
+        return gd, gn, gT, None, None, None, None
+
+
+def homography_matrices_fused(distance, norm, T, K, inv_K, mode=C.PD_HMAT_PLANES, rows=0):
+    """layers.py:206-219, 223-225 in one launch (fp64 inside, rounded once): see include/planedepth_hip.h,
+    ``pd_homography_matrices_fwd``.  distance [B,N], norm [B,N,3], T / K / inv_K [B,4,4] (NOT expanded over planes).
+    Returns (H_t2s, Rn) — [B,N,3,3] or, PD_HMAT_UNIFORM, [B,4,3,3] — or (shift, mask, Rn) for PD_HMAT_STEREO_ROWS."""
+    B, N = distance.shape
+    if tuple(norm.shape) != (B, N, 3):
+        norm = norm.expand(B, N, 3)
+    return _HomographyMatrices.apply(distance, norm, T, K, inv_K, int(mode), int(rows))
+
+
+# PD_TORCH_HOMOGRAPHY=1: form the matrices with the stock torch chain (homography_matrices above: torch.inverse and its
+# rounding, ~12 launches + rocSOLVER, not graph-capturable) instead of pd_homography_matrices_fwd/bwd
+TORCH_HOMOGRAPHY = bool(int(os.environ.get("PD_TORCH_HOMOGRAPHY", "0")))
+
+
 def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
-                           automask=False, render_probability=False, dists=None, return_mean=False, plane_uniform=False):
+                           automask=False, render_probability=False, dists=None, return_mean=False, plane_uniform=False,
+                           stereo_rows=False):
     """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
 
     distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
@@ -231,8 +301,20 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     the novel frames without COLMAP, trainer.py:386-400): K (R + t n^T/d) K^-1 is then the same matrix for every plane,
     so ONE homography per image is formed (from plane 0's d, n — they drop out) and the plane-uniform kernels run
     (geometry once per pixel, atomic-free backward).  The facing test keeps its per-plane normals.
+
+    ``stereo_rows=True`` is the caller's promise that T is the dataset's stereo extrinsic (identity rotation, translation
+    along x only: datasets/mono_dataset.py:203-211) and that no plane normal has an x component (xy and xz planes,
+    networks/depth_decoder.py:153-207).  K (I + t n^T/d) K^-1 then differs from the identity in h01 and h02 only: the
+    warp is a horizontal shift ``h01*y + h02`` per (plane, row) and the facing test is constant along x, i.e. exactly
+    the ``disp_warp`` sweep with per-row disparities and a per-row mask, which runs on the row-shift kernels (no
+    atomics).  H_t2s is still formed by the reference's chain (torch.inverse and all) and autograd carries the
+    gradient of the shifts back into ``distance``; it is NOT taken when T or norm require gradients (their
+    derivatives need h00 as well).
     """
     B, N, H, W = logits.shape
+    if stereo_rows and not render_probability and not T.requires_grad and not norm.requires_grad:
+        return _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, use_mixture_loss, automask,
+                                  return_mean)
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
     inv_K3 = inv_K[:, :3, :3]
     flags = _flags(use_mixture_loss, automask, render=render_probability)
@@ -241,25 +323,55 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
         # One matrix per image (slice 0, layers.py:216-218 for plane 0 with the — zero — translation detached) plus the
         # homographies of three virtual planes n/d = e_j that carry the translation's gradient (include/planedepth_hip.h,
         # PD_HOMO_UNIFORM): dL/dt = sum_j <sum_n G_n n_n[j]/d_n, d f(R + t e_j^T)/dt> is the per-plane formulation's.
-        Rm, t = T[:, :3, :3], T[:, :3, 3:4]
-        K3 = K[:, :3, :3]
-        n0 = norm[:, 0].reshape(B, 1, 3)
-        eye = torch.eye(3, device=T.device, dtype=T.dtype)
-        # [B,4,3,3] in one batch (one inverse, two matmuls: the per-call launch overhead of four separate chains cost
-        # 0.5 ms per step): slice 0 = R + t_detached n0^T / d0, slices 1..3 = R_detached + t e_j^T
-        Rtnd = torch.cat([(Rm + torch.matmul(t.detach(), n0) / distance[:, 0].reshape(B, 1, 1))[:, None],
-                          Rm.detach()[:, None] + t[:, None] * eye.reshape(1, 3, 1, 3)], 1)
-        H_t2s = torch.inverse(torch.matmul(K3[:, None], torch.matmul(Rtnd, inv_K3[:, None])))           # [B,4,3,3]
+        if TORCH_HOMOGRAPHY:
+            Rm, t = T[:, :3, :3], T[:, :3, 3:4]
+            K3 = K[:, :3, :3]
+            n0 = norm[:, 0].reshape(B, 1, 3)
+            eye = torch.eye(3, device=T.device, dtype=T.dtype)
+            # [B,4,3,3] in one batch: slice 0 = R + t_detached n0^T / d0, slices 1..3 = R_detached + t e_j^T
+            Rtnd = torch.cat([(Rm + torch.matmul(t.detach(), n0) / distance[:, 0].reshape(B, 1, 1))[:, None],
+                              Rm.detach()[:, None] + t[:, None] * eye.reshape(1, 3, 1, 3)], 1)
+            H_t2s = torch.inverse(torch.matmul(K3[:, None], torch.matmul(Rtnd, inv_K3[:, None])))       # [B,4,3,3]
+            with torch.no_grad():
+                Rn = torch.matmul(Rm[:, None], norm.reshape(B, N, 3, 1))[..., 0].reshape(B * N, 3)
+        else:
+            H_t2s, Rn = homography_matrices_fused(distance.detach(), norm.detach(), T, K, inv_K, C.PD_HMAT_UNIFORM)
+            Rn = Rn.reshape(B * N, 3)
         with torch.no_grad():
-            Rn = torch.matmul(Rm[:, None], norm.reshape(B, N, 3, 1))[..., 0].reshape(B * N, 3)
             tw = (norm / distance[..., None]).contiguous()                                # [B,N,3]
         flags |= C.PD_HOMO_UNIFORM
-    else:
+    elif TORCH_HOMOGRAPHY:
         H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
+    else:
+        H_t2s, Rn = homography_matrices_fused(distance, norm, T, K, inv_K)
+        H_t2s, Rn = H_t2s.reshape(B * N, 3, 3), Rn.reshape(B * N, 3)
     out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach().contiguous(),
                             inv_K3.detach(), tw, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
                             flags, 0.0)
     return out if return_mean else out[:2]
+
+
+def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean):
+    B, N, H, W = logits.shape
+    if TORCH_HOMOGRAPHY:
+        ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+        H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
+        Hm = H_t2s.reshape(B, N, 3, 3)
+        y = torch.arange(H, device=logits.device, dtype=torch.float32).reshape(1, 1, H)
+        # layers.py:219, 227-229 at h00 = 1, z = 1 (they differ from 1 by the inverse's rounding, <= 2e-7 * W pixels:
+        # the same order as one ulp of the coordinate itself)
+        shift = Hm[:, :, 0, 1, None] * y + Hm[:, :, 0, 2, None]                            # [B,N,H] pixels
+        with torch.no_grad():
+            ik = inv_K[:, :3, :3]
+            ray = ik[:, None, :, 1, None] * y[..., None, :] + ik[:, None, :, 2, None]       # [B,1,3,H]: inv_K (0, y, 1)^T
+            facing = (ray * Rn.reshape(B, N, 3, 1)).sum(2) > 0.0                            # layers.py:223 (Rn_x = 0)
+            z = Hm[:, :, 2, 1, None] * y + Hm[:, :, 2, 2, None]
+            mask = (facing & (z > 1e-7)).float()                                            # layers.py:224-225
+    else:
+        shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
+    return plane_sweep_disp(src, tgt, logits, sigma, shift[..., None].expand(B, N, H, W),
+                            mask[..., None].expand(B, N, H, W), target_side="r", use_mixture_loss=mix,
+                            automask=automask, row_uniform=True, return_mean=return_mean)
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",

@@ -37,7 +37,10 @@ class SweepHandle:
 
     def layers(self):
         if self._cache is None:
-            self._cache = ops.plane_sweep_layers(**self._kw)
+            kw = dict(self._kw)
+            if callable(kw.get("homography")):   # the 3x3 algebra is only redone when somebody asks for the layers
+                kw["homography"] = kw["homography"]()
+            self._cache = ops.plane_sweep_layers(**kw)
         return self._cache
 
     def __getitem__(self, key):
@@ -102,17 +105,33 @@ def pred_novel_images(self, inputs, outputs):
             if uniform and (getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT")):
                 if not bool((T[:, :3, 3] == 0).all()):
                     raise ValueError("outputs[('Rt', %r)] has a translation although opt.use_colmap is off" % (target_side,))
+            # The stereo side: inputs[("Rt", "r")] is the dataset's pure x-translation (mono_dataset.py:203-211, copied
+            # to outputs at trainer.py:364) and xy / xz planes have no x component in their normals, so the warp is a
+            # per-row horizontal shift and runs on the row-shift kernels.
+            stereo_rows = (target_side in ("l", "r") and row_uniform and not render
+                           and getattr(opt, "pd_stereo_rows", True))
+            if stereo_rows and (getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT")):
+                eye = torch.eye(3, device=T.device, dtype=T.dtype)
+                if not (bool((T[:, :3, :3] == eye).all()) and bool((T[:, 1:3, 3] == 0).all())
+                        and bool((outputs["norm"][..., 0] == 0).all())):
+                    raise ValueError("outputs[('Rt', %r)] is not a pure x-translation, or a plane normal has an x "
+                                     "component although opt.yz_levels == 0" % (target_side,))
             rgb_rec, ph_map, ph_mean = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma,
                                                                   outputs["distance"], outputs["norm"], T, inputs["K"],
                                                                   inputs["inv_K"], use_mixture_loss=mix,
                                                                   automask=automask, render_probability=render,
-                                                                  dists=dists, return_mean=True, plane_uniform=uniform)
-            with torch.no_grad():
-                ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
-                H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
-                                                    ex(inputs["inv_K"]))
-            handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma,
-                                 homography=(H_t2s, Rn, inputs["inv_K"][:, :3, :3]), use_mixture_loss=mix,
+                                                                  dists=dists, return_mean=True, plane_uniform=uniform,
+                                                                  stereo_rows=stereo_rows)
+
+            def matrices(T=T):
+                with torch.no_grad():
+                    ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+                    H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
+                                                        ex(inputs["inv_K"]))
+                return H_t2s, Rn, inputs["inv_K"][:, :3, :3]
+
+            handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, homography=matrices,
+                                 use_mixture_loss=mix,
                                  render_probability=render, dists=dists)
         else:
             raise NotImplementedError("warp_type %r: the reference's depth_warp branch raises UnboundLocalError "

@@ -75,7 +75,7 @@ def make_stub_trainer(opt, target_sides, device="cuda"):
     return StubTrainer()
 
 
-def run_product_trainer(z, meta, device="cuda", impl=None):
+def run_product_trainer(z, meta, device="cuda", impl=None, stereo_constant=False):
     """tests/golden/trainer_mono.npz through the patched Trainer methods (pred_novel_images + compute_losses over every
     target side).  Same keys as cases.run_oracle_trainer."""
     from cases import side_key
@@ -95,7 +95,9 @@ def run_product_trainer(z, meta, device="cuda", impl=None):
     Rts = {}
     for s in sides:
         inputs[("color", s)] = c["color_%s" % s]
-        Rts[s] = outputs[("Rt", s)] = leaf(c["Rt_%s" % s])
+        # stereo_constant: inputs[("Rt", "r")] as the dataset hands it over (a constant; trainer.py:364), which is what
+        # lets the stereo side run as per-row shifts.  Otherwise every pose is a leaf so that g_Rt can be compared.
+        Rts[s] = outputs[("Rt", s)] = c["Rt_%s" % s] if (stereo_constant and s == "r") else leaf(c["Rt_%s" % s])
     opt = types.SimpleNamespace(warp_type=meta["warp_type"], match_aug=False, use_mixture_loss=mix,
                                 automask=meta["automask"], render_probability=False, alpha_pc=0.0, alpha_self=0.0,
                                 self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=True,
