@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--hip_graph", action="store_true",
                     help="capture one step (forward + backward, every launch of it) in a HIP graph and time replays: "
                          "takes the host-side launch cost of the small torch operators around the sweep out of the step")
+    ap.add_argument("--mono_sides", action="store_true",
+                    help="homography_warp only: BASELINE configs[3] as the trainer runs it — target_sides = ['r', -1, 1] "
+                         "(trainer.py:532, 717): the stereo view plus two novel frames with pose_net-like poses, three "
+                         "sweeps per step over the same decoder outputs")
     ap.add_argument("--general_stereo", action="store_true",
                     help="homography_warp, stereo target: keep the general per-plane-homography kernels instead of the "
                          "per-row-shift form the stereo extrinsic allows (opt.pd_stereo_rows = False)")
@@ -108,10 +112,19 @@ def build_step(args, c, device):
     # --mono_pose: the target is a novel frame (-1), whose pose predict_poses builds without translation -> the
     # plane-uniform kernels; --colmap_pose: a novel frame with a translation (opt.use_colmap) -> the general kernels
     side = -1 if (args.mono_pose or args.colmap_pose) else "r"
+    sides = ["r", -1, 1] if args.mono_sides else [side]
     opt.use_colmap = bool(args.colmap_pose)
     opt.pd_stereo_rows = not args.general_stereo
-    ns = types.SimpleNamespace(opt=opt, target_sides=[side], perceptual_loss=lambda *a, **k: zero)
-    inputs = {("color", "l"): c["color_l"], ("color", side): c["color_r"], "K": c["K"], "inv_K": c["inv_K"]}
+    ns = types.SimpleNamespace(opt=opt, target_sides=sides, perceptual_loss=lambda *a, **k: zero)
+    inputs = {("color", "l"): c["color_l"], "K": c["K"], "inv_K": c["inv_K"]}
+    poses = {}
+    for i, sd in enumerate(sides):   # the novel frames get their own images (a shifted copy) and poses
+        inputs[("color", sd)] = c["color_r"] if i == 0 else torch.roll(c["color_r"], shifts=7 * i, dims=3).contiguous()
+        poses[sd] = Rt
+    if args.mono_sides:
+        margs = argparse.Namespace(**dict(vars(args), mono_pose=True))
+        poses[-1] = bench_pose(margs, c, device)
+        poses[1] = bench_pose(margs, c, device).transpose(1, 2).contiguous()   # the opposite rotation
     norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
     shape_probe = torch.empty(B, N, H, W, device="meta")
     g_rgb = c["g_rgb_rec"]
@@ -136,15 +149,17 @@ def build_step(args, c, device):
         else:
             disp_layered = disp_pp.expand(-1, -1, H, W)
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
-                   "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm, ("Rt", side): Rt}
+                   "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm}
+        for sd in sides:
+            outputs[("Rt", sd)] = poses[sd]
         if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
             outputs["distance"] = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
-        ph = outputs[("ph_mean", side)]  # = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
-        rgb_rec = outputs[("rgb_rec", side)]
-        torch.autograd.backward([ph, rgb_rec], [one, g_rgb])
-        return ph
+        # ph_mean = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
+        heads = [outputs[(k, sd)] for sd in sides for k in ("ph_mean", "rgb_rec")]
+        torch.autograd.backward(heads, [one, g_rgb] * len(sides))
+        return heads[0]
 
     return step, (logits, sigma, disp_pp)
 
@@ -167,7 +182,7 @@ def kernel_times(args, c, device, iters):
     mix = not args.no_mixture
     if args.xz_levels:
         return None  # direct-launch timing is wired for the xy-plane configurations only
-    if args.warp_type == "homography_warp" and not (args.mono_pose or args.colmap_pose or args.general_stereo):
+    if args.warp_type == "homography_warp" and (args.mono_sides or not (args.mono_pose or args.colmap_pose or args.general_stereo)):
         return None  # stereo target: runs as per-row shifts on the row-shift kernels; the in-step events time those
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
     pm = None
@@ -577,7 +592,7 @@ def main():
     parallel.barrier(device)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
 
-    value = parallel.throughput(args.batch, args.steps, world, elapsed)
+    value = parallel.throughput(args.batch, args.steps, world, elapsed)   # images (not image-views) per second
     result = {
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -585,7 +600,7 @@ def main():
         "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
         "config": {"workload": "BASELINE configs[1]: %s, %s, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
-                               % (args.warp_type, "mono pose (pose_net: rotation only, F8)" if args.mono_pose
+                               % (args.warp_type, "target_sides ['r', -1, 1]: stereo + two pose_net frames, 3 sweeps per image" if args.mono_sides else "mono pose (pose_net: rotation only, F8)" if args.mono_pose
                                   else ("colmap pose (rotation + translation)" if args.colmap_pose else
                                         ("stereo target r" + (" as per-row shifts (row-shift kernels)" if args.warp_type == "homography_warp" and not args.general_stereo else ""))), "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
                                   args.height, args.width, args.planes + args.xz_levels),
