@@ -26,6 +26,24 @@ int check_launch(const char* what);
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device side -----------------------------------------------------------------------------------------------
+// Workgroup i of a launch runs on XCD i % 8, and every XCD has its own L2.  The pixel-linear gather kernels read a
+// footprint of two (or a few) source rows per target row, so rows dealt round-robin to the XCDs are fetched into several
+// L2s; handing each XCD one contiguous band of the image instead lets the vertical neighbours share their lines.
+// Measured at 8x49x192x640 (scripts/gpu_r2_band.sh): plane-uniform kernels fwd 0.161 -> 0.148 ms, bwd 0.538 -> 0.518 ms;
+// the general per-plane kernels do NOT want it (disp_warp forward 0.233 -> 0.571 ms: their taps stay in the row, and
+// a band per XCD takes the DRAM-page sharing between concurrently running neighbours away), so only the former use it.
+#ifndef PD_XCD_BAND
+#define PD_XCD_BAND 1
+#endif
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_banded(int bx, int nblk) {
+#if PD_XCD_BAND
+  const int per = nblk / kXcds;   // blocks per band; a remainder keeps its place at the end
+  if (bx < per * kXcds) return (bx % kXcds) * per + bx / kXcds;
+#endif
+  return bx;
+}
+
 // Bilinear footprint of one sample under F.grid_sample(align_corners=True) semantics: the four taps
 // (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1) with torch's weights  nw=(x1-ix)(y1-iy), ne=(ix-x0)(y1-iy), ...
 struct Tap {

@@ -71,7 +71,7 @@ template <bool MIX>
 __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                              float* __restrict__ ph_map, float* __restrict__ stash) {
   const int HW = a.H * a.W;
-  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int pix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   const int b = blockIdx.y;
   float ph_val = 0.0f;
   if (pix < HW) {
@@ -139,10 +139,11 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
   if (run_flag && *run_flag == 0) return;   // the fused kernel served the whole launch
   __shared__ float red[kUniG * 9];
   const int HW = a.H * a.W, N = a.N;
-  const int pix = blockIdx.x * kBlock + threadIdx.x;
+  const int pix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   const int b = b0 + blockIdx.y;
-  float* __restrict__ tmp_l = tmp + (long)blockIdx.y * 2 * N * HW;
-  float* __restrict__ tmp_s = tmp_l + (long)N * HW;
+  // (g_l, g_s) of a pixel-plane side by side: one 8-byte store here, one 8-byte load per list entry in pass 2 (pass 2
+  // is paced by its number of memory instructions: 0.386 -> see DESIGN.md with the two tensors apart)
+  float* __restrict__ tmp_b = tmp + (long)blockIdx.y * 2 * N * HW;
   if (threadIdx.x < kUniG * 9) red[threadIdx.x] = 0.0f;
   __syncthreads();
   const bool want_plane = (o.g_plane != nullptr);
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
           }
         }
       }
-      tmp_l[(long)n * HW + pix] = g_l;
-      if (MIX) tmp_s[(long)n * HW + pix] = g_s;
+      if (MIX) reinterpret_cast<float2*>(tmp_b)[(long)n * HW + pix] = make_float2(g_l, g_s);
+      else tmp_b[(long)n * HW + pix] = g_l;
     }
     float inv_z = fast_rcp(u.g.zc);
     inv_z = fmaf(fmaf(-u.g.zc, inv_z, 1.0f), inv_z, inv_z);
@@ -290,6 +291,19 @@ __device__ __forceinline__ UniWindow uni_window(const UniPrep& p, int sx, int sy
 // OVERFLOW = true:  the follow-up kernel; it repeats the scan, returns at once for everybody else and re-scans the
 //                   candidates per plane for those pixels (strong minification only).  Kept out of the main kernel: with the
 //                   re-scan loop inside it the main kernel ran 0.99 instead of 0.58 ms at 8x49x192x640.
+struct PairLS { float l, s; };
+template <bool MIX>
+__device__ __forceinline__ PairLS load_ls(const float* __restrict__ tmp_b, long i) {
+  PairLS r;
+  if (MIX) {
+    const float2 v = reinterpret_cast<const float2*>(tmp_b)[i];
+    r.l = v.x; r.s = v.y;
+  } else {
+    r.l = tmp_b[i]; r.s = 0.0f;
+  }
+  return r;
+}
+
 template <bool MIX, bool OVERFLOW>
 __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
                                                                    const UniPrep* __restrict__ prep,
@@ -297,11 +311,10 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
                                                                    int* __restrict__ overflow_flag, const int* __restrict__ run_flag) {
   if (run_flag && *run_flag == 0) return;        // the fused kernel served the whole launch
   const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
-  const int spix = blockIdx.x * kBlock + threadIdx.x;
+  const int spix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   const int b = b0 + blockIdx.y;
   if (OVERFLOW && *overflow_flag == 0) return;   // nobody asked for the re-scan: the usual case, no second scan
-  const float* __restrict__ tmp_l = tmp + (long)blockIdx.y * 2 * N * HW;
-  const float* __restrict__ tmp_s = tmp_l + (long)N * HW;
+  const float* __restrict__ tmp_b = tmp + (long)blockIdx.y * 2 * N * HW;
   if (spix >= HW) return;
   const int sy = spix / W, sx = spix - sy * W;
   const CoordNorm cn = make_coord_norm(W, H);
@@ -330,16 +343,15 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
   if (OVERFLOW) {
     if (cnt <= kUniK) return;
     for (int n = 0; n < N; ++n) {
-      const float* tl = tmp_l + (long)n * HW;
-      const float* ts = tmp_s + (long)n * HW;
       float accl = 0.0f, accs = 0.0f;
       for (int ty = win.y0; ty <= win.y1; ++ty)
         for (int tx = win.x0; tx <= win.x1; ++tx) {
           const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
           const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
           if (w != 0.0f) {
-            accl += w * tl[ty * W + tx];
-            if (MIX) accs += w * ts[ty * W + tx];
+            const PairLS v = load_ls<MIX>(tmp_b, (long)n * HW + ty * W + tx);
+            accl += w * v.l;
+            accs += w * v.s;
           }
         }
       if (gl) gl[(long)n * HW] = accl;
@@ -356,19 +368,20 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
   kmax = __builtin_amdgcn_readfirstlane(kmax);
 #pragma unroll 2
   for (int n = 0; n < N; ++n) {
-    const float* tl = tmp_l + (long)n * HW;
-    const float* ts = tmp_s + (long)n * HW;
+    const long base = (long)n * HW;
     float accl = 0.0f, accs = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      accl += wgt[k] * tl[idx[k]];
-      if (MIX) accs += wgt[k] * ts[idx[k]];
+      const PairLS v = load_ls<MIX>(tmp_b, base + idx[k]);
+      accl += wgt[k] * v.l;
+      accs += wgt[k] * v.s;
     }
 #pragma unroll
     for (int k = 4; k < kUniK; ++k) {
       if (k < kmax) {   // wave-uniform
-        accl += wgt[k] * tl[idx[k]];
-        if (MIX) accs += wgt[k] * ts[idx[k]];
+        const PairLS v = load_ls<MIX>(tmp_b, base + idx[k]);
+        accl += wgt[k] * v.l;
+        accs += wgt[k] * v.s;
       }
     }
     if (gl) gl[(long)n * HW] = accl;
