@@ -254,6 +254,24 @@ int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other
 int pd_crop_grid(int B, int H, int W, const int32_t* params, float* grid, pd_stream_t stream);
 
 /*
+ * Photometric loss under the occlusion mask `mask_novel` (trainer.py:724-742; the mask is produced after
+ * pred_novel_images, trainer.py:342-349, so it cannot enter the sweep's forward):
+ *   pred = rgb_rec * mask + target * (1 - mask)                      -> pred [B,3,H,W] (may be NULL)
+ *   mixture = 0:  mean over (b, pixel) of mean_c |pred - target|, or of min(that, mean_c |source - target|) when
+ *                 `source` (the automask's identity view) is given   (trainer.py:738-742)
+ *   mixture = 1:  mean over (b, pixel) of ph_map * mask, ph_map [B,1,H,W] = the sweep's per-pixel NLL (:736, :742)
+ * mask [B,1,H,W] (NULL = all ones).  partials: workspace of B * ceil(H*W / 256) floats; mean: 1 float.
+ * Backward: g_mean [1] (d loss / d mean, device scalar, may be NULL) and g_pred [B,3,H,W] (upstream gradient of the
+ * blended prediction, e.g. from the perceptual net; may be NULL) -> g_rgb_rec [B,3,H,W], g_ph_map [B,1,H,W] (mixture).
+ */
+int pd_masked_photometric_fwd(int B, int H, int W, int mixture, const float* rgb_rec, const float* target,
+                              const float* source, const float* mask, const float* ph_map, float* pred, float* partials,
+                              float* mean, pd_stream_t stream);
+int pd_masked_photometric_bwd(int B, int H, int W, int mixture, const float* rgb_rec, const float* target,
+                              const float* source, const float* mask, const float* g_mean, const float* g_pred,
+                              float* g_rgb_rec, float* g_ph_map, pd_stream_t stream);
+
+/*
  * The O(B*N) 3x3 algebra of HomographyWarp.forward (layers.py:206-219, 223-225) and its adjoint, one launch each:
  *   M = R + t n^T / d;  H_t2s = inverse(K M K^-1);  Rn = R n          (R, t from T [B,4,4]; K, inv_K [B,4,4])
  * evaluated in fp64 and rounded once to fp32.  distance [B,N], norm [B,N,3].

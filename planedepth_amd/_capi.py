@@ -59,6 +59,8 @@ SIGNATURES = {
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
+    "pd_masked_photometric_fwd": (_I, [_I] * 4 + [_P] * 9),
+    "pd_masked_photometric_bwd": (_I, [_I] * 4 + [_P] * 9),
     "pd_homography_matrices_fwd": (_I, [_I] * 4 + [_P] * 10),
     "pd_homography_matrices_bwd": (_I, [_I] * 4 + [_P] * 11),
     "pd_backproject": (_I, [_I] * 3 + [_P] * 4),

@@ -626,6 +626,61 @@ def crop_grid(params, height, width):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Photometric loss under mask_novel (trainer.py:724-742)
+# ---------------------------------------------------------------------------------------------------------------------
+class _MaskedPhotometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_rec, ph_map, target, source, mask):
+        lib = C.load()
+        B, _, H, W = rgb_rec.shape
+        dev = rgb_rec.device
+        mix = ph_map is not None
+        rgb_rec, target = _contig(rgb_rec.detach()), _contig(target)
+        source = _contig(source) if source is not None else None
+        mask = _contig(mask.float()) if mask is not None else None
+        C.require_gpu_tensor("rgb_rec", rgb_rec, (B, 3, H, W))
+        C.require_gpu_tensor("target", target, (B, 3, H, W))
+        if mask is not None:
+            C.require_gpu_tensor("mask_novel", mask, (B, 1, H, W))
+        pm = _contig(ph_map.detach()) if mix else None
+        pred = torch.empty_like(rgb_rec)
+        partials = torch.empty(B * ((H * W + 255) // 256), device=dev)
+        mean = torch.empty(1, device=dev)
+        with torch.cuda.device(dev):
+            C.check(lib.pd_masked_photometric_fwd(B, H, W, int(mix), C.ptr(rgb_rec), C.ptr(target), C.ptr(source),
+                                                  C.ptr(mask), C.ptr(pm), C.ptr(pred), C.ptr(partials), C.ptr(mean),
+                                                  C.stream_handle(dev)), "pd_masked_photometric_fwd")
+        ctx.save_for_backward(rgb_rec, target, source, mask)
+        ctx.mix = mix
+        return pred, mean.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_pred, g_mean):
+        lib = C.load()
+        rgb_rec, target, source, mask = ctx.saved_tensors
+        B, _, H, W = rgb_rec.shape
+        dev = rgb_rec.device
+        g_pred = _contig(g_pred) if g_pred is not None else None
+        g_mean = _contig(g_mean.reshape(1)) if g_mean is not None else None
+        g_rgb = torch.empty_like(rgb_rec) if ctx.needs_input_grad[0] else None
+        g_ph = torch.empty(B, 1, H, W, device=dev) if (ctx.mix and ctx.needs_input_grad[1]) else None
+        if g_rgb is not None or g_ph is not None:
+            with torch.cuda.device(dev):
+                C.check(lib.pd_masked_photometric_bwd(B, H, W, int(ctx.mix), C.ptr(rgb_rec), C.ptr(target), C.ptr(source),
+                                                      C.ptr(mask), C.ptr(g_mean), C.ptr(g_pred), C.ptr(g_rgb),
+                                                      C.ptr(g_ph), C.stream_handle(dev)), "pd_masked_photometric_bwd")
+        return g_rgb, g_ph, None, None, None
+
+
+def masked_photometric(rgb_rec, target, mask, *, source=None, ph_map=None):
+    """trainer.py:724-742 under ``outputs["mask_novel"]``: returns ``(pred, ph_loss)`` with
+    ``pred = rgb_rec * mask + target * (1 - mask)`` (what the perceptual net is fed) and the scalar photometric loss —
+    ``ph_map`` given (mixture): ``(ph_map * mask).mean()``; otherwise L1 on ``pred`` with the automask's ``min`` against
+    ``source`` when that is given.  One kernel each way (pd_masked_loss.hip)."""
+    return _MaskedPhotometric.apply(rgb_rec, ph_map, target, source, mask)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Smoothness loss (SURVEY.md 8f rank 3)
 # ---------------------------------------------------------------------------------------------------------------------
 def _row_strided(name, t):

@@ -165,20 +165,18 @@ def compute_losses(self, inputs, outputs):
         pred = outputs[("rgb_rec", target_side)]
         target = inputs[(cname, target_side)]
         mask = outputs["mask_novel"] if "mask_novel" in outputs else None
-        if mask is not None:
-            pred = pred * mask + target * (1.0 - mask)
         if mask is None:
             # mixture NLL or mean_c |rgb_rec - target| (+ automask min) AND its `.mean()` (trainer.py:742) come out
             # of the sweep kernel; the backward takes the scalar's gradient directly
             ph_loss = outputs[("ph_mean", target_side)]
-        elif opt.use_mixture_loss:
-            ph_loss = (outputs[("ph_map", target_side)] * mask).mean()
-        else:  # L1 on the blended prediction: [B,3,H,W] elementwise work, left to torch
-            ph_loss = torch.abs(pred - target).mean(1, True)
-            if opt.automask:
-                ph_auto = torch.abs(inputs[(cname, "l")] - target).mean(1, True)
-                ph_loss, _ = torch.cat([ph_loss, ph_auto], dim=1).min(1, True)
-            ph_loss = ph_loss.mean()
+        else:
+            # mask_novel is produced after pred_novel_images (trainer.py:342-349), so the blend, the masked loss and its
+            # mean are one small kernel here (mixture: the sweep's ph_map * mask; L1: on the blended prediction, with
+            # the automask's min) instead of a chain of [B,3,H,W] torch operators
+            mix = bool(opt.use_mixture_loss)
+            pred, ph_loss = ops.masked_photometric(
+                pred, target, mask, ph_map=outputs[("ph_map", target_side)] if mix else None,
+                source=inputs[(cname, "l")] if (opt.automask and not mix) else None)
         losses["loss/ph_loss"] += ph_loss
         total_loss += ph_loss
 

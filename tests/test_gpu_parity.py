@@ -992,6 +992,51 @@ def test_homography_matrices_kernel_vs_fp64_chain(mode):
         assert float(Td.grad[:, 3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mix,automask,with_mask", [(False, False, True), (False, True, True), (True, False, True),
+                                                    (False, True, False)])
+def test_masked_photometric_loss_vs_torch_expression(mix, automask, with_mask):
+    """pd_masked_photometric_fwd/bwd against the reference's own statements (trainer.py:724-742) written in torch: the
+    blended prediction, the scalar loss, and the gradients into rgb_rec / ph_map, with an upstream gradient on the
+    blended prediction (the perceptual net's) on top of the loss's."""
+    from planedepth_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 3, 37, 150
+    dev = "cuda"
+    rgb, tgt, src = (torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3))
+    ph_map = (torch.rand(B, 1, H, W, generator=g) * 5).to(dev)
+    mask = torch.rand(B, 1, H, W, generator=g).clamp(0.1, 0.8).sub(0.1).div(0.7).to(dev) if with_mask else None  # zeros and ones included
+    gw = torch.randn(B, 3, H, W, generator=g).to(dev) * 1e-5
+
+    def reference(r, pm):
+        m = mask if mask is not None else torch.ones(B, 1, H, W, device=dev)
+        pred = r * m + tgt * (1.0 - m)                                         # trainer.py:726
+        if mix:
+            ph = pm * m                                                        # :736
+        else:
+            ph = torch.abs(pred - tgt).mean(1, True)                          # :738
+            if automask:
+                ph_auto = torch.abs(src - tgt).mean(1, True)                   # :740
+                ph, _ = torch.cat([ph, ph_auto], dim=1).min(1, True)           # :741
+        return pred, ph.mean()                                                 # :742
+
+    def product(r, pm):
+        return ops.masked_photometric(r, tgt, mask, source=src if (automask and not mix) else None,
+                                      ph_map=pm if mix else None)
+
+    out = {}
+    for name, fn in (("ref", reference), ("hip", product)):
+        r, pm = rgb.clone().requires_grad_(True), ph_map.clone().requires_grad_(True)
+        pred, loss = fn(r, pm)
+        (loss * 3.0 + (pred * gw).sum()).backward()
+        out[name] = dict(pred=pred.detach().cpu(), loss=loss.detach().cpu(), g_rgb=r.grad.cpu(),
+                         g_ph=pm.grad.cpu() if pm.grad is not None else torch.zeros(1))
+    assert torch.equal(out["hip"]["pred"], out["ref"]["pred"])                 # same three roundings per element
+    assert abs(float(out["hip"]["loss"]) - float(out["ref"]["loss"])) < 2e-6 * abs(float(out["ref"]["loss"]))
+    assert rel_err(out["hip"]["g_rgb"], out["ref"]["g_rgb"]) < 1e-6
+    if mix:
+        assert rel_err(out["hip"]["g_ph"], out["ref"]["g_ph"]) < 1e-6
+
+
 def _wild_homographies(B, N, H, W, seed):
     """[B*N,3,3] target->source homographies well away from the identity: in-plane rotation up to ~12 degrees, zoom
     0.8-1.25, shear, a perspective term, shifts of up to a third of the image — plus their (K^-1, R n) companions."""
