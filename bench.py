@@ -51,6 +51,9 @@ def parse():
                     help="homography_warp only: BASELINE configs[3] as the trainer runs it — target_sides = ['r', -1, 1] "
                          "(trainer.py:532, 717): the stereo view plus two novel frames with pose_net-like poses, three "
                          "sweeps per step over the same decoder outputs")
+    ap.add_argument("--per_view_nodes", action="store_true",
+                    help="--mono_sides: one autograd node per target view (opt.pd_fuse_sides = False) instead of one node "
+                         "for all views with in-kernel gradient accumulation")
     ap.add_argument("--general_stereo", action="store_true",
                     help="homography_warp, stereo target: keep the general per-plane-homography kernels instead of the "
                          "per-row-shift form the stereo extrinsic allows (opt.pd_stereo_rows = False)")
@@ -115,6 +118,7 @@ def build_step(args, c, device):
     sides = ["r", -1, 1] if args.mono_sides else [side]
     opt.use_colmap = bool(args.colmap_pose)
     opt.pd_stereo_rows = not args.general_stereo
+    opt.pd_fuse_sides = not args.per_view_nodes
     ns = types.SimpleNamespace(opt=opt, target_sides=sides, perceptual_loss=lambda *a, **k: zero)
     inputs = {("color", "l"): c["color_l"], "K": c["K"], "inv_K": c["inv_K"]}
     poses = {}

@@ -60,6 +60,12 @@ enum pd_sweep_flags {
                          back-propagated through f(R + t e_j^T) it gives the exact translation gradient of the per-plane
                          formulation.  Served by pd_plane_sweep_uniform.hip: geometry once per pixel, atomic-free
                          two-pass backward */
+  ,
+  PD_BWD_ACCUMULATE = 128 /* pd_plane_sweep_bwd only: g_logits / g_sigma are ADDED TO instead of overwritten, so the target
+                         views of one step (trainer.py:532: the same logits / sigma feed every side) sum their
+                         gradients in place instead of through [B,N,H,W]-sized add kernels.  Honoured where
+                         pd_sweep_bwd_accumulates() says so (the plane-uniform kernels: read-modify-write stores; the
+                         general kernels: their atomics simply skip the zero-fill); refused elsewhere */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
@@ -95,6 +101,8 @@ int pd_version(void);
 const char* pd_last_error(void);
 
 /* 1 if this descriptor is served by the row-shift kernels (PD_WARP_DISP, scalar or per-row disparities), else 0. */
+/* 1 if pd_plane_sweep_bwd honours PD_BWD_ACCUMULATE for this descriptor (see the flag), else 0. */
+int pd_sweep_bwd_accumulates(const pd_sweep_desc* d);
 int pd_sweep_uses_rowshift(const pd_sweep_desc* d);
 
 /* Floats per image the forward pass stashes for the backward pass (softmax statistics + mask bits). */

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth
 
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_ROWS, PD_HOMO_UNIFORM = 1, 2, 4, 8, 16, 32, 64
+PD_BWD_ACCUMULATE = 128
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
@@ -38,6 +39,7 @@ SIGNATURES = {
     "pd_version": (_I, []),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_sweep_uses_rowshift": (_I, [_D]),
+    "pd_sweep_bwd_accumulates": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
     "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),
     "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 14),

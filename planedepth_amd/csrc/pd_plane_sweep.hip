@@ -439,6 +439,13 @@ extern "C" int pd_sweep_uses_rowshift(const pd_sweep_desc* d) {
   return (d && wants_rowshift(d) && rowshift_applicable(d)) ? 1 : 0;
 }
 
+extern "C" int pd_sweep_bwd_accumulates(const pd_sweep_desc* d) {
+  if (!d) return 0;
+  if (wants_rowshift(d) && rowshift_applicable(d)) return 0;   // owner-computes ring stores: no read-modify-write form
+  if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) return 1;
+  return tile_bwd_applicable(d) ? 0 : 1;                       // the atomic scatter accumulates by nature
+}
+
 extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
   if (!d) return 0;
   const size_t words = (d->mode == PD_WARP_DISP) ? (size_t)(d->N + 31) / 32 : 0;
@@ -517,6 +524,8 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_ROWS1, "unknown impl %d", d->impl);
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;
+  const bool accumulate = (d->flags & PD_BWD_ACCUMULATE) != 0;
+  PD_REQUIRE(!accumulate || pd_sweep_bwd_accumulates(d), "PD_BWD_ACCUMULATE is not served for this descriptor (pd_sweep_bwd_accumulates)");
   SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
@@ -542,8 +551,8 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   dim3 grid(bwd_blocks(HW), d->B);
   const int K = (d->mode == PD_WARP_DISP) ? 1 : 9;
   // general path: the bilinear adjoint is an atomic scatter into zero-filled gradients
-  if (g_logits) (void)hipMemsetAsync(g_logits, 0, plane_bytes, stream);
-  if (g_sigma) (void)hipMemsetAsync(g_sigma, 0, plane_bytes, stream);
+  if (g_logits && !accumulate) (void)hipMemsetAsync(g_logits, 0, plane_bytes, stream);
+  if (g_sigma && !accumulate) (void)hipMemsetAsync(g_sigma, 0, plane_bytes, stream);
   const size_t shmem = (size_t)d->N * K * sizeof(float);
   PD_DISPATCH(sweep_bwd_kernel, d->mode, mix, grid, dim3(kBlock), shmem, stream, ak, o);
   rc = check_launch("sweep_bwd_kernel");

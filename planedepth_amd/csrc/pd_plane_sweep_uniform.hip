@@ -308,7 +308,8 @@ template <bool MIX, bool OVERFLOW>
 __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
                                                                    const UniPrep* __restrict__ prep,
                                                                    float* __restrict__ g_logits, float* __restrict__ g_sigma,
-                                                                   int* __restrict__ overflow_flag, const int* __restrict__ run_flag) {
+                                                                   int* __restrict__ overflow_flag, const int* __restrict__ run_flag,
+                                                                   int accumulate) {
   if (run_flag && *run_flag == 0) return;        // the fused kernel served the whole launch
   const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
   const int spix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
@@ -354,6 +355,10 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
             accs += w * v.s;
           }
         }
+      if (accumulate) {   // PD_BWD_ACCUMULATE: another target view's gradient is already there
+        if (gl) accl += gl[(long)n * HW];
+        if (gs) accs += gs[(long)n * HW];
+      }
       if (gl) gl[(long)n * HW] = accl;
       if (gs) gs[(long)n * HW] = accs;
     }
@@ -383,6 +388,10 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
         accl += wgt[k] * v.l;
         accs += wgt[k] * v.s;
       }
+    }
+    if (accumulate) {
+      if (gl) accl += gl[(long)n * HW];
+      if (gs) accs += gs[(long)n * HW];
     }
     if (gl) gl[(long)n * HW] = accl;
     if (gs) gs[(long)n * HW] = accs;
@@ -646,7 +655,8 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   int* irregular = reinterpret_cast<int*>(&prep[0].pad[1]);
   // Measured at 8x49x192x640 (pose_net-like rotations): two-pass 0.27 + 0.38 = 0.65 ms, fused 0.75 ms — sixteen waves
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
-  const bool fused = getenv("PD_UNI_FUSED") != nullptr;
+  const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
+  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate;
   const int tiles_x = ceil_div(d->W, kFuseC), ntiles = tiles_x * ceil_div(d->H, kFuseR);
   if (!rc && fused) {   // regular case: per-plane gradients handed over through LDS
     dim3 grid(ntiles, d->B);
@@ -661,12 +671,12 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
     dim3 grid(nblk, nb);
     if (mix) {
       uniform_bwd_pass1_kernel<true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
-      uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag);
-      uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag);
+      uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
+      uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
     } else {
       uniform_bwd_pass1_kernel<false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
-      uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag);
-      uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag);
+      uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
+      uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
     }
     rc = check_launch("uniform_bwd_pass kernels");
   }

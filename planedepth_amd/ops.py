@@ -51,6 +51,86 @@ def _contig(t):
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused plane sweep + photometric loss
 # ---------------------------------------------------------------------------------------------------------------------
+def _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign):
+    """One target view through pd_plane_sweep_fwd -> ((rgb_rec, ph_map, ph_mean[1]), tensors the backward needs)."""
+    global LAST_SWEEP_FLAGS
+    LAST_SWEEP_FLAGS = flags
+    lib = C.load()
+    B, N, H, W = logits.shape
+    C.require_gpu_tensor("logits", logits)
+    C.require_gpu_tensor("src", src, (B, 3, H, W))
+    C.require_gpu_tensor("tgt", tgt, (B, 3, H, W))
+    if flags & C.PD_MIXTURE:
+        C.require_gpu_tensor("sigma", sigma, (B, N, H, W))
+    if mode == C.PD_WARP_DISP:
+        C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else
+                             ((B, N, H) if flags & C.PD_DISP_ROWS else (B, N)))
+        if padding_mask is not None:
+            C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H) if flags & C.PD_MASK_ROWS else (B, N, H, W))
+    else:
+        C.require_gpu_tensor("H_t2s", plane, (B, 4, 3, 3) if flags & C.PD_HOMO_UNIFORM else (B * N, 3, 3))
+        if flags & C.PD_HOMO_UNIFORM and padding_mask is not None:
+            C.require_gpu_tensor("translation weights", padding_mask, (B, N, 3))
+        C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
+        C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
+    if flags & C.PD_RENDER_PROB:
+        C.require_gpu_tensor("dists", dists, (B, N - 1, H, W))
+    else:
+        dists = None
+    src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists = map(
+        _contig, (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists))
+    d = _desc(B, N, H, W, mode, flags, sign)
+    k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
+    rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
+    ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
+    ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
+    stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
+    with torch.cuda.device(logits.device), _timed("fwd"):
+        rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
+                                    C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
+                                    C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(ph_mean), C.ptr(stash),
+                                    C.stream_handle(logits.device))
+    C.check(rc, "pd_plane_sweep_fwd")
+    if DEBUG_STASH is not None:
+        DEBUG_STASH.append(stash)
+    return (rgb_rec, ph_map, ph_mean), (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
+
+
+def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False):
+    """pd_plane_sweep_bwd of one target view.  ``need`` = (logits, sigma, plane, dists) gradients wanted; ``into`` =
+    (g_logits, g_sigma) buffers to write (or, ``accumulate``: add) into instead of fresh ones.
+    Returns (g_logits, g_sigma, g_plane, g_dists)."""
+    lib = C.load()
+    src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = saved
+    mode, flags, sign = cfg
+    g_rgb_rec, g_ph_map, g_ph_mean = grads
+    B, N, H, W = logits.shape
+    d = _desc(B, N, H, W, mode, flags | (C.PD_BWD_ACCUMULATE if accumulate else 0), sign)
+    need_logits, need_sigma, need_plane, need_dists = need
+    mix = bool(flags & C.PD_MIXTURE)
+    if into is not None:
+        g_logits, g_sigma = into
+    else:
+        g_logits = torch.empty_like(logits) if need_logits else None
+        g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
+    g_plane = torch.empty_like(plane) if need_plane else None
+    g_dists = torch.empty_like(dists) if (dists is not None and need_dists) else None
+    # scratch: partial sums of the plane-parameter gradient and the row-shift kernels' boundary spill
+    ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device,
+                     dtype=torch.float32)
+    g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
+    if g_ph_mean is not None:
+        g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
+    with torch.cuda.device(logits.device), _timed("bwd"):
+        rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
+                                    C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
+                                    C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
+                                    C.ptr(g_logits), C.ptr(g_sigma if mix else None), C.ptr(g_plane), C.ptr(g_dists),
+                                    C.ptr(ws), C.stream_handle(logits.device))
+    C.check(rc, "pd_plane_sweep_bwd")
+    return g_logits, (g_sigma if mix else None), g_plane, g_dists
+
+
 class _PlaneSweep(torch.autograd.Function):
     """(src, tgt, logits, sigma, plane, ...) -> (rgb_rec [B,3,H,W], ph_map [B,1,H,W], ph_mean []).
 
@@ -63,78 +143,111 @@ class _PlaneSweep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign):
-        global LAST_SWEEP_FLAGS
-        LAST_SWEEP_FLAGS = flags
-        lib = C.load()
-        B, N, H, W = logits.shape
-        C.require_gpu_tensor("logits", logits)
-        C.require_gpu_tensor("src", src, (B, 3, H, W))
-        C.require_gpu_tensor("tgt", tgt, (B, 3, H, W))
-        if flags & C.PD_MIXTURE:
-            C.require_gpu_tensor("sigma", sigma, (B, N, H, W))
-        if mode == C.PD_WARP_DISP:
-            C.require_gpu_tensor("disp", plane, (B, N, H, W) if flags & C.PD_DISP_DENSE else
-                                 ((B, N, H) if flags & C.PD_DISP_ROWS else (B, N)))
-            if padding_mask is not None:
-                C.require_gpu_tensor("padding_mask", padding_mask, (B, N, H) if flags & C.PD_MASK_ROWS else (B, N, H, W))
-        else:
-            C.require_gpu_tensor("H_t2s", plane, (B, 4, 3, 3) if flags & C.PD_HOMO_UNIFORM else (B * N, 3, 3))
-            if flags & C.PD_HOMO_UNIFORM and padding_mask is not None:
-                C.require_gpu_tensor("translation weights", padding_mask, (B, N, 3))
-            C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
-            C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
-        if flags & C.PD_RENDER_PROB:
-            C.require_gpu_tensor("dists", dists, (B, N - 1, H, W))
-        else:
-            dists = None
-        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists = map(
-            _contig, (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists))
-        d = _desc(B, N, H, W, mode, flags, sign)
-        k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
-        rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
-        ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
-        ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
-        stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
-        with torch.cuda.device(logits.device), _timed("fwd"):
-            rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
-                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
-                                        C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(ph_mean), C.ptr(stash),
-                                        C.stream_handle(logits.device))
-        C.check(rc, "pd_plane_sweep_fwd")
-        if DEBUG_STASH is not None:
-            DEBUG_STASH.append(stash)
-        ctx.save_for_backward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
+        (rgb_rec, ph_map, ph_mean), saved = _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3,
+                                                           padding_mask, dists, mode, flags, sign)
+        ctx.save_for_backward(*saved)
         ctx.cfg = (mode, flags, sign)
         ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward, not as zero tensors
         return rgb_rec, ph_map, ph_mean.reshape(())
 
     @staticmethod
     def backward(ctx, g_rgb_rec, g_ph_map, g_ph_mean):
-        lib = C.load()
-        src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = ctx.saved_tensors
-        mode, flags, sign = ctx.cfg
-        B, N, H, W = logits.shape
-        d = _desc(B, N, H, W, mode, flags, sign)
-        need_logits, need_sigma, need_plane = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
-        mix = bool(flags & C.PD_MIXTURE)
-        g_logits = torch.empty_like(logits) if need_logits else None
-        g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
-        g_plane = torch.empty_like(plane) if need_plane else None
-        g_dists = torch.empty_like(dists) if (dists is not None and ctx.needs_input_grad[8]) else None
-        # scratch: partial sums of the plane-parameter gradient and the row-shift kernels' boundary spill
-        ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device,
-                         dtype=torch.float32)
-        g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
-        if g_ph_mean is not None:
-            g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
-        with torch.cuda.device(logits.device), _timed("bwd"):
-            rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
-                                        C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
-                                        C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
-                                        C.ptr(g_logits), C.ptr(g_sigma), C.ptr(g_plane), C.ptr(g_dists), C.ptr(ws),
-                                        C.stream_handle(logits.device))
-        C.check(rc, "pd_plane_sweep_bwd")
+        need = (ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[8])
+        g_logits, g_sigma, g_plane, g_dists = _sweep_backward(ctx.saved_tensors, ctx.cfg,
+                                                              (g_rgb_rec, g_ph_map, g_ph_mean), need)
         return None, None, g_logits, g_sigma, g_plane, None, None, None, g_dists, None, None, None
+
+
+_PER_SIDE = 9   # tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign
+
+
+class _MultiPlaneSweep(torch.autograd.Function):
+    """Every target view of one step (trainer.py:532: ``for target_side in self.target_sides``) over the SAME source
+    image, logits and sigma as ONE autograd node: the views' gradients into logits / sigma are summed inside the backward
+    kernels (PD_BWD_ACCUMULATE) instead of by [B,N,H,W]-sized add kernels between separate nodes (at 8x49x192x640 each
+    such add moves 0.58 GB; three views need four of them).
+
+    apply(src, logits, sigma, *flat) with ``flat`` = per view (tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode,
+    flags, sign) -> per view (rgb_rec, ph_map, ph_mean)."""
+
+    @staticmethod
+    def forward(ctx, src, logits, sigma, *flat):
+        n = len(flat) // _PER_SIDE
+        outs, tensors, cfgs, layout = [], [], [], []
+        for i in range(n):
+            tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign = flat[i * _PER_SIDE:(i + 1) * _PER_SIDE]
+            (rgb_rec, ph_map, ph_mean), saved = _sweep_forward(src, tgt, logits, sigma if flags & C.PD_MIXTURE else None,
+                                                               plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign)
+            outs += [rgb_rec, ph_map, ph_mean.reshape(())]
+            cfgs.append((mode, flags, sign))
+            idx = []
+            for t in saved:     # save_for_backward takes tensors only: remember where the Nones were
+                if t is None:
+                    idx.append(-1)
+                else:
+                    idx.append(len(tensors))
+                    tensors.append(t)
+            layout.append(idx)
+        ctx.save_for_backward(*tensors)
+        ctx.cfgs, ctx.layout, ctx.n = cfgs, layout, n
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = C.load()
+        tensors = ctx.saved_tensors
+        n = ctx.n
+        need_logits, need_sigma = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        views = []
+        for i in range(n):
+            g = grads[3 * i:3 * i + 3]
+            if all(x is None for x in g):
+                continue   # this view took no part in the loss
+            saved = tuple(None if j < 0 else tensors[j] for j in ctx.layout[i])
+            logits = saved[2]
+            B, N, H, W = logits.shape
+            mode, flags, sign = ctx.cfgs[i]
+            can = bool(lib.pd_sweep_bwd_accumulates(ctypes.byref(_desc(B, N, H, W, mode, flags, sign))))
+            views.append((i, saved, g, can))
+        views.sort(key=lambda v: v[3])   # kernels that cannot add in place (the row-shift ones) first: one of them starts the sum
+        g_logits = g_sigma = None
+        per_view = {}
+        for k, (i, saved, g, can) in enumerate(views):
+            base = 3 + i * _PER_SIDE
+            need = (need_logits, need_sigma, ctx.needs_input_grad[base + 1], ctx.needs_input_grad[base + 5])
+            if k == 0:
+                g_logits, g_sigma, gp, gd = _sweep_backward(saved, ctx.cfgs[i], g, need)
+            elif can:
+                gl, gs, gp, gd = _sweep_backward(saved, ctx.cfgs[i], g, need, into=(g_logits, g_sigma), accumulate=True)
+                g_sigma = g_sigma if g_sigma is not None else gs
+            else:
+                gl, gs, gp, gd = _sweep_backward(saved, ctx.cfgs[i], g, need)
+                if gl is not None:
+                    g_logits = gl if g_logits is None else g_logits.add_(gl)
+                if gs is not None:
+                    g_sigma = gs if g_sigma is None else g_sigma.add_(gs)
+            per_view[i] = (gp, gd)
+        out = [None, g_logits, g_sigma]
+        for i in range(n):
+            gp, gd = per_view.get(i, (None, None))
+            out += [None, gp, None, None, None, gd, None, None, None]
+        return tuple(out)
+
+
+def plane_sweep_multi(deferred):
+    """``deferred``: one argument tuple per target view as returned by ``plane_sweep_disp(..., defer=True)`` /
+    ``plane_sweep_homography(..., defer=True)`` — all over the same (src, logits, sigma).  Returns a list of
+    ``(rgb_rec, ph_map, ph_mean)`` per view; see _MultiPlaneSweep."""
+    src, _, logits = deferred[0][0], deferred[0][1], deferred[0][2]
+    sigma = next((d[3] for d in deferred if d[3] is not None), None)
+    flat = []
+    for d in deferred:
+        if d[0] is not src or d[2] is not logits or (d[3] is not None and d[3] is not sigma):
+            raise ValueError("plane_sweep_multi: every view must sweep the same src / logits / sigma tensors")
+        flat += [d[1]] + list(d[4:])
+    outs = _MultiPlaneSweep.apply(src, logits, sigma, *flat)
+    return [tuple(outs[3 * i:3 * i + 3]) for i in range(len(deferred))]
 
 
 def _flags(use_mixture_loss, automask, dense=False, render=False, rows=False):
@@ -164,7 +277,7 @@ def _per_plane_view(disp_layered):
 
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
                      use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False,
-                     return_mean=False):
+                     return_mean=False, defer=False):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
 
     ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
@@ -199,8 +312,11 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
             padding_mask = padding_mask[..., 0]
             flags |= C.PD_MASK_ROWS
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
-    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
-                            dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
+    call = (src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
+            dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
+    if defer:      # the argument tuple for plane_sweep_multi (several target views as one autograd node)
+        return call
+    out = _PlaneSweep.apply(*call)
     return out if return_mean else out[:2]  # (rgb_rec, ph_map[, ph_map.mean() fused into the kernel])
 
 
@@ -292,7 +408,7 @@ TORCH_HOMOGRAPHY = bool(int(os.environ.get("PD_TORCH_HOMOGRAPHY", "0")))
 
 def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K, *, use_mixture_loss=True,
                            automask=False, render_probability=False, dists=None, return_mean=False, plane_uniform=False,
-                           stereo_rows=False):
+                           stereo_rows=False, defer=False):
     """``homography_warp`` sweep (reference trainer.py:556-560 + layers.py:206-234 + trainer.py:567-603, 728-742).
 
     distance [B,N], norm [B,N,3]; T, K, inv_K are the per-image [B,4,4] matrices (expanded over planes here).
@@ -314,7 +430,7 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     B, N, H, W = logits.shape
     if stereo_rows and not render_probability and not T.requires_grad and not norm.requires_grad:
         return _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, use_mixture_loss, automask,
-                                  return_mean)
+                                  return_mean, defer)
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
     inv_K3 = inv_K[:, :3, :3]
     flags = _flags(use_mixture_loss, automask, render=render_probability)
@@ -345,13 +461,15 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     else:
         H_t2s, Rn = homography_matrices_fused(distance, norm, T, K, inv_K)
         H_t2s, Rn = H_t2s.reshape(B * N, 3, 3), Rn.reshape(B * N, 3)
-    out = _PlaneSweep.apply(src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach().contiguous(),
-                            inv_K3.detach(), tw, dists if render_probability else None, C.PD_WARP_HOMOGRAPHY,
-                            flags, 0.0)
+    call = (src, tgt, logits, sigma if use_mixture_loss else None, H_t2s, Rn.detach().contiguous(), inv_K3.detach(), tw,
+            dists if render_probability else None, C.PD_WARP_HOMOGRAPHY, flags, 0.0)
+    if defer:
+        return call
+    out = _PlaneSweep.apply(*call)
     return out if return_mean else out[:2]
 
 
-def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean):
+def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean, defer=False):
     B, N, H, W = logits.shape
     if TORCH_HOMOGRAPHY:
         ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
@@ -371,7 +489,7 @@ def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix
         shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
     return plane_sweep_disp(src, tgt, logits, sigma, shift[..., None].expand(B, N, H, W),
                             mask[..., None].expand(B, N, H, W), target_side="r", use_mixture_loss=mix,
-                            automask=automask, row_uniform=True, return_mean=return_mean)
+                            automask=automask, row_uniform=True, return_mean=return_mean, defer=defer)
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",

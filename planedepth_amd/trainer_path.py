@@ -84,15 +84,20 @@ def pred_novel_images(self, inputs, outputs):
             raise ValueError("opt.yz_levels == 0 promises disparities that are constant along x, but disp_layered is not")
         if row_uniform and pm is not None and pm.dim() == 4 and pm.shape[-1] > 1 and not bool((pm == pm[..., :1]).all()):
             raise ValueError("opt.yz_levels == 0 promises a padding_mask that is constant along x, but it is not")
+    # Several target views (trainer.py:532; mono training: ["r", -1, 1]) sweep the same logits / sigma: they are issued as
+    # ONE autograd node whose backward kernels add their gradients in place (ops._MultiPlaneSweep) instead of one node
+    # per view with [B,N,H,W]-sized adds in between.  opt.pd_fuse_sides = False keeps one node per view.
+    fuse_sides = len(self.target_sides) > 1 and getattr(opt, "pd_fuse_sides", True)
+    calls, handles = [], []
     for target_side in self.target_sides:
         tgt = inputs[(cname, target_side)]
         sigma = outputs["sigma"] if mix else None
         if opt.warp_type == "disp_warp":
-            rgb_rec, ph_map, ph_mean = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
-                                                            padding_mask, target_side=target_side,
-                                                            use_mixture_loss=mix, automask=automask,
-                                                            render_probability=render, dists=dists,
-                                                            row_uniform=row_uniform, return_mean=True)
+            call = ops.plane_sweep_disp(src, tgt, outputs["logits"], sigma, outputs["disp_layered"],
+                                        padding_mask, target_side=target_side,
+                                        use_mixture_loss=mix, automask=automask,
+                                        render_probability=render, dists=dists,
+                                        row_uniform=row_uniform, return_mean=True, defer=True)
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, disp_layered=outputs["disp_layered"],
                                  padding_mask=padding_mask, target_side=target_side, use_mixture_loss=mix,
                                  render_probability=render, dists=dists)
@@ -116,12 +121,12 @@ def pred_novel_images(self, inputs, outputs):
                         and bool((outputs["norm"][..., 0] == 0).all())):
                     raise ValueError("outputs[('Rt', %r)] is not a pure x-translation, or a plane normal has an x "
                                      "component although opt.yz_levels == 0" % (target_side,))
-            rgb_rec, ph_map, ph_mean = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma,
-                                                                  outputs["distance"], outputs["norm"], T, inputs["K"],
-                                                                  inputs["inv_K"], use_mixture_loss=mix,
-                                                                  automask=automask, render_probability=render,
-                                                                  dists=dists, return_mean=True, plane_uniform=uniform,
-                                                                  stereo_rows=stereo_rows)
+            call = ops.plane_sweep_homography(src, tgt, outputs["logits"], sigma,
+                                              outputs["distance"], outputs["norm"], T, inputs["K"],
+                                              inputs["inv_K"], use_mixture_loss=mix,
+                                              automask=automask, render_probability=render,
+                                              dists=dists, return_mean=True, plane_uniform=uniform,
+                                              stereo_rows=stereo_rows, defer=True)
 
             def matrices(T=T):
                 with torch.no_grad():
@@ -137,6 +142,10 @@ def pred_novel_images(self, inputs, outputs):
             raise NotImplementedError("warp_type %r: the reference's depth_warp branch raises UnboundLocalError "
                                       "(padding_mask is never assigned, trainer.py:533-538/580); use disp_warp or "
                                       "homography_warp" % (opt.warp_type,))
+        calls.append(call)
+        handles.append(handle)
+    results = ops.plane_sweep_multi(calls) if fuse_sides else [ops._PlaneSweep.apply(*c) for c in calls]
+    for target_side, handle, (rgb_rec, ph_map, ph_mean) in zip(self.target_sides, handles, results):
         outputs[("rgb_rec", target_side)] = rgb_rec
         outputs[("ph_map", target_side)] = ph_map
         outputs[("ph_mean", target_side)] = ph_mean  # ph_map.mean(), accumulated by the sweep kernel itself

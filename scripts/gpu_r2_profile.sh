@@ -79,6 +79,7 @@ PD_TORCH_HOMOGRAPHY=1 b homography_mono_f8_49_torch_algebra --warp_type homograp
 PD_UNI_FUSED=1 b homography_mono_f8_49_fused_bwd_optin --warp_type homography_warp --mono_pose
 PD_SWEEP_IMPL=4 b rows1_headline
 PD_SWEEP_IMPL=2 b fast_rows_optin
-PD_SWEEP_IMPL=3 b tile_backward_homography_stereo --warp_type homography_warp
+PD_SWEEP_IMPL=3 b tile_backward_homography_stereo --warp_type homography_warp --general_stereo
+b homography_mono_sides_one_node_per_view --warp_type homography_warp --mono_sides --per_view_nodes
 } | tee $OUT/r02_configs_table.md
 for n in bench homography_stereo homography_mono_uniform homography_colmap homography_stereo_general homography_mono_sides; do echo "== $n"; head -5 $OUT/r02_${n}_kernel_stats.csv | cut -d, -f1-5 | cut -c1-140; done

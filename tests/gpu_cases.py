@@ -75,7 +75,7 @@ def make_stub_trainer(opt, target_sides, device="cuda"):
     return StubTrainer()
 
 
-def run_product_trainer(z, meta, device="cuda", impl=None, stereo_constant=False):
+def run_product_trainer(z, meta, device="cuda", impl=None, stereo_constant=False, opt_extra=None):
     """tests/golden/trainer_mono.npz through the patched Trainer methods (pred_novel_images + compute_losses over every
     target side).  Same keys as cases.run_oracle_trainer."""
     from cases import side_key
@@ -101,7 +101,8 @@ def run_product_trainer(z, meta, device="cuda", impl=None, stereo_constant=False
     opt = types.SimpleNamespace(warp_type=meta["warp_type"], match_aug=False, use_mixture_loss=mix,
                                 automask=meta["automask"], render_probability=False, alpha_pc=0.0, alpha_self=0.0,
                                 self_distillation=0.0, gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=True,
-                                xz_levels=meta["xz_levels"], yz_levels=0, novel_frame_ids=[s for s in sides if s != "r"])
+                                xz_levels=meta["xz_levels"], yz_levels=0, novel_frame_ids=[s for s in sides if s != "r"],
+                                **(opt_extra or {}))
     trainer = make_stub_trainer(opt, sides, device)
     if impl is not None:
         ops.SWEEP_IMPL = impl

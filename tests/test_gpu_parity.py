@@ -767,6 +767,25 @@ def test_trainer_mono_fixture_through_patch_trainer(tag, stereo_constant, monkey
     print(tag, {k: "%.1e" % e for k, e in worst.items()})
 
 
+@pytest.mark.parametrize("tag,stereo_constant", [("homo3", True), ("homo3", False), ("homo_nostereo_l1", False)])
+def test_views_as_one_autograd_node_equal_one_node_per_view(tag, stereo_constant):
+    """pred_novel_images issues the target views of a step as ONE autograd node whose backward kernels add into the same
+    g_logits / g_sigma (PD_BWD_ACCUMULATE: read-modify-write stores in the plane-uniform kernels, no zero-fill in the
+    atomic ones, the row-shift view first) — against one node per view with torch's own gradient accumulation."""
+    from cases import load_trainer_fixture
+    from gpu_cases import run_product_trainer
+    z, meta = load_trainer_fixture(tag)
+    one = run_product_trainer(z, meta, stereo_constant=stereo_constant)
+    per_view = run_product_trainer(z, meta, stereo_constant=stereo_constant, opt_extra=dict(pd_fuse_sides=False))
+    for k, v in one.items():
+        w = per_view[k]
+        if float(w.abs().max()) == 0.0:
+            assert float(v.abs().max()) == 0.0, k
+            continue
+        tol = 2e-5 if k.startswith("g_Rt") or k == "g_distance" else 3e-6   # atomics / partial sums in another order
+        assert rel_err(v, w) < tol, (tag, k, rel_err(v, w))
+
+
 @pytest.mark.parametrize("tag", ["homo3", "disp_xz"])
 def test_trainer_mono_fixture_general_kernels(tag):
     """The same fixtures forced onto the general kernels (PD_IMPL_GENERAL)."""
