@@ -24,6 +24,8 @@
 //           than 12 contributors (strong minification) is left to a follow-up kernel that re-scans per plane.
 // The scratch of one image (2 x 24 MB at 49 x 192 x 640) is produced and consumed back to back, so it lives in the
 // 256 MB memory-side cache rather than in HBM.
+#include <type_traits>
+
 #include "pd_sweep_geom.h"
 
 namespace pd {
@@ -399,6 +401,164 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward, pass 2 with the scratch staged through LDS
+// ---------------------------------------------------------------------------------------------------------------
+// The gather above issues one 8-byte load per list entry, plane and lane (4-6 of them) and is paced by that instruction
+// count.  Neighbouring source pixels share most of their contributors, so here a workgroup owns a 32 x 8 tile of source
+// pixels, copies the tile's pre-image box of the scratch (~35 x 12 target pixels for pose_net rotations) to LDS with
+// coalesced loads — kStageP planes at a time, the next group's loads in flight while the current one is reduced — and
+// the list entries become ds_read_b64s.  A box that does not fit kStageBox pixels (strong rotation / minification)
+// makes the workgroup take the direct gather of the kernel above (workgroup-uniform branch, same lists).
+#ifndef PD_STAGE_P
+#define PD_STAGE_P 2
+#endif
+constexpr int kStageW = 32, kStageH = 8, kStageP = PD_STAGE_P, kStageBox = 1024;
+constexpr int kStagePre = (kStageBox * kStageP + kBlock - 1) / kBlock;   // staged elements per thread and group
+
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
+                                                                          const UniPrep* __restrict__ prep,
+                                                                          float* __restrict__ g_logits, float* __restrict__ g_sigma,
+                                                                          int* __restrict__ overflow_flag, int tiles_x, int accumulate) {
+  typedef typename std::conditional<MIX, float2, float>::type Elem;
+  __shared__ Elem buf[2][kStageP][kStageBox];
+  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
+  const int b = b0 + blockIdx.y, tid = threadIdx.x;
+  const int blk = xcd_banded(blockIdx.x, gridDim.x);
+  const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
+  const int xs0 = txi * kStageW, ys0 = tyi * kStageH;
+  const int tw_ = min(kStageW, W - xs0), th = min(kStageH, H - ys0);
+  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp + (long)blockIdx.y * 2 * N * HW);
+  const CoordNorm cn = make_coord_norm(W, H);
+  const float* Hm = a.plane + (long)b * kUniH;
+  const float* Ki = a.inv_K3 + (long)b * 9;
+  const UniPrep pr = prep[b];
+  int bx0, bx1, by0, by1;   // box of the tile: union of its corner pixels' windows (the pre-image of a convex region is convex)
+  {
+    const UniWindow w0 = uni_window(pr, xs0, ys0, W, H), w1 = uni_window(pr, xs0 + tw_ - 1, ys0 + th - 1, W, H);
+    const UniWindow w2 = uni_window(pr, xs0 + tw_ - 1, ys0, W, H), w3 = uni_window(pr, xs0, ys0 + th - 1, W, H);
+    bx0 = min(min(w0.x0, w1.x0), min(w2.x0, w3.x0)); bx1 = max(max(w0.x1, w1.x1), max(w2.x1, w3.x1));
+    by0 = min(min(w0.y0, w1.y0), min(w2.y0, w3.y0)); by1 = max(max(w0.y1, w1.y1), max(w2.y1, w3.y1));
+  }
+  const int bw = max(bx1 - bx0 + 1, 0), bh = max(by1 - by0 + 1, 0);
+  const int npx = bw * bh;
+  const bool staged = npx <= kStageBox;          // workgroup-uniform
+  const int lx = tid & (kStageW - 1), ly = tid >> 5;
+  const bool has_s = lx < tw_ && ly < th;
+  const int sx = xs0 + lx, sy = ys0 + ly;
+  int idx[kUniK];
+  float wgt[kUniK];
+#pragma unroll
+  for (int k = 0; k < kUniK; ++k) { idx[k] = 0; wgt[k] = 0.0f; }
+  int cnt = 0;
+  if (has_s) {
+    const UniWindow win = uni_window(pr, sx, sy, W, H);
+    for (int ty = win.y0; ty <= win.y1; ++ty)
+      for (int tx = win.x0; tx <= win.x1; ++tx) {
+        const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
+        const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
+        if (w != 0.0f) {
+          // a confirmed contributor lies in the box by construction; the clamp only guards the LDS index
+          const int slot = staged ? min(max((ty - by0) * bw + (tx - bx0), 0), kStageBox - 1) : ty * W + tx;
+#pragma unroll
+          for (int k = 0; k < kUniK; ++k)
+            if (k == cnt) { idx[k] = slot; wgt[k] = w; }
+          ++cnt;
+        }
+      }
+  }
+  bool live = has_s;
+  if (cnt > kUniK) { atomicOr(overflow_flag, 1); live = false; cnt = 0; }   // the follow-up kernel's pixel
+  int kmax = cnt;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, kWave));
+  kmax = __builtin_amdgcn_readfirstlane(kmax);
+  float* gl = (live && g_logits) ? g_logits + (long)b * N * HW + (long)sy * W + sx : nullptr;
+  float* gs = (live && MIX && g_sigma) ? g_sigma + (long)b * N * HW + (long)sy * W + sx : nullptr;
+
+  if (!staged) {   // the direct gather (idx = absolute pixel index)
+    for (int n = 0; n < N; ++n) {
+      const long base = (long)n * HW;
+      float accl = 0.0f, accs = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kUniK; ++k) {
+        if (k < kmax) {
+          const PairLS v = load_ls<MIX>(reinterpret_cast<const float*>(tmp_b), base + idx[k]);
+          accl += wgt[k] * v.l;
+          accs += wgt[k] * v.s;
+        }
+      }
+      if (accumulate) {
+        if (gl) accl += gl[base];
+        if (gs) accs += gs[base];
+      }
+      if (gl) gl[base] = accl;
+      if (gs) gs[base] = accs;
+    }
+    return;
+  }
+
+  // staging map: element e of a group = (plane p, box slot q); thread t copies e = t, t + 256, ...  The map is the same for
+  // every group, so its divisions are done once.
+  const int per_group = npx * kStageP;
+  int e_pl[kStagePre], e_rc[kStagePre], e_q[kStagePre];   // plane within the group (-1: none), pixel offset, box slot
+#pragma unroll
+  for (int j = 0; j < kStagePre; ++j) {
+    const int e = tid + j * kBlock;
+    const int pp = e / max(npx, 1), q = e - pp * npx;
+    const int ry = q / max(bw, 1), rx = q - ry * bw;
+    e_pl[j] = e < per_group ? pp : -1;
+    e_rc[j] = (by0 + ry) * W + (bx0 + rx);
+    e_q[j] = q;
+  }
+  Elem pre[kStagePre];
+  auto issue = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < kStagePre; ++j) {
+      Elem v = Elem();
+      if (e_pl[j] >= 0) v = tmp_b[(long)min(n0 + e_pl[j], N - 1) * HW + e_rc[j]];
+      pre[j] = v;
+    }
+  };
+  auto park = [&](int which) {
+#pragma unroll
+    for (int j = 0; j < kStagePre; ++j)
+      if (e_pl[j] >= 0) buf[which][e_pl[j]][e_q[j]] = pre[j];
+  };
+  issue(0);
+  park(0);
+  int which = 0;
+  for (int n0 = 0; n0 < N; n0 += kStageP, which ^= 1) {
+    __syncthreads();                               // buf[which] complete; buf[which ^ 1] no longer read by anybody
+    const bool more = n0 + kStageP < N;
+    if (more) issue(n0 + kStageP);                 // in flight while this group is reduced
+#pragma unroll
+    for (int p = 0; p < kStageP; ++p) {
+      const int n = n0 + p;
+      if (n < N) {
+        const long base = (long)n * HW;
+        float accl = 0.0f, accs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kUniK; ++k) {
+          if (k < 4 || k < kmax) {
+            const Elem v = buf[which][p][idx[k]];
+            if constexpr (MIX) { accl += wgt[k] * v.x; accs += wgt[k] * v.y; }
+            else accl += wgt[k] * v;
+          }
+        }
+        if (accumulate) {
+          if (gl) accl += gl[base];
+          if (gs) accs += gs[base];
+        }
+        if (gl) gl[base] = accl;
+        if (gs) gs[base] = accs;
+      }
+    }
+    if (more) park(which ^ 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward, fused: pass 1 and pass 2 in one kernel, the per-plane gradients handed over through LDS
 // ---------------------------------------------------------------------------------------------------------------
 // A workgroup of 1024 threads owns a 16 x 40 tile of source pixels of image b (192 x 640: 12 x 16 tiles, six full
@@ -669,13 +829,20 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   for (int b0 = 0; b0 < d->B && !rc; b0 += chunk) {
     const int nb = (d->B - b0) < chunk ? (d->B - b0) : chunk;
     dim3 grid(nblk, nb);
+    const int stiles_x = ceil_div(d->W, kStageW);
+    dim3 sgrid(stiles_x * ceil_div(d->H, kStageH), nb);
+    // pass 2 with the scratch staged through LDS unless the fused kernel is selected (its run_flag protocol belongs to
+    // the direct-gather kernel) or PD_UNI_DIRECT asks for the direct gather
+    const bool staged = !fused && !getenv("PD_UNI_DIRECT");
     if (mix) {
       uniform_bwd_pass1_kernel<true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
-      uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
+      if (staged) uniform_bwd_pass2_staged_kernel<true><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, stiles_x, accumulate);
+      else uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
     } else {
       uniform_bwd_pass1_kernel<false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
-      uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
+      if (staged) uniform_bwd_pass2_staged_kernel<false><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, stiles_x, accumulate);
+      else uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
     }
     rc = check_launch("uniform_bwd_pass kernels");
