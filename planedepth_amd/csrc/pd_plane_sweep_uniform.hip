@@ -409,6 +409,10 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
 // coalesced loads — kStageP planes at a time, the next group's loads in flight while the current one is reduced — and
 // the list entries become ds_read_b64s.  A box that does not fit kStageBox pixels (strong rotation / minification)
 // makes the workgroup take the direct gather of the kernel above (workgroup-uniform branch, same lists).
+// Measured at 8x49x192x640: 0.329 -> 0.215 ms.  The same staging for the TARGET-side kernels (forward, pass 1: logits and
+// sigma boxes in LDS, taps as ds_reads) was built and measured SLOWER — forward 0.140 -> 0.199 ms, pass 1 0.188 ->
+// 0.277 ms: those kernels are bound by their arithmetic, and eight ds_reads + a barrier per plane pair come on top — so
+// they keep their direct gathers.
 #ifndef PD_STAGE_P
 #define PD_STAGE_P 2
 #endif
