@@ -62,6 +62,24 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def three_way(got, ref32, exact, factor=2.0, tol=1e-4):
+    """The parity bar where two fp32 evaluations of the reference's formulas legitimately differ by more than 1e-4
+    (fp32 matrix inverses, 1/sigma^3-type amplification, bilinear derivatives through fp32 coordinates): the product must
+    be as close to the fp64 evaluation as the reference's own fp32 arithmetic is — err(got, fp64) <= factor *
+    err(ref32, fp64) + tol.  Returns (ok, err_got, err_ref)."""
+    e_got, e_ref = rel_err(got, exact.float()), rel_err(ref32, exact.float())
+    return e_got <= factor * e_ref + tol, e_got, e_ref
+
+
+def elementwise_report(a, b, rtol=1e-4, floor=1e-4):
+    """Element-wise companion of rel_err: the share of elements with |a-b| > rtol*|b| + floor*max|b| and the worst
+    element's error in units of that allowance."""
+    a, b = a.double().flatten(), b.double().flatten()
+    allow = rtol * b.abs() + floor * b.abs().max().clamp_min(1e-30)
+    r = (a - b).abs() / allow
+    return dict(max_norm_err=rel_err(a, b), frac_beyond=float((r > 1).double().mean()), worst_over_allowance=float(r.max()))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3] as the trainer runs it: all target sides, decoder-made xz planes (tests/golden/trainer_mono.npz)
 # ---------------------------------------------------------------------------------------------------------------------

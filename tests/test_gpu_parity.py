@@ -21,6 +21,21 @@ NOT_YET = set()
 ILL_CONDITIONED = {"homo_mix_stereo": {"g_Rt"}}
 
 
+def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0):
+    """Three-way bound (cases.three_way) of a product result against the oracle in fp32 (the reference's arithmetic) and
+    in fp64 (the same formulas, exact to ~1e-13)."""
+    from cases import three_way
+    ref32, exact = run_oracle(case, run), run_oracle(case, run, dtype=torch.float64)
+    for k, w in exact.items():
+        if k not in got or (keys and k not in keys) or k in skip:
+            continue
+        if float(w.abs().max()) == 0.0:
+            assert float(got[k].abs().max()) < 1e-6, (tag, k)
+            continue
+        ok, e_got, e_ref = three_way(got[k], ref32[k], w)
+        assert ok, (tag, k, e_got, e_ref)
+
+
 def _compare(got, want, keys=None, tol=TOL, tag="", skip=()):
     for k, w in want.items():
         if k not in got or (keys and k not in keys) or k in skip:
@@ -69,17 +84,19 @@ def test_dense_disparity_path_matches_per_plane_path(name):
 def test_random_cases_vs_oracle(seed, kw, run):
     """Ragged sizes (W not a multiple of 64, odd H), many planes, against the oracle (fp32, the reference's arithmetic).
 
-    homography_warp end to end is looser (5e-3): H_t2s = inverse(K (R + t n^T/d) K^-1) is formed in fp32 by
-    torch.inverse on both sides (rocSOLVER here, LAPACK in the oracle) and cond(H) ~ 1e3-1e4 turns its last-ulp
-    differences into ~1e-4-relative coordinate differences — the reference's own CPU and GPU runs differ by that
-    much.  The kernel itself is held to 1e-4 with H_t2s pinned in the next test."""
+    homography_warp end to end uses the three-way bound: H_t2s = inverse(K (R + t n^T/d) K^-1) is
+    an fp32 torch.inverse in the reference (LAPACK / cuSOLVER / rocSOLVER: three roundings) and cond(H) ~ 1e3-1e4 turns
+    its last-ulp differences into ~1e-4-relative coordinate differences, so the product has to be as
+    close to the fp64 evaluation as the fp32 oracle is.  The kernel itself is held to 1e-4 with H_t2s pinned in the
+    next test.  (g_Rt of the stereo pose: ILL_CONDITIONED, every sample on an integer row.)"""
     from gpu_cases import run_product
     from planedepth_amd.synthetic import build_case
     case = build_case(seed=seed, sigma_interior=True, **kw)
     got = run_product(case, run)
-    want = run_oracle(case, run)
-    tol = 5e-3 if run.get("warp_type") == "homography_warp" else TOL
-    _compare(got, want, tag="seed%d" % seed, tol=tol)
+    if run.get("warp_type") == "homography_warp":
+        _compare3(got, case, run, tag="seed%d" % seed, skip=("g_Rt",))
+    else:
+        _compare(got, run_oracle(case, run), tag="seed%d" % seed)
 
 
 @pytest.mark.parametrize("mix,automask", [(True, False), (True, True), (False, True)])
@@ -154,8 +171,12 @@ def test_rowshift_kernels_vs_general_kernels_and_oracle(W, side, disps):
     # follows the reference's fp32 op order lands on the same side (the fp64 oracle legitimately differs there).
     want = run_oracle(case, run)
     keys = ("rgb_rec", "ph_map", "g_logits", "g_sigma", "g_disp_pp")
-    _compare(slow, {k: want[k] for k in keys}, tag="general/W%d" % W, tol=2e-4)
-    _compare(fast, {k: want[k] for k in keys}, tag="rowshift/W%d" % W, tol=2e-4)
+    # g_disp_pp at 2e-4: with (almost-)integer shifts the bilinear derivative is a one-sided difference that switches
+    # sides with the last ulp of the coordinate — the disparities of this test are chosen to sit exactly there
+    _compare(slow, {k: want[k] for k in keys if k != "g_disp_pp"}, tag="general/W%d" % W)
+    _compare(fast, {k: want[k] for k in keys if k != "g_disp_pp"}, tag="rowshift/W%d" % W)
+    _compare(slow, {"g_disp_pp": want["g_disp_pp"]}, tag="general/W%d" % W, tol=2e-4)
+    _compare(fast, {"g_disp_pp": want["g_disp_pp"]}, tag="rowshift/W%d" % W, tol=2e-4)
     for k in ("g_logits", "g_sigma"):  # the only deliberate difference: the eps-weighted cross-row adjoint term
         assert rel_err(fast[k], slow[k]) < 3e-5, (k, rel_err(fast[k], slow[k]))
 
@@ -200,21 +221,30 @@ def test_fullsize_known_answers():
     with open(os.path.join(GOLDEN, "kat_fullsize.json")) as f:
         kat = json.load(f)
     case = survey_fullsize_case()
+    sums = lambda r: dict(ph_loss=float(r["ph_loss"]), sum_rgb_rec=float(r["rgb_rec"].double().sum()),  # noqa: E731
+                          l1_g_logits=float(r["g_logits"].double().abs().sum()),
+                          l1_g_sigma=float(r["g_sigma"].double().abs().sum()),
+                          l1_g_disp_pp=float(r["g_disp_pp"].double().abs().sum()))
     for name, k in kat.items():
-        got = run_product(case, k["run"])
-        close = lambda a, b, tol=TOL: abs(a - b) <= tol * max(abs(b), 1e-30)  # noqa: E731
-        # homography_warp: the reference's own fp32 inverse moves the loss by 1.6e-4 relative to its disp_warp
-        # twin (0.78829277 vs 0.78841859); the HIP result lands next to disp_warp's.
-        ftol = 5e-4 if k["run"].get("warp_type") == "homography_warp" else TOL
-        assert close(float(got["ph_loss"]), k["ph_loss"], ftol), (name, float(got["ph_loss"]), k["ph_loss"])
-        assert close(float(got["rgb_rec"].double().sum()), k["sum_rgb_rec"], ftol), name
-        assert close(float(got["g_logits"].double().abs().sum()), k["l1_g_logits"], 5 * ftol), name
-        # the prescribed inputs put 1% of sigma exactly ON the clamp bound 0.01, where the clamp's gradient gate flips
-        # with the last ulp of the interpolated value (oracle fp32 vs fp64 disagree there too): looser bound on the
-        # two sums that see it.  g_Rt of the stereo homography is ill-conditioned altogether (see ILL_CONDITIONED).
-        if k["l1_g_sigma"]:
-            assert close(float(got["g_sigma"].double().abs().sum()), k["l1_g_sigma"], 5e-3), name
-        assert close(float(got["g_disp_pp"].double().abs().sum()), k["l1_g_disp_pp"], 5e-3), name
+        got = sums(run_product(case, k["run"]))
+        # The reference's captured scalars at 1e-4 where its fp32 arithmetic is the thing to match (disp_warp: ph_loss,
+        # sum rgb_rec, |g_logits|).  Three-way against the fp64 oracle where two fp32 evaluations legitimately differ:
+        # homography_warp (the reference's own fp32 inverse moves its loss by 1.6e-4 relative to its disp_warp twin,
+        # SURVEY.md H2 / BASELINE.md section 4: 0.78829277 vs 0.78841859) and the two sums that see the 1 % of sigma
+        # the prescribed inputs put exactly ON the clamp bound 0.01, where the clamp's gradient gate flips with the
+        # last ulp of the interpolated value.
+        homo = k["run"].get("warp_type") == "homography_warp"
+        exact = None
+        for key, v in got.items():
+            ref = k[key]
+            if not ref:
+                continue
+            if not homo and key in ("ph_loss", "sum_rgb_rec", "l1_g_logits"):
+                assert abs(v - ref) <= TOL * abs(ref), (name, key, v, ref)
+                continue
+            if exact is None:
+                exact = sums(run_oracle(case, k["run"], dtype=torch.float64))
+            assert abs(v - exact[key]) <= 2.0 * abs(ref - exact[key]) + TOL * abs(exact[key]), (name, key, v, ref, exact[key])
 
 
 def test_fullsize_vs_oracle_tensors():
@@ -227,16 +257,15 @@ def test_fullsize_vs_oracle_tensors():
         want = run_oracle(case, run)  # fp32: at x ~ 600 the fp32 coordinate rounding of the reference itself moves
         # results by 1e-4..3e-2 relative to exact arithmetic (scripts/diag_errors.py), so "the reference's fp32
         # arithmetic" is the thing to match, as BASELINE.json's north_star asks.
-        _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_disp_pp"), tag=str(run))
-        # g_sigma carries 1/sigma^3-type amplification: two fp32 evaluations agree to 1.1e-4 here while either is
-        # 2.6e-4 away from the fp64 value.
-        _compare(got, want, keys=("g_sigma",), tag=str(run), tol=2e-4)
+        # (g_sigma carries 1/sigma^3-type amplification — the fp32 oracle is 2.6e-4 away from the fp64 value — and was
+        # held to 2e-4 in round 1; measured 3.4e-6 against the fp32 oracle now: profiles/r02_parity.md)
+        _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=str(run))
 
 
 def test_fast_rows_mode_is_opt_in_and_bounded():
     """PD_IMPL_FAST_ROWS drops a second source row whose bilinear weight is below 2^-16 (fp32 noise of the reference's y
     round trip, a quarter of the rows at H=192).  The default keeps it (rounding-level agreement with the fp32 oracle);
-    the opt-in mode stays within the parity budget on random data (g_sigma at its usual 2e-4, see
+    the opt-in mode stays within the parity budget on random data (g_sigma under the three-way bound, see
     test_fullsize_vs_oracle_tensors)."""
     from gpu_cases import run_product
     from planedepth_amd import _capi as C
@@ -253,7 +282,7 @@ def test_fast_rows_mode_is_opt_in_and_bounded():
         ops.SWEEP_IMPL = C.PD_IMPL_AUTO
     _compare(exact, want, keys=keys, tag="default", tol=1.5e-5)
     _compare(fast, want, keys=keys, tag="fast_rows", tol=1e-4)
-    _compare(fast, want, keys=("g_sigma",), tag="fast_rows", tol=2e-4)
+    _compare3(fast, case, dict(), keys=("g_sigma",), tag="fast_rows")
     assert not torch.equal(fast["rgb_rec"], exact["rgb_rec"])  # the two modes really are different code paths
 
 
@@ -346,19 +375,28 @@ def test_geometry_and_sampling_gradients_vs_oracle():
     depth = torch.rand(B, 1, H, W, generator=g) * 5 + 0.5
     img = torch.rand(B, C, H, W, generator=g)
     gw = torch.randn(B, C, H, W, generator=g)
+    from cases import three_way
+
+    def chain(dt, pad):   # the reference's operators (oracle restatement) in the given precision
+        dd, TT, im = (v.detach().clone().to(dt).requires_grad_(True) for v in (depth, T, img))
+        cam = orc.backproject_depth(dd, inv_K.to(dt))
+        grid = orc.project_3d(cam, K.to(dt), TT, H, W)
+        (orc.bilinear_sample(im, grid, pad) * gw.to(dt)).sum().backward()
+        return dd, TT, im, grid
+
     for pad in ("zeros", "border"):
-        d64, T64, im64 = depth.double().requires_grad_(True), T.double().requires_grad_(True), img.double().requires_grad_(True)
-        cam = orc.backproject_depth(d64, inv_K.double())
-        grid = orc.project_3d(cam, K.double(), T64, H, W)
-        (orc.bilinear_sample(im64, grid, pad) * gw.double()).sum().backward()
+        d64, T64, im64, grid = chain(torch.float64, pad)
+        d32, T32, _, _ = chain(torch.float32, pad)
         dg, Tg, ig = depth.cuda().requires_grad_(True), T.cuda().requires_grad_(True), img.cuda().requires_grad_(True)
         camg = pa.BackprojectDepth(H, W)(dg, inv_K.cuda())
         gridg = pa.Project3D(H, W)(camg, K.cuda(), Tg)
         out = ops.grid_sample(ig, gridg, padding_mode=pad)
         (out * gw.cuda()).sum().backward()
         assert rel_err(gridg.detach().cpu(), grid.detach().float()) < TOL
-        assert rel_err(dg.grad.cpu(), d64.grad.float()) < 2e-4, pad
-        assert rel_err(Tg.grad.cpu(), T64.grad.float()) < 2e-4, pad
+        # gradients THROUGH the fp32 sampling coordinates (bilinear derivative = difference of neighbours / rounding of
+        # the position): three-way against the same chain in torch fp32
+        assert three_way(dg.grad.cpu(), d32.grad, d64.grad)[0], (pad, three_way(dg.grad.cpu(), d32.grad, d64.grad))
+        assert three_way(Tg.grad.cpu(), T32.grad, T64.grad)[0], (pad, three_way(Tg.grad.cpu(), T32.grad, T64.grad))
         assert rel_err(ig.grad.cpu(), im64.grad.float()) < TOL, pad
     # HomographyWarp backward
     N = 3
@@ -366,14 +404,18 @@ def test_geometry_and_sampling_gradients_vs_oracle():
     n = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
     gg = torch.randn(B * N, H, W, 2, generator=g)
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
-    d64, T64 = d.double().requires_grad_(True), T.double().requires_grad_(True)
-    grid, _ = orc.homography_grid(d64, n.double(), ex(T64), ex(K.double()), ex(inv_K.double()), H, W)
-    (grid * gg.double()).sum().backward()
+    def hchain(dt):
+        dd, TT = d.detach().clone().to(dt).requires_grad_(True), T.detach().clone().to(dt).requires_grad_(True)
+        gr, _ = orc.homography_grid(dd, n.to(dt), ex(TT), ex(K.to(dt)), ex(inv_K.to(dt)), H, W)
+        (gr * gg.to(dt)).sum().backward()
+        return dd, TT
+
+    (d64, T64), (d32, T32) = hchain(torch.float64), hchain(torch.float32)
     dg, Tg = d.cuda().requires_grad_(True), T.cuda().requires_grad_(True)
     gridg, _ = pa.HomographyWarp(H, W)(dg, n.cuda(), ex(Tg), ex(K.cuda()), ex(inv_K.cuda()))
     (gridg * gg.cuda()).sum().backward()
-    assert rel_err(dg.grad.cpu(), d64.grad.float()) < 2e-4
-    assert rel_err(Tg.grad.cpu(), T64.grad.float()) < 2e-4
+    assert three_way(dg.grad.cpu(), d32.grad, d64.grad)[0], three_way(dg.grad.cpu(), d32.grad, d64.grad)
+    assert three_way(Tg.grad.cpu(), T32.grad, T64.grad)[0], three_way(Tg.grad.cpu(), T32.grad, T64.grad)
     # SSIM backward w.r.t. both inputs
     x, y = torch.rand(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g)
     x64, y64 = x.double().requires_grad_(True), y.double().requires_grad_(True)
@@ -606,8 +648,7 @@ def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extr
     if label == "n63_xz":
         assert ops.LAST_SWEEP_FLAGS & C.PD_DISP_ROWS and ops.LAST_SWEEP_FLAGS & C.PD_MASK_ROWS
     want = run_oracle(case, run)
-    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_disp_pp"), tag=label)
-    _compare(got, want, keys=("g_sigma",), tag=label, tol=2e-4)
+    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=label)
 
 
 @pytest.mark.parametrize("impl", ["rows", "general"])
@@ -652,12 +693,16 @@ def test_pred_self_images_vs_oracle():
     color = torch.rand(B, 3, H, W, generator=g)
     gw = torch.randn(B, 3, H, W, generator=g)
 
-    d64 = disp.double().requires_grad_(True)
-    depth = 0.1 * 0.58 * W / d64
-    cam = orc.backproject_depth(depth, inv_K.double())
-    grid = orc.project_3d(cam, K.double(), T.double(), H, W)
-    want = orc.bilinear_sample(color.double(), grid, "border")
-    (want * gw.double()).sum().backward()
+    from cases import three_way
+
+    def chain(dt):
+        dd = disp.detach().clone().to(dt).requires_grad_(True)
+        cam = orc.backproject_depth(0.1 * 0.58 * W / dd, inv_K.to(dt))
+        out = orc.bilinear_sample(color.to(dt), orc.project_3d(cam, K.to(dt), T.to(dt), H, W), "border")
+        (out * gw.to(dt)).sum().backward()
+        return dd, out
+
+    (d64, want), (d32, _) = chain(torch.float64), chain(torch.float32)
 
     dg = disp.cuda().requires_grad_(True)
     ns = types.SimpleNamespace(opt=types.SimpleNamespace(match_aug=False))
@@ -666,7 +711,8 @@ def test_pred_self_images_vs_oracle():
     pa.pred_self_images(ns, inputs, outputs)
     (outputs["self_rec"] * gw.cuda()).sum().backward()
     assert rel_err(outputs["self_rec"].detach().cpu(), want.detach().float()) < TOL
-    assert rel_err(dg.grad.cpu(), d64.grad.float()) < 5e-4   # bilinear derivative through fp32 coordinates
+    # bilinear derivative through fp32 coordinates: as close to fp64 as the same chain in torch fp32 is
+    assert three_way(dg.grad.cpu(), d32.grad, d64.grad)[0], three_way(dg.grad.cpu(), d32.grad, d64.grad)
 
 
 @pytest.mark.parametrize("seed,kw,run", [
@@ -685,9 +731,10 @@ def test_degenerate_shapes_vs_oracle(seed, kw, run):
     from planedepth_amd.synthetic import build_case
     case = build_case(seed=seed, sigma_interior=True, **kw)
     got = run_product(case, run)
-    want = run_oracle(case, run)
-    tol = 5e-3 if run.get("warp_type") == "homography_warp" else TOL
-    _compare(got, want, tag="seed%d" % seed, tol=tol)
+    if run.get("warp_type") == "homography_warp":
+        _compare3(got, case, run, tag="seed%d" % seed)
+    else:
+        _compare(got, run_oracle(case, run), tag="seed%d" % seed)
 
 
 def test_randomised_shapes_rowshift_vs_general():
