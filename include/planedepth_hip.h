@@ -337,6 +337,16 @@ int pd_grid_sample_fwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding
 int pd_grid_sample_bwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding_mode, const float* input,
                        const float* grid, const float* g_out, float* g_input, float* g_grid, pd_stream_t stream);
 
+/*
+ * Diagnostics (used by tests/ and scripts/, not by the product path).
+ *   pd_selftest_division        counts, over `count` samples lo + i*step, where the row kernels' fast division by W-1
+ *                               (refined reciprocal) differs from the IEEE quotient; *d_mismatches (device int) += count.
+ *   pd_debug_rowquad_occupancy  out[0], out[1] = resident workgroups per CU of the opt-in row-quad forward / backward
+ *                               kernels for a row of W pixels and N planes (hipOccupancyMaxActiveBlocksPerMultiprocessor).
+ */
+int pd_selftest_division(float Wm1, int count, float lo, float step, int* d_mismatches, pd_stream_t stream);
+int pd_debug_rowquad_occupancy(int W, int N, int* out);
+
 #ifdef __cplusplus
 }
 #endif

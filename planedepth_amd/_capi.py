@@ -61,6 +61,8 @@ SIGNATURES = {
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
+    "pd_selftest_division": (_I, [_F, _I, _F, _F, _P, _P]),
+    "pd_debug_rowquad_occupancy": (_I, [_I, _I, _P]),
     "pd_masked_photometric_fwd": (_I, [_I] * 4 + [_P] * 9),
     "pd_masked_photometric_bwd": (_I, [_I] * 4 + [_P] * 9),
     "pd_homography_matrices_fwd": (_I, [_I] * 4 + [_P] * 10),
