@@ -24,8 +24,11 @@ def init_process_group_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # a rank that died must not leave the others (and the GPU box) waiting in a collective for the default 10-30 min
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("PD_PG_TIMEOUT_S", "240")))
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
-                                rank=rank, world_size=world)
+                                rank=rank, world_size=world, timeout=timeout)
     return rank, world, local_rank
 
 
