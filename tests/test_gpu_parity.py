@@ -636,6 +636,8 @@ def test_add_flip_right_inputs_is_bit_exact():
     ("n63_xz", dict(B=1, N=63, H=192, W=640, n_xz=14), dict(automask=True), dict(yz_levels=0, xz_levels=14)),
     # BASELINE config (5): high resolution
     ("hr", dict(B=1, N=49, H=384, W=1280), dict(), dict(yz_levels=0, xz_levels=0)),
+    # BASELINE configs[2]: batch 12 per GPU — every tensor of all twelve images (the loss mean runs over the whole batch)
+    ("batch12", dict(B=12, N=49, H=192, W=640), dict(), dict(yz_levels=0, xz_levels=0)),
 ])
 def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extra):
     """The other full-size configurations of BASELINE.json / SURVEY §8d against the fp32 oracle (B=1)."""
