@@ -135,20 +135,76 @@ __global__ __launch_bounds__(kWave) void homography_matrices_fwd_kernel(
         h[i][q] = (float)c.H.m[i][q];
         if (H_t2s) H_t2s[((long)b * NH + j) * 9 + i * 3 + q] = h[i][q];
       }
-    if (mode != PD_HMAT_STEREO_ROWS) continue;
-    // per-row shift and mask (layers.py:219-229 at x = 0: h00 = 1 and the x terms of the facing test vanish)
-    const float ik01 = inv_K[(long)b * 16 + 1], ik02 = inv_K[(long)b * 16 + 2], ik11 = inv_K[(long)b * 16 + 5],
-                ik12 = inv_K[(long)b * 16 + 6], ik21 = inv_K[(long)b * 16 + 9], ik22 = inv_K[(long)b * 16 + 10];
-    for (int y = 0; y < rows; ++y) {
-#pragma clang fp contract(off)
-      const float fy = (float)y;
-      const float facing = (ik01 * fy + ik02) * rn[0] + (ik11 * fy + ik12) * rn[1] + (ik21 * fy + ik22) * rn[2];
-      const float z = h[2][1] * fy + h[2][2];
-      const long o = ((long)b * N + j) * rows + y;
-      shift[o] = (float)(c.H.m[0][1] * (double)y + c.H.m[0][2]);   // one rounding
-      mask[o] = (facing > 0.0f && z > 1e-7f) ? 1.0f : 0.0f;
-    }
   }
+}
+
+// PD_HMAT_STEREO_ROWS: one wave per (plane, image); the 3x3 chain is evaluated by every lane (a few hundred flops) and the
+// lanes stride over the rows.  (As a serial loop over the rows inside the per-image kernel above these took 13 + 22 us
+// per step at 8 x 49 x 192.)
+__global__ __launch_bounds__(kWave) void stereo_rows_fwd_kernel(
+    int N, int rows, const float* __restrict__ distance, const float* __restrict__ norm, const float* __restrict__ T,
+    const float* __restrict__ K, const float* __restrict__ inv_K, float* __restrict__ H_t2s, float* __restrict__ Rn,
+    float* __restrict__ shift, float* __restrict__ mask) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  const long k = (long)b * N + j;
+  float rn[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {   // R n (layers.py:223)
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s += (double)T[(long)b * 16 + i * 4 + q] * (double)norm[k * 3 + q];
+    rn[i] = (float)s;
+    if (Rn && threadIdx.x == 0) Rn[k * 3 + i] = rn[i];
+  }
+  const Chain c = homography_chain(T, K, inv_K, b, plane_of(PD_HMAT_STEREO_ROWS, b, j, N, distance, norm));
+  if (H_t2s && threadIdx.x < 9) H_t2s[k * 9 + threadIdx.x] = (float)c.H.m[threadIdx.x / 3][threadIdx.x % 3];
+  // per-row shift and mask (layers.py:219-229 at x = 0: h00 = 1 and the x terms of the facing test vanish)
+  const float ik01 = inv_K[(long)b * 16 + 1], ik02 = inv_K[(long)b * 16 + 2], ik11 = inv_K[(long)b * 16 + 5],
+              ik12 = inv_K[(long)b * 16 + 6], ik21 = inv_K[(long)b * 16 + 9], ik22 = inv_K[(long)b * 16 + 10];
+  const float h21 = (float)c.H.m[2][1], h22 = (float)c.H.m[2][2];
+  for (int y = threadIdx.x; y < rows; y += kWave) {
+#pragma clang fp contract(off)
+    const float fy = (float)y;
+    const float facing = (ik01 * fy + ik02) * rn[0] + (ik11 * fy + ik12) * rn[1] + (ik21 * fy + ik22) * rn[2];
+    const float z = h21 * fy + h22;
+    shift[k * rows + y] = (float)(c.H.m[0][1] * (double)y + c.H.m[0][2]);   // one rounding
+    mask[k * rows + y] = (facing > 0.0f && z > 1e-7f) ? 1.0f : 0.0f;
+  }
+}
+
+// shift = h01 * y + h02  ->  g_h01 = sum_y y g, g_h02 = sum_y g  ->  (adjoint of the chain)  ->  g_distance
+__global__ __launch_bounds__(kWave) void stereo_rows_bwd_kernel(
+    int N, int rows, const float* __restrict__ distance, const float* __restrict__ norm, const float* __restrict__ T,
+    const float* __restrict__ K, const float* __restrict__ inv_K, const float* __restrict__ g_H,
+    const float* __restrict__ g_shift, float* __restrict__ g_distance) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  const long k = (long)b * N + j;
+  double s1 = 0.0, s0 = 0.0;
+  if (g_shift)
+    for (int y = threadIdx.x; y < rows; y += kWave) {
+      const double g = (double)g_shift[k * rows + y];
+      s1 += g * (double)y;
+      s0 += g;
+    }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, kWave); s0 += __shfl_xor(s0, off, kWave); }
+  if (threadIdx.x != 0 || !g_distance) return;
+  const PlaneOf p = plane_of(PD_HMAT_STEREO_ROWS, b, j, N, distance, norm);
+  const Chain c = homography_chain(T, K, inv_K, b, p);
+  M3 gH;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gH.m[i][q] = g_H ? (double)g_H[k * 9 + i * 3 + q] : 0.0;
+  gH.m[0][1] += s1;
+  gH.m[0][2] += s0;
+  const M3 Ht = transpose3(c.H);
+  const M3 gA = mul3(Ht, mul3(gH, Ht));            // (sign applied below)
+  const M3 gM = mul3(transpose3(c.K), mul3(gA, transpose3(c.Ki)));
+  double tgMn = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tgMn += c.t[i] * (gM.m[i][0] * p.n[0] + gM.m[i][1] * p.n[1] + gM.m[i][2] * p.n[2]);
+  g_distance[k] = (float)(tgMn / (p.d * p.d));     // -(-t^T gM n) / d^2
 }
 
 // Adjoint.  dH_t2s = -H dA H  ->  gA = -H^T gH H^T ;  A = K M K^-1  ->  gM = K^T gA K^-T ;
@@ -171,16 +227,6 @@ __global__ __launch_bounds__(kWave) void homography_matrices_bwd_kernel(
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q) gH.m[i][q] = g_H ? (double)g_H[((long)b * NH + j) * 9 + i * 3 + q] : 0.0;
-    if (mode == PD_HMAT_STEREO_ROWS && g_shift) {   // shift = h01 * y + h02
-      double s1 = 0.0, s0 = 0.0;
-      for (int y = 0; y < rows; ++y) {
-        const double g = (double)g_shift[((long)b * N + j) * rows + y];
-        s1 += g * (double)y;
-        s0 += g;
-      }
-      gH.m[0][1] += s1;
-      gH.m[0][2] += s0;
-    }
     const M3 Ht = transpose3(c.H);
     M3 gA = mul3(Ht, mul3(gH, Ht));
 #pragma unroll
@@ -256,6 +302,12 @@ extern "C" int pd_homography_matrices_fwd(int B, int N, int mode, int rows, cons
   PD_REQUIRE(mode == PD_HMAT_PLANES || mode == PD_HMAT_UNIFORM || mode == PD_HMAT_STEREO_ROWS, "bad mode");
   PD_REQUIRE(distance && norm && T && K && inv_K, "null input");
   PD_REQUIRE(mode == PD_HMAT_STEREO_ROWS ? (rows > 0 && shift && mask) : H_t2s != nullptr, "null output");
+  if (mode == PD_HMAT_STEREO_ROWS) {
+    PD_REQUIRE(B <= 65535, "bad shape");
+    stereo_rows_fwd_kernel<<<dim3(N, B), kWave, 0, (hipStream_t)stream>>>(N, rows, distance, norm, T, K, inv_K, H_t2s, Rn,
+                                                                            shift, mask);
+    return check_launch("stereo_rows_fwd_kernel");
+  }
   homography_matrices_fwd_kernel<<<B, kWave, 0, (hipStream_t)stream>>>(B, N, homography_slots(mode, N), mode, rows,
                                                                         distance, norm, T, K, inv_K, H_t2s, Rn, shift, mask);
   return check_launch("homography_matrices_fwd_kernel");
@@ -269,6 +321,12 @@ extern "C" int pd_homography_matrices_bwd(int B, int N, int mode, int rows, cons
   PD_REQUIRE(mode == PD_HMAT_PLANES || mode == PD_HMAT_UNIFORM || mode == PD_HMAT_STEREO_ROWS, "bad mode");
   PD_REQUIRE(distance && norm && T && K && inv_K, "null input");
   PD_REQUIRE(g_H || (mode == PD_HMAT_STEREO_ROWS && g_shift && rows > 0), "no upstream gradient");
+  if (mode == PD_HMAT_STEREO_ROWS) {   // g_distance only (see the header): the pose and the normals are constants there
+    PD_REQUIRE(B <= 65535 && !g_norm && !g_T, "PD_HMAT_STEREO_ROWS carries the gradient of distance only");
+    stereo_rows_bwd_kernel<<<dim3(N, B), kWave, 0, (hipStream_t)stream>>>(N, rows, distance, norm, T, K, inv_K, g_H, g_shift,
+                                                                            g_distance);
+    return check_launch("stereo_rows_bwd_kernel");
+  }
   homography_matrices_bwd_kernel<<<B, kWave, 0, (hipStream_t)stream>>>(B, N, homography_slots(mode, N), mode, rows,
                                                                         distance, norm, T, K, inv_K, g_H, g_shift,
                                                                         g_distance, g_norm, g_T);

@@ -529,19 +529,39 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
     for (int j = 0; j < kStagePre; ++j)
       if (e_pl[j] >= 0) buf[which][e_pl[j]][e_q[j]] = pre[j];
   };
+  // PD_BWD_ACCUMULATE: the values already in g_logits / g_sigma are fetched one group ahead, with the staging loads (read
+  // at the point of use they put a full memory round trip between every plane's gather and its store: 0.218 -> 0.405 ms)
+  float nextl[kStageP], nexts[kStageP];
+  auto fetch_old = [&](int n0) {
+#pragma unroll
+    for (int p = 0; p < kStageP; ++p) {
+      nextl[p] = 0.0f; nexts[p] = 0.0f;
+      if (accumulate && n0 + p < N) {
+        if (gl) nextl[p] = gl[(long)(n0 + p) * HW];
+        if (gs) nexts[p] = gs[(long)(n0 + p) * HW];
+      }
+    }
+  };
   issue(0);
+  fetch_old(0);
   park(0);
   int which = 0;
   for (int n0 = 0; n0 < N; n0 += kStageP, which ^= 1) {
     __syncthreads();                               // buf[which] complete; buf[which ^ 1] no longer read by anybody
     const bool more = n0 + kStageP < N;
-    if (more) issue(n0 + kStageP);                 // in flight while this group is reduced
+    float oldl[kStageP], olds[kStageP];
+#pragma unroll
+    for (int p = 0; p < kStageP; ++p) { oldl[p] = nextl[p]; olds[p] = nexts[p]; }
+    if (more) {                                    // in flight while this group is reduced
+      issue(n0 + kStageP);
+      fetch_old(n0 + kStageP);
+    }
 #pragma unroll
     for (int p = 0; p < kStageP; ++p) {
       const int n = n0 + p;
       if (n < N) {
         const long base = (long)n * HW;
-        float accl = 0.0f, accs = 0.0f;
+        float accl = oldl[p], accs = olds[p];
 #pragma unroll
         for (int k = 0; k < kUniK; ++k) {
           if (k < 4 || k < kmax) {
@@ -549,10 +569,6 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
             if constexpr (MIX) { accl += wgt[k] * v.x; accs += wgt[k] * v.y; }
             else accl += wgt[k] * v;
           }
-        }
-        if (accumulate) {
-          if (gl) accl += gl[base];
-          if (gs) accs += gs[base];
         }
         if (gl) gl[base] = accl;
         if (gs) gs[base] = accs;

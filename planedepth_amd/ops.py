@@ -277,7 +277,7 @@ def _per_plane_view(disp_layered):
 
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
                      use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False,
-                     return_mean=False, defer=False):
+                     return_mean=False, defer=False, _rows=None):
     """``disp_warp`` sweep (reference trainer.py:540-554 + 567-603 + 728-742) -> (rgb_rec, ph_map).
 
     ``disp_layered`` is the decoder's ``outputs["disp_layered"]``: either an expanded view of per-plane scalars
@@ -288,6 +288,20 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     keeps the row-shift kernels applicable.
     """
     B, N, H, W = logits.shape
+    if _rows is not None:
+        # internal (the stereo view of homography_warp): per-row shifts [B,N,H] and per-row mask [B,N,H] as they are — no
+        # [B,N,H,W] view whose slice-backward would zero-fill and reduce 190 MB per step
+        probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS | C.PD_MASK_ROWS, 1.0, SWEEP_IMPL)
+        if C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)):
+            shift, mask = _rows
+            flags = _flags(use_mixture_loss, automask, rows=True) | C.PD_MASK_ROWS
+            call = (src, tgt, logits, sigma if use_mixture_loss else None, shift, None, None, mask, None, C.PD_WARP_DISP,
+                    flags, _SIGN.get(target_side, 0.0))
+            if defer:
+                return call
+            out = _PlaneSweep.apply(*call)
+            return out if return_mean else out[:2]
+        disp_layered, padding_mask = (t[..., None].expand(B, N, H, W) for t in _rows)   # PD_IMPL_GENERAL & co.
     if tuple(disp_layered.shape) != (B, N, H, W):
         disp_layered = disp_layered.expand(B, N, H, W)
     per_plane = disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0
@@ -487,9 +501,9 @@ def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix
             mask = (facing & (z > 1e-7)).float()                                            # layers.py:224-225
     else:
         shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
-    return plane_sweep_disp(src, tgt, logits, sigma, shift[..., None].expand(B, N, H, W),
-                            mask[..., None].expand(B, N, H, W), target_side="r", use_mixture_loss=mix,
-                            automask=automask, row_uniform=True, return_mean=return_mean, defer=defer)
+    return plane_sweep_disp(src, tgt, logits, sigma, None, None, target_side="r", use_mixture_loss=mix,
+                            automask=automask, row_uniform=True, return_mean=return_mean, defer=defer,
+                            _rows=(shift, mask))
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",
