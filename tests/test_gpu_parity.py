@@ -835,15 +835,16 @@ def test_views_as_one_autograd_node_equal_one_node_per_view(tag, stereo_constant
         assert rel_err(v, w) < tol, (tag, k, rel_err(v, w))
 
 
-@pytest.mark.parametrize("tag", ["homo3", "disp_xz"])
-def test_trainer_mono_fixture_general_kernels(tag):
-    """The same fixtures forced onto the general kernels (PD_IMPL_GENERAL)."""
+@pytest.mark.parametrize("tag,stereo_constant", [("homo3", False), ("homo3", True), ("disp_xz", False)])
+def test_trainer_mono_fixture_general_kernels(tag, stereo_constant):
+    """The same fixtures forced onto the general kernels (PD_IMPL_GENERAL); with the stereo pose a constant the stereo
+    view's per-row shifts are expanded to a dense disparity map for them."""
     from cases import load_trainer_fixture
     from gpu_cases import run_product_trainer
     from planedepth_amd import _capi as C
     from cases import run_oracle_trainer
     z, meta = load_trainer_fixture(tag)
-    got = run_product_trainer(z, meta, impl=C.PD_IMPL_GENERAL)
+    got = run_product_trainer(z, meta, impl=C.PD_IMPL_GENERAL, stereo_constant=stereo_constant)
     homo = meta["warp_type"] == "homography_warp"
     exact = run_oracle_trainer(z, meta, dtype=torch.float64) if homo else None
     for k in ("ph_loss", "total_loss", "g_logits") + (("g_sigma",) if meta["use_mixture_loss"] else ()):
