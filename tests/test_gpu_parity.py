@@ -835,6 +835,28 @@ def test_views_as_one_autograd_node_equal_one_node_per_view(tag, stereo_constant
         assert rel_err(v, w) < tol, (tag, k, rel_err(v, w))
 
 
+def test_two_row_shift_views_as_one_node():
+    """Two disp_warp views ("r" and "l") over the same logits / sigma as one autograd node: neither row-shift backward can
+    add in place, so the second goes through a temporary and one add — same result as two nodes."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    case = build_case(B=2, N=6, H=20, W=96, seed=77, disp_min=0.5, disp_max=25.0, sigma_interior=True)
+    c = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.items()}
+    res = {}
+    for fused in (True, False):
+        lg, sg, dp = (c[k].clone().requires_grad_(True) for k in ("logits", "sigma", "disp_pp"))
+        dl = dp.expand(-1, -1, 20, 96)
+        calls = [ops.plane_sweep_disp(c["color_l"], c["color_r"], lg, sg, dl, None, target_side=side, return_mean=True,
+                                      defer=True) for side in ("r", "l")]
+        outs = ops.plane_sweep_multi(calls) if fused else [ops._PlaneSweep.apply(*cc) for cc in calls]
+        loss = sum(o[2] * (i + 1.0) + (o[0] * c["g_rgb_rec"]).sum() for i, o in enumerate(outs))
+        loss.backward()
+        res[fused] = dict(rgb0=outs[0][0].detach().cpu(), rgb1=outs[1][0].detach().cpu(), g_logits=lg.grad.cpu(),
+                          g_sigma=sg.grad.cpu(), g_disp=dp.grad.cpu())
+    for k in res[True]:
+        assert rel_err(res[True][k], res[False][k]) < 2e-6, (k, rel_err(res[True][k], res[False][k]))
+
+
 @pytest.mark.parametrize("tag,stereo_constant", [("homo3", False), ("homo3", True), ("disp_xz", False)])
 def test_trainer_mono_fixture_general_kernels(tag, stereo_constant):
     """The same fixtures forced onto the general kernels (PD_IMPL_GENERAL); with the stereo pose a constant the stereo
