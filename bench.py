@@ -51,6 +51,9 @@ def parse():
                     help="homography_warp only: BASELINE configs[3] as the trainer runs it — target_sides = ['r', -1, 1] "
                          "(trainer.py:532, 717): the stereo view plus two novel frames with pose_net-like poses, three "
                          "sweeps per step over the same decoder outputs")
+    ap.add_argument("--render_probability", action="store_true",
+                    help="alpha compositing over the planes instead of the softmax (trainer.py:584-591; needs the decoder's "
+                         "outputs['dists'], a synthetic [B,N-1,H,W] leaf here)")
     ap.add_argument("--per_view_nodes", action="store_true",
                     help="--mono_sides: one autograd node per target view (opt.pd_fuse_sides = False) instead of one node "
                          "for all views with in-kernel gradient accumulation")
@@ -108,7 +111,7 @@ def build_step(args, c, device):
     disp_pp = c["disp_pp"].clone().requires_grad_(not args.no_plane_grad)  # per-plane disparities incl. the learnt residual
     Rt = bench_pose(args, c, device)
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
-                                render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                render_probability=bool(args.render_probability), alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
                                 gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
                                 xz_levels=args.xz_levels, yz_levels=0)
     zero = torch.zeros((), device=device)
@@ -139,6 +142,9 @@ def build_step(args, c, device):
     else:
         pm_arg = pm
 
+    dists = None
+    if args.render_probability:
+        dists = (torch.rand(B, N - 1, H, W, generator=torch.Generator().manual_seed(5)) * 2.0).to(device).requires_grad_(True)
     dense_disp = None
     if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182): that is
         # decoder work, so it is built ONCE here and handed to the path as the decoder would hand it over (a dense
@@ -147,6 +153,8 @@ def build_step(args, c, device):
 
     def step():
         logits.grad = sigma.grad = disp_pp.grad = None
+        if dists is not None:
+            dists.grad = None
         if dense_disp is not None:
             dense_disp.grad = None
             disp_layered = dense_disp
@@ -156,6 +164,8 @@ def build_step(args, c, device):
                    "disp_layered": disp_layered, "padding_mask": pm_arg, "norm": norm}
         for sd in sides:
             outputs[("Rt", sd)] = poses[sd]
+        if dists is not None:
+            outputs["dists"] = dists
         if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
             outputs["distance"] = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
@@ -184,8 +194,8 @@ def kernel_times(args, c, device, iters):
     lib = C.load()
     B, N, H, W = c["logits"].shape
     mix = not args.no_mixture
-    if args.xz_levels:
-        return None  # direct-launch timing is wired for the xy-plane configurations only
+    if args.xz_levels or args.render_probability:
+        return None  # direct-launch timing is wired for the xy-plane softmax configurations only
     if args.warp_type == "homography_warp" and (args.mono_sides or not (args.mono_pose or args.colmap_pose or args.general_stereo)):
         return None  # stereo target: runs as per-row shifts on the row-shift kernels; the in-step events time those
     flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if args.automask else 0)
@@ -393,7 +403,7 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     optim = torch.optim.Adam(ddp.parameters(), 1e-4, betas=(0.5, 0.999))                                       # :102
     n_params = sum(p.numel() for p in model.parameters())
     opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
-                                render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                render_probability=bool(args.render_probability), alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
                                 gamma_smooth=2.0, alpha_smooth=0.04, use_ssim=False, xz_levels=0, yz_levels=0,
                                 novel_frame_ids=[], flip_right=True)
     zero = torch.zeros((), device=device)

@@ -45,11 +45,12 @@ struct PlaneGroup {
   ColourTaps<NROWS> tc[U];  // LDS colour taps ride along with the global loads (their latency overlaps too)
 #endif
   float mval[U];
+  float dist[U];  // PD_RENDER_PROB: the decoder's inter-plane distance at the TARGET pixel (trainer.py:587)
 };
 
 // Issue every global load of planes n0 .. n0+U-1 (no use of the results here: the caller overlaps the latency with
 // the arithmetic of the previous group — one-group-ahead software prefetch).
-template <bool MIX, bool HASMASK, int NROWS, int U>
+template <bool MIX, bool HASMASK, int NROWS, int U, bool RENDER = false>
 __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const SweepArgs& a, const RowSel& row,
                                             const char* __restrict__ lrgb, const float* __restrict__ sdisp, int b,
                                             int y, int n0, int x, int HW, float Wm1, float rcpWm1) {
@@ -65,6 +66,8 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
 #if PD_TC_IN_GROUP
     if (!(kAblate & 2)) g.tc[u] = load_colour_taps<NROWS>(lrgb, a.W, colour_off(g.ct[u].x0, a.W));
 #endif
+    if (RENDER)  // unshifted, coalesced: read where the pixel is, not where it samples
+      g.dist[u] = (n < a.N - 1 && x < a.W) ? a.dists[((long)b * (a.N - 1) + n) * HW + (long)y * a.W + x] : 0.0f;
     g.mval[u] = 1.0f;
     if (HASMASK && !(kAblate & 16))
       g.mval[u] = buf_load(row_rsrc_uniform(plane_ptr(a.padding_mask + (long)b * a.N * HW + (long)y * a.W, n, HW), a.W), (unsigned)x << 2);
@@ -82,11 +85,11 @@ __device__ __forceinline__ void group_issue(PlaneGroup<NROWS, U>& g, const Sweep
   }
 }
 
-template <bool MIX, bool HASMASK, int NROWS, int U>
+template <bool MIX, bool HASMASK, int NROWS, int U, bool RENDER = false>
 __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const SweepArgs& a, const RowSel& row,
                                             const char* __restrict__ lrgb, int b, int n0, int pix, int HW, float t0,
                                             float t1, float t2, float ea, bool automask, FwdAcc& acc, uint32_t& bits,
-                                            float* __restrict__ stash) {
+                                            float* __restrict__ stash, RenderState* rs = nullptr) {
 #if PD_TC_IN_GROUP
   const ColourTaps<NROWS>* tc = g.tc;
 #else
@@ -123,6 +126,9 @@ __device__ __forceinline__ void fwd_compute(const PlaneGroup<NROWS, U>& g, const
     if (kAblate & 2) { c0 = w.a0; c1 = w.a1; c2 = l; }  // diagnostics: no colour taps
     else colour_values<NROWS>(tc[u], w, c0, c1, c2);
     if (kAblate & 4) { acc.Z += l; acc.S += s; acc.C0 += c0; acc.C1 += c1; acc.C2 += c2; acc.m = 0.0f; }  // no softmax/mixture math
+    else if (RENDER)  // alpha compositing front to back (trainer.py:584-591): the planes arrive in order
+      mixture_accumulate<MIX>(acc, render_prob(*rs, render_alpha(l, g.dist[u], n == a.N - 1)), s, c0, c1, c2, t0, t1, t2,
+                              ea, automask);
     else fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
   }
 }
@@ -202,8 +208,8 @@ __device__ __forceinline__ FwdAcc fetch_acc(const float* __restrict__ slot, int 
 template <bool MIX>
 __device__ __forceinline__ float fwd_store(const SweepArgs& a, const FwdAcc& acc, int b, int pix, int HW, float t0,
                                           float t1, float t2, float ea, bool automask, float* __restrict__ rgb_rec,
-                                          float* __restrict__ ph_map, float* __restrict__ stash) {
-  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask);
+                                          float* __restrict__ ph_map, float* __restrict__ stash, bool normalise = true) {
+  const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask, normalise);
   float* st = stash + (long)b * a.stash_k * HW + pix;
   st[0] = r.lse2;
   st[HW] = r.Sn;
@@ -216,11 +222,14 @@ __device__ __forceinline__ float fwd_store(const SweepArgs& a, const FwdAcc& acc
   return r.ph;
 }
 
-template <bool MIX, bool HASMASK, bool AUTO, int NROWS>
+template <bool MIX, bool HASMASK, bool AUTO, int NROWS, bool RENDER = false>
 __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const RowSel& row, float4* lrgb, float* sdisp,
                                                   float* parts, float* __restrict__ rgb_rec,
                                                   float* __restrict__ ph_map, float* __restrict__ stash) {
-  constexpr int U = (NROWS == 1) ? PD_FWD_U : (PD_FWD_U > 1 ? PD_FWD_U / 2 : 1);
+  // (compositing keeps a distance per plane of the group and its running state alive: half the group size, or the
+  // register allocator spills 40-70 VGPRs at the 168 this kernel may use)
+  constexpr int UB = (RENDER && PD_FWD_U > 1) ? PD_FWD_U / 2 : PD_FWD_U;
+  constexpr int U = (NROWS == 1) ? UB : (UB > 1 ? UB / 2 : 1);
   constexpr int G = HASMASK ? 32 : U;  // chunk of the work split (mask words of the stash are written whole)
   static_assert(32 % U == 0, "plane groups must tile the 32-plane mask words");
   const int y = block_row(wg_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
@@ -235,7 +244,11 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
   const int lane = threadIdx.x & (kWave - 1), nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nseg = (a.W + kWave - 1) / kWave;
-  const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  if (RENDER) {   // compositing walks the planes of a pixel in order: whole segments only (a ragged last round)
+    rw.full = (nseg + nwaves - 1) / nwaves;
+    rw.r = 0;
+  }
   float ph_sum = 0.0f;  // this lane's share of sum(ph_map) (returned: the kernel adds the wave totals to a.ph_mean)
   auto target_pixel = [&](int pix, float& t0, float& t1, float& t2, float& ea) {
     t0 = a.tgt[((long)b * 3 + 0) * HW + pix];
@@ -253,13 +266,14 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
     float t0, t1, t2, ea;
     target_pixel(pix, t0, t1, t2, ea);
     FwdAcc acc;
+    RenderState rs;
     uint32_t bits = 0;
     // Groups of U planes through a software pipeline: while group i is reduced the loads of group i+1 (PD_PF_DEPTH 2;
     // measured best) or of groups i+1 and i+2 (PD_PF_DEPTH 3; no faster, more registers) are in flight.
     PlaneGroup<NROWS, U> g0, g1, g2;
     const int nfull = (n_hi - n_lo) / U;  // full groups
-#define PD_FISSUE(GR, I) group_issue<MIX, HASMASK, NROWS, U>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, x, HW, Wm1, rcpWm1)
-#define PD_FCOMP(GR, I) fwd_compute<MIX, HASMASK, NROWS, U>(GR, a, row, lbytes, b, n_lo + (I) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash)
+#define PD_FISSUE(GR, I) group_issue<MIX, HASMASK, NROWS, U, RENDER>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, x, HW, Wm1, rcpWm1)
+#define PD_FCOMP(GR, I) fwd_compute<MIX, HASMASK, NROWS, U, RENDER>(GR, a, row, lbytes, b, n_lo + (I) * U, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash, &rs)
     int gi = 0;
     if (PD_FWD_PF && PD_PF_DEPTH == 2) {
       if (nfull > 0) PD_FISSUE(g0, 0);
@@ -293,10 +307,10 @@ __device__ __forceinline__ float rowshift_fwd_body(const SweepArgs& a, const Row
 #undef PD_FCOMP
     for (int n = n_lo + nfull * U; n < n_hi; ++n) {  // remainder planes (only at the end of the plane axis)
       PlaneGroup<NROWS, 1> gr;
-      group_issue<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
-      fwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash);
+      group_issue<MIX, HASMASK, NROWS, 1, RENDER>(gr, a, row, lbytes, sdisp, b, y, n, x, HW, Wm1, rcpWm1);
+      fwd_compute<MIX, HASMASK, NROWS, 1, RENDER>(gr, a, row, lbytes, b, n, pix, HW, t0, t1, t2, ea, automask, acc, bits, stash, &rs);
     }
-    if (piece < 0) ph_sum += fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash);
+    if (piece < 0) ph_sum += fwd_store<MIX>(a, acc, b, pix, HW, t0, t1, t2, ea, automask, rgb_rec, ph_map, stash, !RENDER);
     else park_acc(parts + ((wave * 2 + piece) * 8) * kWave, lane, acc);
     }
   }
@@ -500,7 +514,7 @@ __device__ __forceinline__ float rowpair_fwd_body(const SweepArgs& a, int yL, in
   return ph_sum;
 }
 
-template <bool MIX, bool HASMASK, bool AUTO>
+template <bool MIX, bool HASMASK, bool AUTO, bool RENDER = false>
 __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rowshift_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                      float* __restrict__ ph_map,
                                                                      float* __restrict__ stash) {
@@ -513,16 +527,16 @@ __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rows
   float ph_sum = 0.0f;
   int partner = y;
   // row pairs: per-plane scalar disparities and no per-pixel mask (then the sampling column is shared by the rows)
-  const PairRole role = (a.pairs && !HASMASK) ? pair_role(y, a.H, partner) : kSingle;
+  const PairRole role = (a.pairs && !HASMASK && !RENDER) ? pair_role(y, a.H, partner) : kSingle;
   if (role == kAbsorbed) {
     // this row is computed by its neighbour's workgroup
   } else if (role == kLeader) {
-    if (!HASMASK)
+    if (!HASMASK && !RENDER)
       ph_sum = rowpair_fwd_body<MIX, AUTO>(a, y, partner, wg_image(a.B, a.H), lds4, sdisp, parts, rgb_rec, ph_map, stash);
   } else if (row.nrows == 2) {
-    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 2, RENDER>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
   } else {
-    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
+    ph_sum = rowshift_fwd_body<MIX, HASMASK, AUTO, 1, RENDER>(a, row, lds4, sdisp, parts, rgb_rec, ph_map, stash);
   }
   if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup (one per wave
     // measured +13 us on the forward: 6144 atomics on a single address serialise in L2)
@@ -597,13 +611,20 @@ struct SegCtx {
   bool active;
 };
 
-template <bool MIX, bool HASMASK, int NROWS, int U>
+// PD_RENDER_PROB: what the front-to-back compositing carries from plane to plane of one pixel
+struct RenderBwd {
+  float T = 1.0f;        // transmittance in front of the current plane
+  float prefix = 0.0f;   // sum_{k <= n} p_k dL/dp_k
+  float Rtot = 0.0f;     // sum over all planes of the same, known in closed form from the pixel's stash
+};
+
+template <bool MIX, bool HASMASK, int NROWS, int U, bool RENDER = false>
 __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const SweepArgs& a, const BwdOut& o,
                                             const RowSel& row, const char* __restrict__ lrgb,
                                             const int* __restrict__ kshift, float* __restrict__ red,
                                             const Boundary& bnd, int b, int y, int n0, const SegCtx& sc,
                                             const PixelCtx& c, int HW, float gix_scale, int want_plane,
-                                            int gl_bytes, int gs_bytes, uint32_t& bits) {
+                                            int gl_bytes, int gs_bytes, uint32_t& bits, RenderBwd* rb = nullptr) {
   const int W = a.W, N = a.N;
 #if PD_TC_IN_GROUP
   const ColourTaps<NROWS>* tc = g.tc;
@@ -636,7 +657,24 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
     if (MIX) fix_edge<NROWS>(ts, edge);
     const float l = tap_value<NROWS>(tl, w);
     const float s = MIX ? tap_value<NROWS>(ts, w) : 0.0f;
-    const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    PlaneGrad pg;
+    if (RENDER) {  // d prob_k / d alpha_n for k >= n through the transmittance (trainer.py:584-591)
+      const bool last = (n == N - 1);
+      const float lm = mk ? l : 0.0f;   // a masked plane samples as all-zero features: alpha = 0, the state passes through
+      const float dist = g.dist[u];
+      const float alpha = render_alpha(lm, dist, last);
+      const float pn = alpha * rb->T;
+      pg = plane_grad_p<MIX>(c, pn, s, c0, c1, c2);
+      rb->prefix += pg.g_l * pn;
+      const float keep = 1.0f - alpha + 1e-10f;
+      const float g_alpha = pg.g_l * rb->T - (rb->Rtot - rb->prefix) / keep;
+      const float da = 1.0f - alpha;   // d alpha / d (relu(l) * dist)
+      pg.g_l = (!last && lm > 0.0f) ? g_alpha * dist * da : 0.0f;
+      if (o.g_dists && !last && sc.active) o.g_dists[((long)b * (N - 1) + n) * HW + sc.pix] = g_alpha * fmaxf(lm, 0.0f) * da;
+      rb->T *= keep;
+    } else {
+      pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    }
     // adjoint of the horizontal gather: contributions to source x0 (weight w0) and x0+1 (weight w1), if inside
     const bool v0 = (unsigned)t.x0 < (unsigned)W, v1 = (unsigned)(t.x0 + 1) < (unsigned)W;
     const float live = mk ? (NROWS == 1 ? 1.0f : row.wy_main) : 0.0f;   // padding mask x vertical adjoint weight of the own row
@@ -701,7 +739,7 @@ __device__ __forceinline__ void bwd_compute(const PlaneGroup<NROWS, U>& g, const
   }
 }
 
-template <bool MIX, bool HASMASK, int NROWS>
+template <bool MIX, bool HASMASK, int NROWS, bool RENDER = false>
 __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdOut& o, const RowSel& row,
                                                   float* sdisp, int* kshift, float* red, const Boundary& bnd, float4* lrgb) {
   constexpr int U = PD_BWD_U;
@@ -731,10 +769,15 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   // is closed-form given the pixel's stash, so a segment split between two waves needs no merge at all
   constexpr int G = HASMASK ? 32 : U;  // mask words are fetched whole
   static_assert(32 % U == 0, "plane groups must tile the 32-plane mask words");
-  const RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  RowWork rw = row_work(nseg, N, G, wave, nwaves);
+  if (RENDER) {   // the compositing state runs along the planes of a pixel: whole segments only (a ragged last round)
+    rw.full = (nseg + nwaves - 1) / nwaves;
+    rw.r = 0;
+  }
   for (int it = 0;; ++it) {
     int seg, n_lo, n_hi, piece;
     if (!work_item(rw, it, wave, nwaves, N, G, seg, n_lo, n_hi, piece)) break;
+    if (RENDER && seg >= nseg) break;   // (wave-uniform) nothing left in the ragged round
     SegCtx sc;
     sc.seg = seg;
     sc.seg_prev = (seg == 0) ? nseg - 1 : seg - 1;
@@ -745,12 +788,14 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
     sc.last = min(kWave - 1, W - 1 - sc.T0);
     sc.pix = y * W + (sc.active ? sc.xt : 0);
     const PixelCtx c = sc.active ? make_pixel_ctx<MIX>(a, o, b, sc.pix, HW) : zero_pixel_ctx();
+    RenderBwd rb;
+    rb.Rtot = MIX ? -c.A * c.mx : c.gdotr;
     uint32_t bits = 0;
     // same software pipeline as the forward (the mask comes from the stash bits, not from memory)
     PlaneGroup<NROWS, U> g0, g1, g2;
     const int nfull = (n_hi - n_lo) / U;
-#define PD_BISSUE(GR, I) group_issue<MIX, false, NROWS, U>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, sc.xt, HW, Wm1, rcpWm1)
-#define PD_BCOMP(GR, I) bwd_compute<MIX, HASMASK, NROWS, U>(GR, a, o, row, lbytes, kshift, red, bnd, b, y, n_lo + (I) * U, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits)
+#define PD_BISSUE(GR, I) group_issue<MIX, false, NROWS, U, RENDER>(GR, a, row, lbytes, sdisp, b, y, n_lo + (I) * U, sc.xt, HW, Wm1, rcpWm1)
+#define PD_BCOMP(GR, I) bwd_compute<MIX, HASMASK, NROWS, U, RENDER>(GR, a, o, row, lbytes, kshift, red, bnd, b, y, n_lo + (I) * U, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits, &rb)
     int gi = 0;
     if (PD_BWD_PF && PD_BWD_PF_DEPTH == 2) {
       if (nfull > 0) PD_BISSUE(g0, 0);
@@ -781,8 +826,8 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
 #undef PD_BCOMP
     for (int n = n_lo + nfull * U; n < n_hi; ++n) {
       PlaneGroup<NROWS, 1> gr;
-      group_issue<MIX, false, NROWS, 1>(gr, a, row, lbytes, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
-      bwd_compute<MIX, HASMASK, NROWS, 1>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits);
+      group_issue<MIX, false, NROWS, 1, RENDER>(gr, a, row, lbytes, sdisp, b, y, n, sc.xt, HW, Wm1, rcpWm1);
+      bwd_compute<MIX, HASMASK, NROWS, 1, RENDER>(gr, a, o, row, lbytes, kshift, red, bnd, b, y, n, sc, c, HW, gix_scale, want_plane, gl_bytes, gs_bytes, bits, &rb);
     }
   }
   __syncthreads();
@@ -823,7 +868,7 @@ __device__ __forceinline__ void rowshift_bwd_body(const SweepArgs& a, const BwdO
   }
 }
 
-template <bool MIX, bool HASMASK>
+template <bool MIX, bool HASMASK, bool RENDER = false>
 __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   // LDS: colour rows float4[2*(W+4)] | sdisp[N] | kshift[N] | red[N] | rec[nseg][N][2] | irr[ceil(nseg*N/32)]
@@ -836,8 +881,8 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kerne
   bnd.irr = reinterpret_cast<unsigned*>(bnd.rec + 2 * nsn);
   bnd.side = o.side + ((long)wg_image(a.B, a.H) * a.H + bwd_rowid(a.B, a.H)) * (4L * nsn);
   const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
-  if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2>(a, o, row, sdisp, kshift, red, bnd, lds4);
-  else                rowshift_bwd_body<MIX, HASMASK, 1>(a, o, row, sdisp, kshift, red, bnd, lds4);
+  if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2, RENDER>(a, o, row, sdisp, kshift, red, bnd, lds4);
+  else                rowshift_bwd_body<MIX, HASMASK, 1, RENDER>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }
 
 // partials [B][R][M] -> out [B][M]; one wave per (b, j): lanes stride over R, then wave-reduce.  Deterministic.
@@ -886,7 +931,7 @@ bool rowshift_applicable(const pd_sweep_desc* d) {
   const size_t colour = (size_t)(d->W + 4) * 2 * sizeof(float4);
   const size_t bwd = colour + ((size_t)3 * d->N + (size_t)ceil_div(d->W, kWave) * d->N * 3) * 4;
   const size_t fwd = colour + ((size_t)d->N + (size_t)(kRowThreadsMax / kWave) * 2 * 8 * kWave * 2) * 4;
-  return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && !(d->flags & PD_RENDER_PROB) && d->H <= 65535 &&
+  return d->mode == PD_WARP_DISP && !(d->flags & PD_DISP_DENSE) && d->H <= 65535 &&
          (long)d->N * d->H * d->W < (1L << 31) && bwd <= 160 * 1024 && fwd <= 160 * 1024;
 }
 
@@ -900,16 +945,6 @@ static void allow_lds(K kernel, size_t shmem) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 }
 
-#define PD_ROW_DISPATCH(KERNEL, mix, hasmask, grid, block, shmem, stream, ...)                 \
-  do {                                                                                          \
-    if (mix) {                                                                                  \
-      if (hasmask) { allow_lds(KERNEL<true, true>, shmem);  KERNEL<true, true><<<grid, block, shmem, stream>>>(__VA_ARGS__); }   \
-      else         { allow_lds(KERNEL<true, false>, shmem); KERNEL<true, false><<<grid, block, shmem, stream>>>(__VA_ARGS__); }  \
-    } else {                                                                                    \
-      if (hasmask) { allow_lds(KERNEL<false, true>, shmem);  KERNEL<false, true><<<grid, block, shmem, stream>>>(__VA_ARGS__); } \
-      else         { allow_lds(KERNEL<false, false>, shmem); KERNEL<false, false><<<grid, block, shmem, stream>>>(__VA_ARGS__); }\
-    }                                                                                           \
-  } while (0)
 
 int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
                  hipStream_t stream) {
@@ -920,10 +955,15 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
   const size_t park = (nseg % nwaves) ? (size_t)nwaves * 2 * 8 * kWave * (a.pairs ? 2 : 1) : (size_t)kWave;
   const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)d->N + park) * sizeof(float);
   const bool mix = (d->flags & PD_MIXTURE) != 0, hasmask = a.has_mask != 0, am = (d->flags & PD_AUTOMASK) != 0;
+  const bool render = (d->flags & PD_RENDER_PROB) != 0;
+#define PD_FWD_LAUNCH_R(M, K, A, R)                                                               \
+  do {                                                                                            \
+    allow_lds(rowshift_fwd_kernel<M, K, A, R>, shmem);                                            \
+    rowshift_fwd_kernel<M, K, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash);   \
+  } while (0)
 #define PD_FWD_LAUNCH(M, K, A)                                                              \
   do {                                                                                      \
-    allow_lds(rowshift_fwd_kernel<M, K, A>, shmem);                                         \
-    rowshift_fwd_kernel<M, K, A><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash); \
+    if (render) PD_FWD_LAUNCH_R(M, K, A, true); else PD_FWD_LAUNCH_R(M, K, A, false);       \
   } while (0)
   if (mix) {
     if (hasmask) { if (am) PD_FWD_LAUNCH(true, true, true); else PD_FWD_LAUNCH(true, true, false); }
@@ -932,6 +972,7 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
     if (hasmask) PD_FWD_LAUNCH(false, true, false); else PD_FWD_LAUNCH(false, false, false);
   }
 #undef PD_FWD_LAUNCH
+#undef PD_FWD_LAUNCH_R
   return check_launch("rowshift_fwd_kernel");
 }
 
@@ -942,7 +983,19 @@ int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o_in,
   const size_t shmem = (size_t)(d->W + 4) * 2 * sizeof(float4) + ((size_t)3 * d->N + nsn * 2 + (nsn + 31) / 32) * sizeof(float);
   BwdOut o = o_in;
   o.side = o_in.partials + (size_t)d->B * d->H * d->N;   // workspace: [B][H][N] partial sums | [B][H][nseg*N][4] spill
-  PD_ROW_DISPATCH(rowshift_bwd_kernel, (d->flags & PD_MIXTURE) != 0, a.has_mask != 0, grid, block, shmem, stream, a, o);
+  {
+    const bool mix = (d->flags & PD_MIXTURE) != 0, hasmask = a.has_mask != 0, render = (d->flags & PD_RENDER_PROB) != 0;
+#define PD_BWD_LAUNCH(M, K, R)                                                         \
+  do {                                                                                 \
+    allow_lds(rowshift_bwd_kernel<M, K, R>, shmem);                                    \
+    rowshift_bwd_kernel<M, K, R><<<grid, block, shmem, stream>>>(a, o);                \
+  } while (0)
+#define PD_BWD_PICK(M, K) do { if (render) PD_BWD_LAUNCH(M, K, true); else PD_BWD_LAUNCH(M, K, false); } while (0)
+    if (mix) { if (hasmask) PD_BWD_PICK(true, true); else PD_BWD_PICK(true, false); }
+    else     { if (hasmask) PD_BWD_PICK(false, true); else PD_BWD_PICK(false, false); }
+#undef PD_BWD_PICK
+#undef PD_BWD_LAUNCH
+  }
   int rc = check_launch("rowshift_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
   reduce_rows_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);

@@ -308,7 +308,7 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     rows = False
     if per_plane:
         plane = _per_plane_view(disp_layered)
-    elif row_uniform and not render_probability:
+    elif row_uniform:
         probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS, 1.0, SWEEP_IMPL)
         rows = bool(C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)))
         plane = disp_layered[..., 0] if rows else disp_layered
@@ -319,7 +319,7 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     if padding_mask is not None and tuple(padding_mask.shape) != (B, N, H, W):
         padding_mask = padding_mask.expand(B, N, H, W)
     flags = _flags(use_mixture_loss, automask, dense=not (per_plane or rows), render=render_probability, rows=rows)
-    if padding_mask is not None and row_uniform and (per_plane or rows) and not render_probability:
+    if padding_mask is not None and row_uniform and (per_plane or rows):
         # the mask of xy / xz planes is constant along x as well (depth_decoder.py:157, 166): hand over its first column
         probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, 1.0, SWEEP_IMPL)
         if C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)):

@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors captured from the reference and against
 the oracle.  Tolerance: BASELINE.json north_star — 1e-4 relative, fp32 — measured as normalised max error
 max|a-b| / max|b| per tensor (cases.rel_err)."""
+import ctypes
 import json
 import os
 
@@ -737,6 +738,42 @@ def test_degenerate_shapes_vs_oracle(seed, kw, run):
         _compare3(got, case, run, tag="seed%d" % seed)
     else:
         _compare(got, run_oracle(case, run), tag="seed%d" % seed)
+
+
+@pytest.mark.parametrize("kw,run", [
+    (dict(B=2, N=9, H=12, W=640, disp_min=0.5, disp_max=200.0), dict(automask=True)),        # 10 segments on 4 waves: ragged round
+    (dict(B=1, N=6, H=9, W=130, disp_min=0.5, disp_max=40.0), dict(target_side="l")),        # partial last segment
+    (dict(B=2, N=5, H=7, W=33, disp_min=0.5, disp_max=12.0), dict(use_mixture_loss=False)),  # narrower than a wave, L1
+    (dict(B=1, N=12, H=21, W=200, disp_min=0.5, disp_max=60.0, n_xz=4), dict(automask=True)),  # xz planes: per-row shifts + masks
+    (dict(B=1, N=2, H=5, W=70, disp_min=0.5, disp_max=9.0), dict()),                         # N = 2: one real alpha + the closing plane
+])
+def test_render_probability_on_the_row_kernels(kw, run):
+    """--render_probability (alpha compositing over the planes, trainer.py:584-591) on the row-shift kernels — running
+    transmittance front to back in the forward, transmittance + prefix sum in the backward, g_dists written per pixel —
+    against the general kernels (same formulas, atomic scatter) and the oracle."""
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    case = build_case(seed=4100 + kw["W"], sigma_interior=True, render_probability=True, **kw)
+    run = dict(run, render_probability=True)
+    extra = dict(yz_levels=0, xz_levels=kw.get("n_xz", 0))
+    fast = run_product(case, run, opt_extra=extra)
+    assert ops.LAST_SWEEP_FLAGS & C.PD_RENDER_PROB
+    d = C.SweepDesc(kw["B"], kw["N"], kw["H"], kw["W"], C.PD_WARP_DISP, ops.LAST_SWEEP_FLAGS, 1.0, 0)
+    assert C.load().pd_sweep_uses_rowshift(ctypes.byref(d))            # the fast path really served it
+    ops.SWEEP_IMPL = C.PD_IMPL_GENERAL
+    try:
+        slow = run_product(case, run, opt_extra=extra)
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    want = run_oracle(case, run)
+    keys = ("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp", "g_dists")
+    _compare(fast, {k: want[k] for k in keys if k in want}, tag="rows/render")
+    _compare(slow, {k: want[k] for k in keys if k in want}, tag="general/render")
+    for k in ("g_logits", "g_sigma", "g_dists"):
+        if k in fast and float(slow[k].abs().max()) > 0:
+            assert rel_err(fast[k], slow[k]) < 5e-5, (k, rel_err(fast[k], slow[k]))
 
 
 def test_randomised_shapes_rowshift_vs_general():
