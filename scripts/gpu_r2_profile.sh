@@ -68,6 +68,8 @@ b n63_xz_automask --planes 49 --xz_levels 14 --automask
 b batch12 --batch 12
 b hr_384x1280 --batch 4 --height 384 --width 1280
 b l1_no_mixture --no_mixture
+b render_probability --render_probability
+PD_SWEEP_IMPL=1 b render_probability_general_kernels --render_probability
 b homography_stereo_49 --warp_type homography_warp
 b homography_mono_f8_49 --warp_type homography_warp --mono_pose
 b homography_mono_f8_49_automask --warp_type homography_warp --mono_pose --automask
