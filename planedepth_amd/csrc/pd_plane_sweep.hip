@@ -387,7 +387,6 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
     PD_REQUIRE(padding_mask == nullptr || (d->flags & PD_HOMO_UNIFORM),
                "homography mode computes its own padding mask; pass NULL (PD_HOMO_UNIFORM: the [B,N,3] translation weights)");
     PD_REQUIRE(!(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)), "PD_DISP_DENSE / PD_DISP_ROWS are disp-mode flags");
-    PD_REQUIRE(!((d->flags & PD_HOMO_UNIFORM) && (d->flags & PD_RENDER_PROB)), "PD_HOMO_UNIFORM does not serve PD_RENDER_PROB");
   } else {
     PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM), "PD_HOMO_UNIFORM is a homography-mode flag");
   }

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float*
     const TapK t = tap_kernel(make_tap(u.g.ix, u.g.iy, a.W, a.H), a.W, a.H);
     const float s0 = sample_k(srcb, t), s1 = sample_k(srcb + HW, t), s2 = sample_k(srcb + 2 * HW, t);
     FwdAcc acc;
+    RenderState rs;
+    const bool render = a.flags & PD_RENDER_PROB;   // alpha compositing over the planes instead of the softmax
     const float* Rn = a.plane_aux + (long)b * a.N * 3;
     for (int n = 0; n < a.N; ++n) {
       const bool mk = uni_mask(u, Rn + n * 3);
@@ -100,9 +102,15 @@ __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float*
         if (MIX) s = sample_k(a.sigma + pl, t);
         c0 = s0; c1 = s1; c2 = s2;
       }
-      fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+      if (render) {
+        const bool last = (n == a.N - 1);
+        const float dist = last ? 0.0f : a.dists[((long)b * (a.N - 1) + n) * HW + pix];
+        mixture_accumulate<MIX>(acc, render_prob(rs, render_alpha(l, dist, last)), s, c0, c1, c2, t0, t1, t2, ea, automask);
+      } else {
+        fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+      }
     }
-    const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask, true);
+    const FwdResult r = fwd_finish<MIX>(acc, t0, t1, t2, ea, automask, !render);
     float* st = stash + (long)b * a.stash_k * HW + pix;
     st[0] = r.lse2; st[HW] = r.Sn; st[2 * HW] = r.mx; st[3 * HW] = r.sel;
     rgb_rec[((long)b * 3 + 0) * HW + pix] = r.r0;
@@ -166,8 +174,12 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
                 s2 = sample_vg_k(srcb + 2 * HW, t, d2x, d2y);
     const float* Rn = a.plane_aux + (long)b * N * 3;
     const float* twb = tw ? tw + (long)b * N * 3 : nullptr;
+    const bool render = a.flags & PD_RENDER_PROB;
+    const float Rtot = MIX ? -c.A * c.mx : c.gdotr;   // sum_k p_k dL/dp_k in closed form
+    float T = 1.0f, prefix = 0.0f;
     for (int n = 0; n < N; ++n) {
       float g_l = 0.0f, g_s = 0.0f;
+      if (render && o.g_dists && n < N - 1) o.g_dists[((long)b * (N - 1) + n) * HW + pix] = 0.0f;   // (masked planes keep this)
       if (uni_mask(u, Rn + n * 3)) {
         const long pl = ((long)b * N + n) * HW;
         float dlx = 0.0f, dly = 0.0f, dsx = 0.0f, dsy = 0.0f;
@@ -179,7 +191,23 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
           l = sample_k(a.logits + pl, t);
           if (MIX) s = sample_k(a.sigma + pl, t);
         }
-        const PlaneGrad pg = plane_grad<MIX>(c, l, s, s0, s1, s2);
+        PlaneGrad pg;
+        if (render) {   // d prob_k / d alpha_n for k >= n through the transmittance (trainer.py:584-591)
+          const bool last = (n == N - 1);
+          const float dist = last ? 0.0f : a.dists[((long)b * (N - 1) + n) * HW + pix];
+          const float alpha = render_alpha(l, dist, last);
+          const float pn = alpha * T;
+          pg = plane_grad_p<MIX>(c, pn, s, s0, s1, s2);
+          prefix += pg.g_l * pn;
+          const float keep = 1.0f - alpha + 1e-10f;
+          const float g_alpha = pg.g_l * T - (Rtot - prefix) / keep;
+          const float da = 1.0f - alpha;
+          pg.g_l = (!last && l > 0.0f) ? g_alpha * dist * da : 0.0f;
+          if (o.g_dists && !last) o.g_dists[((long)b * (N - 1) + n) * HW + pix] = g_alpha * fmaxf(l, 0.0f) * da;
+          T *= keep;
+        } else {
+          pg = plane_grad<MIX>(c, l, s, s0, s1, s2);
+        }
         g_l = pg.g_l; g_s = pg.g_s;
         if (want_plane) {
           const float gx = pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x;
@@ -836,7 +864,7 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   // Measured at 8x49x192x640 (pose_net-like rotations): two-pass 0.27 + 0.38 = 0.65 ms, fused 0.75 ms — sixteen waves
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
   const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
-  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate;
+  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !(d->flags & PD_RENDER_PROB);
   const int tiles_x = ceil_div(d->W, kFuseC), ntiles = tiles_x * ceil_div(d->H, kFuseR);
   if (!rc && fused) {   // regular case: per-plane gradients handed over through LDS
     dim3 grid(ntiles, d->B);

@@ -294,9 +294,9 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
         probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS | C.PD_MASK_ROWS, 1.0, SWEEP_IMPL)
         if C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)):
             shift, mask = _rows
-            flags = _flags(use_mixture_loss, automask, rows=True) | C.PD_MASK_ROWS
-            call = (src, tgt, logits, sigma if use_mixture_loss else None, shift, None, None, mask, None, C.PD_WARP_DISP,
-                    flags, _SIGN.get(target_side, 0.0))
+            flags = _flags(use_mixture_loss, automask, rows=True, render=render_probability) | C.PD_MASK_ROWS
+            call = (src, tgt, logits, sigma if use_mixture_loss else None, shift, None, None, mask,
+                    dists if render_probability else None, C.PD_WARP_DISP, flags, _SIGN.get(target_side, 0.0))
             if defer:
                 return call
             out = _PlaneSweep.apply(*call)
@@ -442,14 +442,14 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     derivatives need h00 as well).
     """
     B, N, H, W = logits.shape
-    if stereo_rows and not render_probability and not T.requires_grad and not norm.requires_grad:
+    if stereo_rows and not T.requires_grad and not norm.requires_grad:
         return _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, use_mixture_loss, automask,
-                                  return_mean, defer)
+                                  return_mean, defer, render_probability, dists)
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
     inv_K3 = inv_K[:, :3, :3]
     flags = _flags(use_mixture_loss, automask, render=render_probability)
     tw = None
-    if plane_uniform and not render_probability:
+    if plane_uniform:
         # One matrix per image (slice 0, layers.py:216-218 for plane 0 with the — zero — translation detached) plus the
         # homographies of three virtual planes n/d = e_j that carry the translation's gradient (include/planedepth_hip.h,
         # PD_HOMO_UNIFORM): dL/dt = sum_j <sum_n G_n n_n[j]/d_n, d f(R + t e_j^T)/dt> is the per-plane formulation's.
@@ -483,7 +483,8 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     return out if return_mean else out[:2]
 
 
-def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean, defer=False):
+def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean, defer=False,
+                       render=False, dists=None):
     B, N, H, W = logits.shape
     if TORCH_HOMOGRAPHY:
         ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
@@ -503,7 +504,7 @@ def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix
         shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
     return plane_sweep_disp(src, tgt, logits, sigma, None, None, target_side="r", use_mixture_loss=mix,
                             automask=automask, row_uniform=True, return_mean=return_mean, defer=defer,
-                            _rows=(shift, mask))
+                            render_probability=render, dists=dists, _rows=(shift, mask))
 
 
 def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=None, target_side="r",

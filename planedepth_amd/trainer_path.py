@@ -105,7 +105,7 @@ def pred_novel_images(self, inputs, outputs):
             T = outputs[("Rt", target_side)]
             # Novel frames without COLMAP: predict_poses leaves the translation at zero (trainer.py:386-400, only
             # `if self.opt.use_colmap` writes it), so one homography serves all planes of an image.
-            uniform = (target_side != "r" and not getattr(opt, "use_colmap", False) and not render
+            uniform = (target_side != "r" and not getattr(opt, "use_colmap", False)
                        and getattr(opt, "pd_uniform_homography", True))
             if uniform and (getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT")):
                 if not bool((T[:, :3, 3] == 0).all()):
@@ -113,7 +113,7 @@ def pred_novel_images(self, inputs, outputs):
             # The stereo side: inputs[("Rt", "r")] is the dataset's pure x-translation (mono_dataset.py:203-211, copied
             # to outputs at trainer.py:364) and xy / xz planes have no x component in their normals, so the warp is a
             # per-row horizontal shift and runs on the row-shift kernels.
-            stereo_rows = (target_side in ("l", "r") and row_uniform and not render
+            stereo_rows = (target_side in ("l", "r") and row_uniform
                            and getattr(opt, "pd_stereo_rows", True))
             if stereo_rows and (getattr(opt, "pd_check_contract", False) or os.environ.get("PD_CHECK_CONTRACT")):
                 eye = torch.eye(3, device=T.device, dtype=T.dtype)

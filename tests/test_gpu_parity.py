@@ -776,6 +776,56 @@ def test_render_probability_on_the_row_kernels(kw, run):
             assert rel_err(fast[k], slow[k]) < 5e-5, (k, rel_err(fast[k], slow[k]))
 
 
+@pytest.mark.parametrize("view", ["pose_net", "stereo"])
+@pytest.mark.parametrize("mix", [True, False])
+def test_render_probability_on_the_homography_shortcuts(view, mix):
+    """--render_probability with homography_warp: the plane-uniform kernels (pose_net view: zero translation) and the
+    per-row-shift form of the stereo view against the general per-plane-homography kernels, all gradients incl. g_dists."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics, small_pose
+    B, N, H, W = 2, 7, 24, 80
+    g = torch.Generator().manual_seed(515)
+    dev = "cuda"
+    src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    # positive logits: alpha = 1 - exp(-relu(l) dist) has a kink at l = 0, and the two stereo paths evaluate the sampling
+    # position with different (equally legitimate) fp32 chains — a sample within 1e-5 of zero would flip the relu's gate
+    # in one of them (seen: one element in 27 000).  Negative logits are covered against the oracle, where the row
+    # kernels' coordinates are bit-exact (test_render_probability_on_the_row_kernels).
+    logits = (torch.randn(B, N, H, W, generator=g).abs() + 0.05).to(dev)
+    sigma = (0.011 + 0.978 * torch.rand(B, N, H, W, generator=g)).to(dev)
+    dists = (torch.rand(B, N - 1, H, W, generator=g) * 2.0).to(dev)
+    gw = (torch.randn(B, 3, H, W, generator=g) * 0.1).to(dev)
+    distance = (0.5 + 5 * torch.rand(B, N, generator=g)).to(dev)
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1)
+    norm[:, N // 2:] = torch.nn.functional.normalize(torch.tensor([0.0, 1.0, 0.07]), dim=0)   # "xz planes"
+    norm = norm.to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    Rt = (_f8_pose(B, 31, 0.03) if view == "pose_net" else small_pose(None, B, stereo=True)).to(dev)
+    res = {}
+    for fast in (True, False):
+        lg, sg, ds, dd = (t.clone().requires_grad_(True) for t in (logits, sigma, dists, distance))
+        T = Rt.clone().requires_grad_(view == "pose_net")
+        rgb, ph, ph_mean = ops.plane_sweep_homography(src, tgt, lg, sg if mix else None, dd, norm, T, K, inv_K,
+                                                      use_mixture_loss=mix, automask=mix, render_probability=True, dists=ds,
+                                                      return_mean=True, plane_uniform=fast and view == "pose_net",
+                                                      stereo_rows=fast and view == "stereo")
+        (ph_mean * 2.0 + (rgb * gw).sum()).backward()
+        res[fast] = dict(rgb=rgb.detach().cpu(), ph=ph.detach().cpu(), g_logits=lg.grad.cpu(), g_dists=ds.grad.cpu(),
+                         g_sigma=sg.grad.cpu() if mix else torch.zeros(1))
+        if view == "pose_net":
+            res[fast]["g_Rt"] = T.grad.cpu()[:, :3]
+        else:
+            res[fast]["g_distance"] = dd.grad.cpu()
+    f, s_ = res[True], res[False]
+    assert float(s_["g_dists"].abs().max()) > 0 and float(s_["g_logits"].abs().max()) > 0
+    tol = 3e-6 if view == "pose_net" else 2e-4    # same coordinates / the row kernels' own coordinate chain (DESIGN 3.5.2)
+    for k in f:
+        # g_distance of the stereo view: a bilinear DERIVATIVE through two different fp32 coordinate chains (the accuracy of
+        # either against fp64 is what test_stereo_homography_as_row_shifts bounds)
+        bound = 1e-3 if k == "g_distance" else (2e-4 if k == "g_Rt" else tol)
+        assert rel_err(f[k], s_[k]) < bound, (view, k, rel_err(f[k], s_[k]))
+
+
 def test_randomised_shapes_rowshift_vs_general():
     """Seeded sweep over odd shapes (heights 2..40 incl. odd ones, widths that are not multiples of 64, fewer planes
     than a plane group, batch 1..3, both sides, L1 / mixture / automask): the specialised kernels (row pairs, plane-axis
