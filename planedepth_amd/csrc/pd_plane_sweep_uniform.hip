@@ -69,7 +69,7 @@ __device__ __forceinline__ bool uni_mask(const UniGeom& u, const float* __restri
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MIX>
+template <bool MIX, bool RENDER = false>
 __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                              float* __restrict__ ph_map, float* __restrict__ stash) {
   const int HW = a.H * a.W;
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float*
     const float s0 = sample_k(srcb, t), s1 = sample_k(srcb + HW, t), s2 = sample_k(srcb + 2 * HW, t);
     FwdAcc acc;
     RenderState rs;
-    const bool render = a.flags & PD_RENDER_PROB;   // alpha compositing over the planes instead of the softmax
+    constexpr bool render = RENDER;   // alpha compositing over the planes instead of the softmax (a template flag: as a
+                                      // run-time one it cost the softmax path 10 % — registers and branches in the plane loop)
     const float* Rn = a.plane_aux + (long)b * a.N * 3;
     for (int n = 0; n < a.N; ++n) {
       const bool mk = uni_mask(u, Rn + n * 3);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float*
 // only one matrix per image is ever formed (pd_plane_sweep_uniform.hip header; ops.plane_sweep_homography).
 constexpr int kUniG = 4;
 
-template <bool MIX>
+template <bool MIX, bool RENDER = false>
 __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, BwdOut o, int b0, float* __restrict__ tmp,
                                                                    float* __restrict__ partials, const float* __restrict__ tw,
                                                                    const int* __restrict__ run_flag) {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
                 s2 = sample_vg_k(srcb + 2 * HW, t, d2x, d2y);
     const float* Rn = a.plane_aux + (long)b * N * 3;
     const float* twb = tw ? tw + (long)b * N * 3 : nullptr;
-    const bool render = a.flags & PD_RENDER_PROB;
+    constexpr bool render = RENDER;
     const float Rtot = MIX ? -c.A * c.mx : c.gdotr;   // sum_k p_k dL/dp_k in closed form
     float T = 1.0f, prefix = 0.0f;
     for (int n = 0; n < N; ++n) {
@@ -840,8 +841,11 @@ size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d) {
 
 int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
   dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
-  if (d->flags & PD_MIXTURE) uniform_fwd_kernel<true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
-  else                       uniform_fwd_kernel<false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
+  const bool mix = (d->flags & PD_MIXTURE) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
+  if (mix) { if (render) uniform_fwd_kernel<true, true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
+             else        uniform_fwd_kernel<true, false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash); }
+  else     { if (render) uniform_fwd_kernel<false, true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
+             else        uniform_fwd_kernel<false, false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash); }
   return check_launch("uniform_fwd_kernel");
 }
 
@@ -864,7 +868,8 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   // Measured at 8x49x192x640 (pose_net-like rotations): two-pass 0.27 + 0.38 = 0.65 ms, fused 0.75 ms — sixteen waves
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
   const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
-  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !(d->flags & PD_RENDER_PROB);
+  const bool render = (d->flags & PD_RENDER_PROB) != 0;
+  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !render;
   const int tiles_x = ceil_div(d->W, kFuseC), ntiles = tiles_x * ceil_div(d->H, kFuseR);
   if (!rc && fused) {   // regular case: per-plane gradients handed over through LDS
     dim3 grid(ntiles, d->B);
@@ -883,12 +888,14 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
     // the direct-gather kernel) or PD_UNI_DIRECT asks for the direct gather
     const bool staged = !fused && !getenv("PD_UNI_DIRECT");
     if (mix) {
-      uniform_bwd_pass1_kernel<true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      if (render) uniform_bwd_pass1_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      else        uniform_bwd_pass1_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       if (staged) uniform_bwd_pass2_staged_kernel<true><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
     } else {
-      uniform_bwd_pass1_kernel<false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      if (render) uniform_bwd_pass1_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      else        uniform_bwd_pass1_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       if (staged) uniform_bwd_pass2_staged_kernel<false><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);

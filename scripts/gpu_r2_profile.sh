@@ -70,6 +70,7 @@ b hr_384x1280 --batch 4 --height 384 --width 1280
 b l1_no_mixture --no_mixture
 b render_probability --render_probability
 PD_SWEEP_IMPL=1 b render_probability_general_kernels --render_probability
+b render_probability_homography_mono_sides --render_probability --warp_type homography_warp --mono_sides
 b homography_stereo_49 --warp_type homography_warp
 b homography_mono_f8_49 --warp_type homography_warp --mono_pose
 b homography_mono_f8_49_automask --warp_type homography_warp --mono_pose --automask
