@@ -4,26 +4,32 @@
 // builds Rt with the pose net's rotation (conjugated by the crop matrix) and ZERO translation (reference
 // trainer.py:386-400), so Rtnd = R + t n^T / d = R for every plane (layers.py:216) and
 // H_t2s = inverse(K R K^-1) does not depend on the plane.  Only the facing test (K^-1 p).(R n) > 0 (layers.py:223) still
-// does, through the plane normal.  PD_HOMO_UNIFORM: `plane` is [B,3,3] (one H_t2s per image), `plane_aux` is [B*N,3].
+// does, through the plane normal.  PD_HOMO_UNIFORM: `plane` is [B,4,3,3] (slice 0: the image's H_t2s; slices 1..3: the
+// virtual planes that carry the translation's gradient, see uniform_bwd_pass1_kernel), `plane_aux` is [B*N,3].
 //
 // Forward: the sampling position, the four tap offsets / weights and the three colour samples are computed ONCE per
-// target pixel; the plane loop is 8 loads + 8 FMAs + the online softmax (the general kernel spends ~190 VALU per pixel
-// and plane on the geometry it re-derives 49 times).
+// target pixel; the plane loop is 8 loads + 8 FMAs + the online softmax (or, PD_RENDER_PROB, the compositing step) — the
+// general kernel spends ~190 VALU per pixel and plane on the geometry it re-derives 49 times.
 //
-// Backward without atomics, in two passes per image (the scatter pattern is the same for all planes, so it can be
-// inverted once per SOURCE pixel and reused 49 times):
+// Backward without atomics, in two passes (the scatter pattern is the same for all planes, so it can be inverted once
+// per SOURCE pixel and reused 49 times):
 //   pass 1 (target-anchored): per pixel and plane the closed-form gradients w.r.t. the sampled logit / sigma
-//           (pd_sweep.h) go to a per-image scratch [2][N][H][W] with coalesced stores (zeros for masked planes); the
-//           homography gradient is accumulated per thread over ALL planes and reduced once per workgroup;
+//           (pd_sweep.h) go side by side, as float2, to a scratch [B][N][H*W] with coalesced 8-byte stores (zeros for
+//           masked planes); the homography gradient is accumulated per thread over ALL planes and reduced once per
+//           workgroup;
 //   pass 2 (source-anchored): every source pixel finds the target pixels whose bilinear footprint covers it — the
 //           integer points in the pre-image of its 2x2 neighbourhood, located with the forward homography (fp64
-//           adjugate) and its local Jacobian, each CONFIRMED with the bit-exact forward coordinate chain, which also
-//           yields the exact bilinear weight — keeps up to 12 (index, weight) pairs in registers, and then gathers
-//           g[n][s] = sum_k w_k * scratch[n][t_k] for all planes with plain coalesced stores.  Every element of
-//           g_logits / g_sigma is written exactly once: no zero-fill, no read-modify-write.  A source pixel with more
-//           than 12 contributors (strong minification) is left to a follow-up kernel that re-scans per plane.
-// The scratch of one image (2 x 24 MB at 49 x 192 x 640) is produced and consumed back to back, so it lives in the
-// 256 MB memory-side cache rather than in HBM.
+//           adjugate), each CONFIRMED with the bit-exact forward coordinate chain, which also yields the exact bilinear
+//           weight — keeps up to 12 (slot, weight) pairs in registers, and then gathers
+//           g[n][s] = sum_k w_k * scratch[n][t_k] for all planes with plain coalesced stores (PD_BWD_ACCUMULATE: added to
+//           what another target view left there).  The scratch reaches the gather through LDS: a workgroup owns a
+//           32 x 8 source tile and stages the tile's pre-image box two planes at a time
+//           (uniform_bwd_pass2_staged_kernel; uniform_bwd_pass2_kernel is the direct-gather form and the follow-up for
+//           source pixels with more than 12 contributors, i.e. strong minification).  Every element of g_logits /
+//           g_sigma is written exactly once: no zero-fill, no atomics, deterministic.
+// The whole batch goes through each pass in one launch (parallelism beat keeping one image's scratch in the 256 MB
+// memory-side cache: uniform_chunk); workgroups are dealt to the XCDs in contiguous bands of the image (xcd_banded).
+// Opt-in alternative (PD_UNI_FUSED): both passes in one kernel with an LDS hand-over per plane — exact, slower.
 #include <type_traits>
 
 #include "pd_sweep_geom.h"
