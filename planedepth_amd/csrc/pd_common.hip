@@ -23,5 +23,5 @@ int check_launch(const char* what) {
 
 }  // namespace pd
 
-extern "C" int pd_version(void) { return 101; /* 0.1.1: pd_plane_sweep_fwd/bwd carry the fused mean of ph_map */ }
+extern "C" int pd_version(void) { return 200; /* 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
