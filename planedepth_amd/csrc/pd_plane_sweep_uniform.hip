@@ -30,6 +30,10 @@
 // The whole batch goes through each pass in one launch (parallelism beat keeping one image's scratch in the 256 MB
 // memory-side cache: uniform_chunk); workgroups are dealt to the XCDs in contiguous bands of the image (xcd_banded).
 // Opt-in alternative (PD_UNI_FUSED): both passes in one kernel with an LDS hand-over per plane — exact, slower.
+// Measured and dropped for the target-side kernels: the two horizontal taps of a row as one 8-byte buffer load with the
+// weights permuted onto the pair (4 instead of 8 memory instructions per pixel and plane): forward 0.147 -> 0.157 ms,
+// pass 1 0.189 -> 0.211 ms — unlike the row kernels' shifted streams these pairs are not 8-byte aligned AND not
+// contiguous across lanes once the view is rotated; and LDS staging of logits / sigma (see uniform_bwd_pass2_staged_kernel).
 #include <type_traits>
 
 #include "pd_sweep_geom.h"
