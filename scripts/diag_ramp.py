@@ -10,6 +10,12 @@ torch.cuda.set_device(dev)
 import __graft_entry__ as e; e.build()
 c = bench.make_batch(args, dev, 0)
 step, _ = bench.build_step(args, c, dev)
+if os.environ.get("PREWARM"):   # busy the device first: does the slow stretch depend on time-since-idle or on step count?
+    x = torch.empty(64 << 20, device=dev)
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < float(os.environ["PREWARM"]):
+        x.add_(1.0)
+    torch.cuda.synchronize()
 ev = []
 t0 = time.perf_counter()
 for i in range(80):
