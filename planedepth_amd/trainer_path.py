@@ -77,10 +77,10 @@ def pred_novel_images(self, inputs, outputs):
         # The two shortcuts above are taken from the OPTIONS (what the reference's three networks guarantee), not from
         # the tensors: a custom decoder whose outputs disagree with opt would get silently wrong warps.  This opt-in
         # check (one reduction + a host sync per call: debugging, not training) verifies them on the data.
-        pm, dl = outputs.get("padding_mask"), outputs["disp_layered"]
+        pm, dl = outputs.get("padding_mask"), outputs.get("disp_layered")   # (homography_warp does not read disp_layered)
         if padding_mask is None and pm is not None and not bool((pm == 1).all()):
             raise ValueError("opt.xz_levels == opt.yz_levels == 0 promises an all-ones padding_mask, but it has zeros")
-        if row_uniform and dl.dim() == 4 and dl.shape[-1] > 1 and not bool((dl == dl[..., :1]).all()):
+        if row_uniform and dl is not None and dl.dim() == 4 and dl.shape[-1] > 1 and not bool((dl == dl[..., :1]).all()):
             raise ValueError("opt.yz_levels == 0 promises disparities that are constant along x, but disp_layered is not")
         if row_uniform and pm is not None and pm.dim() == 4 and pm.shape[-1] > 1 and not bool((pm == pm[..., :1]).all()):
             raise ValueError("opt.yz_levels == 0 promises a padding_mask that is constant along x, but it is not")

@@ -1377,6 +1377,47 @@ def test_contract_check_catches_tensors_that_disagree_with_the_options():
         planedepth_amd.pred_novel_images(ns, inputs, bad_disp)
 
 
+def test_contract_check_covers_the_homography_shortcuts():
+    """The round-2 shortcuts of homography_warp are taken from what the reference's code guarantees (zero translation of
+    a novel frame without COLMAP; the stereo pose is a pure x-translation and no normal has an x component):
+    opt.pd_check_contract verifies each on the tensors."""
+    import types
+    import planedepth_amd
+    from planedepth_amd.synthetic import intrinsics, small_pose
+    B, N, H, W = 1, 4, 8, 32
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
+    base = {"probability": torch.empty(B, N, H, W, device="meta"), "logits": torch.randn(B, N, H, W, generator=g).to(dev),
+            "sigma": (0.1 + 0.8 * torch.rand(B, N, H, W, generator=g)).to(dev),
+            "distance": (1.0 + torch.rand(B, N, generator=g)).to(dev), "norm": norm}
+    imgs = {s: torch.rand(B, 3, H, W, generator=g).to(dev) for s in ("l", "r", -1)}
+    inputs = {("color", s): v for s, v in imgs.items()}
+    inputs.update(K=K, inv_K=inv_K)
+
+    def run(side, Rt, **over):
+        opt = types.SimpleNamespace(warp_type="homography_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                    render_probability=False, xz_levels=0, yz_levels=0, use_colmap=False,
+                                    pd_check_contract=True)
+        ns = types.SimpleNamespace(opt=opt, target_sides=[side])
+        out = dict(base, **over)
+        out[("Rt", side)] = Rt.to(dev)
+        planedepth_amd.pred_novel_images(ns, inputs, out)
+
+    pose = small_pose(g, B, rot=0.02, trans=0.0)
+    run(-1, pose)                                                     # zero translation: fine
+    with pytest.raises(ValueError, match="has a translation"):
+        run(-1, small_pose(g, B, rot=0.02, trans=0.05))
+    run("r", small_pose(None, B, stereo=True))                        # the dataset's stereo extrinsic: fine
+    with pytest.raises(ValueError, match="pure x-translation"):
+        run("r", small_pose(g, B, rot=0.02, trans=0.05))
+    tilted = norm.clone()
+    tilted[:, 1] = torch.nn.functional.normalize(torch.tensor([0.3, 0.0, 1.0]), dim=0).to(dev)
+    with pytest.raises(ValueError, match="x component"):
+        run("r", small_pose(None, B, stereo=True), norm=tilted)
+
+
 def test_on_device_grid_is_bit_identical_to_the_reference_pipeline():
     """SURVEY §8f rank 4 / VERDICT r1 F4: inputs["grid"] generated on the device (pd_crop_grid) against the grids the
     reference's RandomResizeCrop / Resize produced (tests/golden/pipeline.npz); then the whole on-device minibatch has
