@@ -1377,6 +1377,42 @@ def test_contract_check_catches_tensors_that_disagree_with_the_options():
         planedepth_amd.pred_novel_images(ns, inputs, bad_disp)
 
 
+@pytest.mark.parametrize("mode", ["planes", "uniform", "stereo_rows"])
+def test_stock_torch_homography_algebra_still_serves_every_route(mode, monkeypatch):
+    """PD_TORCH_HOMOGRAPHY=1 (ops.TORCH_HOMOGRAPHY): the 3x3 algebra as the reference's stock torch chain (fp32
+    torch.inverse) instead of pd_homography_matrices_*, on all three routes of plane_sweep_homography.  Loose bound: the
+    two differ by the inverse's fp32 rounding times cond(H); what is tested is that the comparison
+    switch works end to end, gradients included."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics, small_pose
+    B, N, H, W = 2, 5, 16, 64
+    g = torch.Generator().manual_seed(808)
+    dev = "cuda"
+    src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    logits = torch.randn(B, N, H, W, generator=g).to(dev)
+    sigma = (0.05 + 0.9 * torch.rand(B, N, H, W, generator=g)).to(dev)
+    distance = (1.0 + 4 * torch.rand(B, N, generator=g)).to(dev)
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    Rt = {"planes": small_pose(g, B, rot=0.02, trans=0.05), "uniform": _f8_pose(B, 3, 0.02),
+          "stereo_rows": small_pose(None, B, stereo=True)}[mode].to(dev)
+    res = {}
+    for stock in (False, True):
+        monkeypatch.setattr(ops, "TORCH_HOMOGRAPHY", stock)
+        lg, sg, dd = (t.clone().requires_grad_(True) for t in (logits, sigma, distance))
+        T = Rt.clone().requires_grad_(mode != "stereo_rows")
+        rgb, ph, ph_mean = ops.plane_sweep_homography(src, tgt, lg, sg, dd, norm, T, K, inv_K, return_mean=True,
+                                                      plane_uniform=mode == "uniform", stereo_rows=mode == "stereo_rows")
+        (ph_mean + rgb.sum() * 1e-3).backward()
+        res[stock] = dict(rgb=rgb.detach().cpu(), g_logits=lg.grad.cpu(), g_sigma=sg.grad.cpu())
+        if mode != "uniform":
+            res[stock]["g_distance"] = dd.grad.cpu()
+        if mode != "stereo_rows":
+            res[stock]["g_Rt"] = T.grad.cpu()[:, :3]
+    for k in res[True]:
+        assert rel_err(res[True][k], res[False][k]) < 5e-3, (mode, k, rel_err(res[True][k], res[False][k]))
+
+
 def test_contract_check_covers_the_homography_shortcuts():
     """The round-2 shortcuts of homography_warp are taken from what the reference's code guarantees (zero translation of
     a novel frame without COLMAP; the stereo pose is a pure x-translation and no normal has an x component):
