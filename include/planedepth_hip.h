@@ -343,9 +343,14 @@ int pd_grid_sample_bwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding
  *                               (refined reciprocal) differs from the IEEE quotient; *d_mismatches (device int) += count.
  *   pd_debug_rowquad_occupancy  out[0], out[1] = resident workgroups per CU of the opt-in row-quad forward / backward
  *                               kernels for a row of W pixels and N planes (hipOccupancyMaxActiveBlocksPerMultiprocessor).
+ *   pd_debug_poison_lds, pd_debug_count_lds_nans   see below (PD_DEBUG_POISON_LDS=1 makes the Python layer poison before every launch).
  */
 int pd_selftest_division(float Wm1, int count, float lo, float step, int* d_mismatches, pd_stream_t stream);
 int pd_debug_rowquad_occupancy(int W, int N, int* out);
+/* Fills the LDS of the device's CUs with NaNs (a kernel that reads shared memory it never wrote then yields NaNs). */
+int pd_debug_poison_lds(pd_stream_t stream);
+/* *d_count += the NaNs 2048 workgroups find in 32 KB of shared memory they never wrote (checks that the poison sticks). */
+int pd_debug_count_lds_nans(int* d_count, pd_stream_t stream);
 
 #ifdef __cplusplus
 }

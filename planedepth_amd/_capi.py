@@ -63,6 +63,8 @@ SIGNATURES = {
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
     "pd_selftest_division": (_I, [_F, _I, _F, _F, _P, _P]),
     "pd_debug_rowquad_occupancy": (_I, [_I, _I, _P]),
+    "pd_debug_poison_lds": (_I, [_P]),
+    "pd_debug_count_lds_nans": (_I, [_P, _P]),
     "pd_masked_photometric_fwd": (_I, [_I] * 4 + [_P] * 9),
     "pd_masked_photometric_bwd": (_I, [_I] * 4 + [_P] * 9),
     "pd_homography_matrices_fwd": (_I, [_I] * 4 + [_P] * 10),
@@ -113,9 +115,15 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+POISON_LDS = bool(int(os.environ.get("PD_DEBUG_POISON_LDS", "0")))   # diagnostics: NaNs into the CUs' LDS before every launch
+
+
 def stream_handle(device=None):
     """The raw hipStream_t torch is currently enqueueing on (so our launches order with torch's ops)."""
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    h = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if POISON_LDS:   # a kernel that reads shared memory it never wrote then produces NaNs instead of luck
+        load().pd_debug_poison_lds(h)
+    return h
 
 
 def require_gpu_tensor(name, t, shape=None, dtype=torch.float32):

@@ -25,3 +25,40 @@ int check_launch(const char* what) {
 
 extern "C" int pd_version(void) { return 200; /* 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
+
+// Diagnostics: fill the LDS of (as good as) every CU with NaNs, so that a kernel that reads shared memory it never wrote
+// shows up as NaN results instead of depending on what the previous tenant left there (tests/test_gpu_parity.py).
+namespace pd {
+__global__ __launch_bounds__(256) void poison_lds_kernel(int* __restrict__ sink) {
+  __shared__ float junk[16 * 1024];   // 64 KB: two workgroups fill a CU's 160 KB almost completely
+  for (int i = threadIdx.x; i < 16 * 1024; i += 256) junk[i] = __int_as_float(0x7fc00000 | i);
+  __syncthreads();
+  if (sink && __float_as_int(junk[(threadIdx.x * 61) & (16 * 1024 - 1)]) == 1) *sink = 1;   // keep the stores alive
+}
+}  // namespace pd
+
+namespace pd {
+__global__ __launch_bounds__(256) void count_lds_nans_kernel(int* __restrict__ count) {
+  __shared__ float junk[8 * 1024];   // 32 KB, read WITHOUT having been written
+  int n = 0;
+  if (count == nullptr)   // never true: it only keeps the compiler from treating the reads below as reads of `undef`
+    for (int i = threadIdx.x; i < 8 * 1024; i += 256) junk[i] = 0.0f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 1024; i += 256) {
+    const float v = junk[i];
+    n += (v != v) ? 1 : 0;
+  }
+  if (n) atomicAdd(count, n);
+}
+}  // namespace pd
+
+/* test of the test: how many NaNs 2048 workgroups find in 32 KB of LDS they never wrote (*d_count += that) */
+extern "C" int pd_debug_count_lds_nans(int* d_count, pd_stream_t stream) {
+  pd::count_lds_nans_kernel<<<256 * 8, 256, 0, (hipStream_t)stream>>>(d_count);
+  return pd::check_launch("count_lds_nans_kernel");
+}
+
+extern "C" int pd_debug_poison_lds(pd_stream_t stream) {
+  pd::poison_lds_kernel<<<256 * 8, 256, 0, (hipStream_t)stream>>>(nullptr);
+  return pd::check_launch("poison_lds_kernel");
+}

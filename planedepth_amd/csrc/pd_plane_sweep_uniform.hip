@@ -516,6 +516,11 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, kWave));
   kmax = __builtin_amdgcn_readfirstlane(kmax);
+  // Entries a lane does not use have weight 0 and slot 0.  Slot 0 of the staged box holds a real value as soon as ANY
+  // lane of the workgroup has a contributor (contributors lie in the box, so the box is not empty); a wave without a
+  // single contributor must not read LDS at all — the box may be empty and the buffer uninitialised, and 0 * garbage is
+  // NaN when the garbage is (seen once in ~40 runs of the minification test on fresh boxes).
+  const int kuse = kmax == 0 ? 0 : max(kmax, 4);   // four entries for everybody (the regular case), the rest wave-bounded
   float* gl = (live && g_logits) ? g_logits + (long)b * N * HW + (long)sy * W + sx : nullptr;
   float* gs = (live && MIX && g_sigma) ? g_sigma + (long)b * N * HW + (long)sy * W + sx : nullptr;
 
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
         float accl = oldl[p], accs = olds[p];
 #pragma unroll
         for (int k = 0; k < kUniK; ++k) {
-          if (k < 4 || k < kmax) {
+          if (k < kuse) {
             const Elem v = buf[which][p][idx[k]];
             if constexpr (MIX) { accl += wgt[k] * v.x; accs += wgt[k] * v.y; }
             else accl += wgt[k] * v;

@@ -16,6 +16,25 @@ from . import _capi as C
 SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
+if int(os.environ.get("PD_DEBUG_POISON_MEM", "0")):
+    # diagnostics: every buffer this module allocates uninitialised (outputs, stash, workspaces) starts as NaNs, so a
+    # kernel that reads global memory nobody wrote produces NaNs instead of depending on the allocator's leftovers
+    class _PoisonedTorch:
+        def __getattr__(self, name):
+            return getattr(_real_torch, name)
+
+        @staticmethod
+        def empty(*a, **k):
+            t = _real_torch.empty(*a, **k)
+            return t.fill_(float("nan")) if t.is_floating_point() and t.device.type == "cuda" else t
+
+        @staticmethod
+        def empty_like(x, **k):
+            t = _real_torch.empty_like(x, **k)
+            return t.fill_(float("nan")) if t.is_floating_point() and t.device.type == "cuda" else t
+
+    _real_torch = torch
+    torch = _PoisonedTorch()
 KERNEL_EVENTS = None     # measurement (bench.py): set to a dict {"fwd": [], "bwd": []} to collect (start, end) CUDA events
                          # recorded on the launch stream around the sweep's C-ABI calls INSIDE a training step
 

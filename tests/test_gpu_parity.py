@@ -1413,6 +1413,34 @@ def test_stock_torch_homography_algebra_still_serves_every_route(mode, monkeypat
         assert rel_err(res[True][k], res[False][k]) < 5e-3, (mode, k, rel_err(res[True][k], res[False][k]))
 
 
+@pytest.mark.parametrize("rot,zoom", [(0.4, 1.0), (0.25, 0.6), (0.05, 1.0)])
+def test_uniform_backward_never_reads_shared_memory_it_did_not_write(rot, zoom):
+    """Regression: a source tile whose pre-image lies outside the target image (the view turned away from it) staged
+    nothing into LDS, yet unused gather entries (weight 0, slot 0) were still read: 0 * whatever the CU's LDS held, i.e.
+    NaN once in a while (fresh boxes hold ~1e-5 NaN patterns in LDS, scripts/diag_lds.py).  With the LDS of the device
+    poisoned with NaNs first, any such read shows up deterministically."""
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics
+    B, N, H, W = 1, 4, 30, 90
+    g = torch.Generator().manual_seed(990)
+    dev = "cuda"
+    src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
+    distance = (1.0 + torch.rand(B, N, generator=g)).to(dev)
+    Rt = _f8_pose(B, 61, rot, dev)
+    Rt[:, :2, :3] *= zoom
+    for _ in range(3):
+        lg = torch.randn(B, N, H, W, generator=g).to(dev).requires_grad_(True)
+        sg = (0.05 + 0.9 * torch.rand(B, N, H, W, generator=g)).to(dev).requires_grad_(True)
+        rgb, ph, ph_mean = ops.plane_sweep_homography(src, tgt, lg, sg, distance, norm, Rt, K, inv_K, return_mean=True,
+                                                      plane_uniform=True)
+        C.check(C.load().pd_debug_poison_lds(C.stream_handle()), "pd_debug_poison_lds")
+        (ph_mean + rgb.sum() * 1e-3).backward()
+        assert bool(torch.isfinite(lg.grad).all()) and bool(torch.isfinite(sg.grad).all())
+
+
 def test_contract_check_covers_the_homography_shortcuts():
     """The round-2 shortcuts of homography_warp are taken from what the reference's code guarantees (zero translation of
     a novel frame without COLMAP; the stereo pose is a pure x-translation and no normal has an x component):
@@ -1504,18 +1532,22 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     (1, 3, 5, 7, True, False, 0.3, 1.0), (1, 63, 192, 640, True, True, 0.01, 1.0),
     (1, 4, 30, 90, True, False, 0.05, 2.6),     # target 2.6x denser than the source: ~27 contributors per source pixel
     (1, 4, 30, 90, True, False, 0.05, 0.45)])   # the other way round: most source pixels get none
-@pytest.mark.parametrize("fused", [False, True])
-def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix, automask, rot, zoom, fused, monkeypatch):
+@pytest.mark.parametrize("bwd", ["staged", "direct", "fused"])
+def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix, automask, rot, zoom, bwd, monkeypatch):
     """PD_HOMO_UNIFORM (pd_plane_sweep_uniform.hip: geometry once per pixel, two-pass atomic-free backward) against the
     general kernels on poses shaped like predict_poses' output (zero translation): one homography per image, planes with
     two different normals (the facing test still differs per plane), rotations up to 17 degrees, ragged sizes, and
     zooms that push the per-source-pixel gather list past its 8 register slots (the follow-up re-scan kernel)."""
     from planedepth_amd import ops
     from planedepth_amd.synthetic import intrinsics
-    if fused:   # the LDS hand-over form of the backward (opt-in); irregular launches fall through to the two-pass kernels
+    # backward variants: pass 2 with the scratch staged through LDS (default), the direct-gather pass 2 (PD_UNI_DIRECT), the
+    # one-kernel LDS hand-over form (PD_UNI_FUSED, opt-in; irregular launches fall through to the two-pass kernels)
+    monkeypatch.delenv("PD_UNI_FUSED", raising=False)
+    monkeypatch.delenv("PD_UNI_DIRECT", raising=False)
+    if bwd == "fused":
         monkeypatch.setenv("PD_UNI_FUSED", "1")
-    else:
-        monkeypatch.delenv("PD_UNI_FUSED", raising=False)
+    elif bwd == "direct":
+        monkeypatch.setenv("PD_UNI_DIRECT", "1")
     g = torch.Generator().manual_seed(900 + W + N)
     dev = "cuda"
     src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
