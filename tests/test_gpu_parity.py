@@ -1441,6 +1441,37 @@ def test_uniform_backward_never_reads_shared_memory_it_did_not_write(rot, zoom):
         assert bool(torch.isfinite(lg.grad).all()) and bool(torch.isfinite(sg.grad).all())
 
 
+def test_launches_follow_torchs_current_stream():
+    """The C ABI takes an explicit stream and the Python layer hands it torch's CURRENT one: the whole path run inside a
+    side-stream context (inputs produced on that stream right before, no synchronisation in between) gives the result
+    of the default stream.  A launch on the wrong stream would race with the producer kernels."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    case = build_case(B=2, N=9, H=24, W=200, seed=321, disp_min=0.5, disp_max=40.0, sigma_interior=True)
+    c = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.items()}
+
+    def run():
+        # the inputs are (re)computed on the current stream immediately before the sweep: a misplaced launch reads them early
+        lg = (c["logits"] * 1.0 + 0.0).requires_grad_(True)
+        sg = (c["sigma"] * 1.0).requires_grad_(True)
+        dp = c["disp_pp"].clone().requires_grad_(True)
+        rgb, ph, ph_mean = ops.plane_sweep_disp(c["color_l"] * 1.0, c["color_r"] * 1.0, lg, sg, dp.expand(-1, -1, 24, 200),
+                                                None, automask=True, return_mean=True)
+        (ph_mean + (rgb * c["g_rgb_rec"]).sum()).backward()
+        return [t.detach().clone() for t in (rgb, ph, lg.grad, sg.grad, dp.grad)]
+
+    want = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            got = run()
+    side.synchronize()
+    for a_, b_ in zip(got, want):
+        assert rel_err(a_.cpu(), b_.cpu()) < 1e-6
+
+
 def test_contract_check_covers_the_homography_shortcuts():
     """The round-2 shortcuts of homography_warp are taken from what the reference's code guarantees (zero translation of
     a novel frame without COLMAP; the stereo pose is a pure x-translation and no normal has an x component):
