@@ -128,11 +128,16 @@ def pred_novel_images(self, inputs, outputs):
                                               dists=dists, return_mean=True, plane_uniform=uniform,
                                               stereo_rows=stereo_rows, defer=True)
 
-            def matrices(T=T):
+            def matrices(T=T):   # the same matrices the sweep itself used (pd_homography_matrices_fwd unless PD_TORCH_HOMOGRAPHY)
                 with torch.no_grad():
-                    ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
-                    H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
-                                                        ex(inputs["inv_K"]))
+                    if ops.TORCH_HOMOGRAPHY:
+                        ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+                        H_t2s, Rn = ops.homography_matrices(outputs["distance"], outputs["norm"], ex(T), ex(inputs["K"]),
+                                                            ex(inputs["inv_K"]))
+                    else:
+                        H_t2s, Rn = ops.homography_matrices_fused(outputs["distance"], outputs["norm"], T, inputs["K"],
+                                                                  inputs["inv_K"])
+                        H_t2s, Rn = H_t2s.reshape(B * N, 3, 3), Rn.reshape(B * N, 3)
                 return H_t2s, Rn, inputs["inv_K"][:, :3, :3]
 
             handle = SweepHandle(src=src, logits=outputs["logits"], sigma=sigma, homography=matrices,
