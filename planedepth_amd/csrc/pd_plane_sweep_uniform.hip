@@ -306,7 +306,11 @@ struct UniWindow { int x0, x1, y0, y1; };
 __device__ __forceinline__ UniWindow uni_window(const UniPrep& p, int sx, int sy, int W, int H) {
   UniWindow w;
   w.x0 = 0; w.y0 = 0; w.x1 = W - 1; w.y1 = H - 1;
-  if (p.ok == 0.0f) return w;
+  // A homography that is not finite / not invertible (a diverged pose net) has no meaningful adjoint: give such an image an
+  // EMPTY window (its gradients are garbage either way) instead of the whole-image scan, which at 192 x 640 would keep the
+  // device busy for seconds per image.  The whole-image fallback below is for valid maps whose line at infinity crosses
+  // the tile (rotations beyond ~50 degrees at KITTI's field of view: nothing a pose net scaled by 0.01 produces).
+  if (p.ok == 0.0f) { w.x1 = -1; w.y1 = -1; return w; }
   float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f, wmin = 3.0e38f, wmax = -3.0e38f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

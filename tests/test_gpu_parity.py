@@ -1555,6 +1555,40 @@ def test_randomised_shapes_homography_shortcuts_vs_general():
             assert rel_err(a_, b_) < tol, (tag, k, rel_err(a_, b_))
 
 
+def test_non_finite_pose_does_not_stall_the_uniform_backward():
+    """A diverged pose net hands over NaNs: the plane-uniform backward must come back at once (empty gather windows for
+    that image) instead of scanning the whole image per source pixel, and the healthy image of the batch must be
+    unaffected."""
+    import time
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics
+    B, N, H, W = 2, 5, 48, 160
+    g = torch.Generator().manual_seed(12)
+    dev = "cuda"
+    src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
+    logits = torch.randn(B, N, H, W, generator=g).to(dev)
+    sigma = (0.05 + 0.9 * torch.rand(B, N, H, W, generator=g)).to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
+    distance = (1.0 + torch.rand(B, N, generator=g)).to(dev)
+    good = _f8_pose(B, 7, 0.03, dev)
+    res = {}
+    for poisoned in (False, True):
+        Rt = good.clone()
+        if poisoned:
+            Rt[1, 0, 0] = float("nan")
+        lg, sg = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+        rgb, ph, ph_mean = ops.plane_sweep_homography(src, tgt, lg, sg, distance, norm, Rt, K, inv_K, return_mean=True,
+                                                      plane_uniform=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        (rgb[0].sum() * 1e-3 + ph[0].mean()).backward()      # a loss over the healthy image only
+        torch.cuda.synchronize()
+        res[poisoned] = (lg.grad[0].cpu(), sg.grad[0].cpu(), time.perf_counter() - t0)
+    assert res[True][2] < 20 * res[False][2] + 0.05
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_contract_check_covers_the_homography_shortcuts():
     """The round-2 shortcuts of homography_warp are taken from what the reference's code guarantees (zero translation of
     a novel frame without COLMAP; the stereo pose is a pure x-translation and no normal has an x component):
