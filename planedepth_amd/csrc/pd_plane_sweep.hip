@@ -535,6 +535,9 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     PD_REQUIRE(workspace, "the row-shift backward needs workspace (pd_sweep_bwd_workspace_floats)");
     // same VALU work per pixel as the one-pixel-per-lane backward (which is VALU-bound), lower occupancy: slower. Opt-in.
     if (rowquad_applicable(d, ak.has_mask != 0) && getenv("PD_QUAD_BWD")) return rowquad_bwd(d, ak, o, stream);
+    // default: lanes own aligned source slots, waves stream along plane rows (pd_plane_sweep_rowstream.hip);
+    // PD_IMPL_ROWS1 keeps the target-ordered row-shift backward (cross-check, A/B)
+    if (d->impl != PD_IMPL_ROWS1 && rowstream_bwd_applicable(d, ak) && !getenv("PD_NO_ROWSTREAM")) return rowstream_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
   }
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) {

@@ -1,0 +1,481 @@
+// Row-stream backward of the fused plane sweep: PD_WARP_DISP with one disparity per (image, plane) or per (image,
+// plane, row), no per-pixel mask, softmax probabilities (reference trainer.py:540-603 + 728-742 through autograd).
+//
+// The row-shift backward (pd_plane_sweep_rowshift.hip) gives every lane a TARGET pixel and routes the adjoint of the
+// 2-tap gather to its source slot: loads and gradient stores start at x + k, k = floor(s*d) — 4-byte-aligned runs that
+// straddle cache lines, one 4-byte store per lane, hand-overs between the segments of different waves.  Measured
+// (scripts/probes/stream_probe.hip, 8x49x192x640): the memory pipeline of gfx950 is paced by instruction count — that
+// shape tops out at 4.0-4.4 TB/s, 12-byte loads + aligned 8-byte stores reach 5.4 TB/s.  This kernel turns the
+// ownership around:
+//   * a lane owns two consecutive, 8-byte-ALIGNED SOURCE slots xs, xs+1 of the row; slot xs is paired with the target
+//     pixel xt = xs - k, whose left tap is xs.  The taps (L[xs..xs+2]) are one aligned 12-byte load per tensor, the
+//     gradient pair one aligned 8-byte store: full cache lines, no ring, no wrap, no edge fix-up, no validity masks
+//     (a slot whose target is outside the row reads an all-zero context and stores the zero it has to store);
+//   * what shifts with the plane is the per-target-pixel context (target colour, softmax statistics, upstream
+//     gradients: 12 floats).  It is staged once per row in LDS and read at xs - k;
+//   * a wave walks the 128-slot segments of one (plane, row) IN ORDER, so the right-tap contribution that leaves a
+//     segment is carried to the next one in a register (v_readlane) — no LDS parking, no atomics, no neighbour waves.
+//     The waves of a workgroup split the row's (plane, segment) list into contiguous ranges; the at most nwaves-1
+//     range boundaries that fall inside a row are settled with one atomic per tensor after the loop;
+//   * the disparity gradient is accumulated per lane over the whole row and reduced once per plane and wave.
+//
+// Exactness.  Slot xs is paired with target xt = xs - k on the premise floor(ix(xt)) = xt + k.  The reference's fp32
+// coordinate chain can move ix across an integer when frac(s*d) is within ~4e-7 * W of 0 or 1 (pd_plane_sweep_rowshift's
+// header): planes with frac(s*d) closer than kIrrTol(W) to an integer ("irregular", decided when the shifts are
+// staged) take a general per-lane path instead — exact floor(ix) per target, gradient rows zero-filled up front,
+// contributions added with atomics (two addends per slot: the order cannot change the sum).  For every other plane
+// the premise holds with a margin of 3x the worst-case rounding error of the chain (bound in DESIGN.md 3.6).
+// Targets whose left tap is column -1 (negative shifts) have no slot: a short epilogue serves them (lanes = planes).
+//
+// Vertical: rows whose y round trip is inexact blend two source rows (weights 1-eps, eps); values and per-pixel
+// gradients use both, the adjoint applies the own row's weight and drops the eps-weighted neighbour term exactly as
+// the row-shift kernels do (same bound, same tests).
+#include <stdlib.h>
+
+#include "pd_rowshift_common.h"
+
+namespace pd {
+
+#ifndef PD_STREAM_D1
+#define PD_STREAM_D1 3   // prefetch depth in (plane, segment) iterations, one live source row
+#endif
+#ifndef PD_STREAM_D2
+#define PD_STREAM_D2 2   // two live source rows (twice the registers per group)
+#endif
+#ifndef PD_STREAM_OCC
+#define PD_STREAM_OCC 4  // waves per SIMD the register allocator must leave room for
+#endif
+
+constexpr int kSlots = 2;               // source slots per lane
+constexpr int kSeg = kWave * kSlots;    // slots per wave iteration
+constexpr int kStreamThreadsMax = 1024;
+
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v3f buf_load3(Rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store2(Rsrc r, unsigned voff, unsigned soff, float x, float y) {
+  __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, (int)voff,
+                                        (int)soff, 0);
+}
+
+// frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
+// chain against exact arithmetic: fl(x + sd) <= ulp(2W)/2, the division, the two additions and the product by W-1
+// each <= ulp(.)/2 scaled by W-1 — 4.2e-7 * W in total for W <= 4096; the threshold keeps a factor of ~3.
+__device__ __forceinline__ float irregular_tol(int W) { return 2.5e-4f + 1.25e-6f * (float)W; }
+
+struct StreamLds {
+  float4* ctx0;   // [CW] (t0, t1, t2, lse2)            cell = pixel + 2, zero-gradient guard cells around the row
+  float4* ctx1;   // [CW] (gr0, gr1, gr2, gdotr)
+  float4* ctx2;   // [CW] (invS, mx, A, -)
+  float4* col;    // [CW] vertically blended source colour (r, g, b, -), zero beyond the row
+  int2* shift;    // [N]  (bits of s*d clamped, k << 1 | irregular) — integers: a float-typed slot may flush the denormal pattern
+  float* red;     // [N]  disparity-gradient sums of the row
+  float* hand;    // [nwaves][2] carries that leave a wave's range in the middle of a row
+  int* special;   // [1]  any plane with a negative shift or an irregular one (the epilogue has work)
+  int CW;
+};
+
+__device__ __forceinline__ PixelCtx ctx_at(const StreamLds& L, int cell) {
+  const float4 a = L.ctx0[cell], g = L.ctx1[cell], h = L.ctx2[cell];
+  PixelCtx c;
+  c.t0 = a.x; c.t1 = a.y; c.t2 = a.z; c.lse2 = a.w;
+  c.gr0 = g.x; c.gr1 = g.y; c.gr2 = g.z; c.gdotr = g.w;
+  c.invS = h.x; c.mx = h.y; c.A = h.z;
+  return c;
+}
+
+// ix of the reference for target column xtf (an integer-valued float) under the shift sd: make_col_tap's chain
+__device__ __forceinline__ float stream_ix(float xtf, float sd, float Wm1, float rcpWm1) {
+#pragma clang fp contract(off)
+  const float px = xtf + sd;
+  const float q = div_by(px, Wm1, rcpWm1);
+  const float h = q - 0.5f;
+  const float hh = h + 0.5f;
+  return hh * Wm1;
+}
+
+template <int NROWS>
+struct StreamGroup {   // the taps of one (plane, segment) iteration: L[xs .. xs+2] per live source row
+  float l[NROWS][3], s[NROWS][3];
+};
+
+struct StreamRow {     // workgroup-uniform
+  int b, y, yA, yB;
+  float wA, wB, wy;    // vertical weights of the two source rows; adjoint weight of the own row
+};
+
+template <bool MIX, int NROWS>
+__device__ __forceinline__ void stream_issue(StreamGroup<NROWS>& g, const SweepArgs& a, const StreamRow& r, int n, int seg,
+                                             unsigned lane8, int HW) {
+  const unsigned soff = (unsigned)seg * (kSeg * 4);
+  const float* pl = plane_ptr(a.logits + (long)r.b * a.N * HW, n, HW);
+  const v3f la = buf_load3(row_rsrc(pl + (long)r.yA * a.W, a.W), lane8, soff);
+  g.l[0][0] = la.x; g.l[0][1] = la.y; g.l[0][2] = la.z;
+  if (NROWS == 2) {
+    const v3f lb = buf_load3(row_rsrc(pl + (long)r.yB * a.W, a.W), lane8, soff);
+    g.l[NROWS - 1][0] = lb.x; g.l[NROWS - 1][1] = lb.y; g.l[NROWS - 1][2] = lb.z;
+  }
+  if (MIX) {
+    const float* ps = plane_ptr(a.sigma + (long)r.b * a.N * HW, n, HW);
+    const v3f sa = buf_load3(row_rsrc(ps + (long)r.yA * a.W, a.W), lane8, soff);
+    g.s[0][0] = sa.x; g.s[0][1] = sa.y; g.s[0][2] = sa.z;
+    if (NROWS == 2) {
+      const v3f sb = buf_load3(row_rsrc(ps + (long)r.yB * a.W, a.W), lane8, soff);
+      g.s[NROWS - 1][0] = sb.x; g.s[NROWS - 1][1] = sb.y; g.s[NROWS - 1][2] = sb.z;
+    }
+  }
+}
+
+// One regular (plane, segment) iteration.  carry_*: right-tap contribution of the previous segment's last slot (wave
+// uniform); returns this segment's in the same variables.
+template <bool MIX, int NROWS>
+__device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, const SweepArgs& a, const BwdOut& o,
+                                               const StreamRow& r, const StreamLds& L, int n, int seg, int k, float sd,
+                                               int lane, unsigned lane8, float lane2f, int HW, float Wm1, float rcpWm1,
+                                               int want_plane, int gl_bytes, int gs_bytes, float& carry_l,
+                                               float& carry_s, float& gacc) {
+  const int xs0 = seg * kSeg + lane * kSlots;
+  const float xs0f = (float)(seg * kSeg) + lane2f;
+  const float xt0f = xs0f - (float)k;   // integers below 2^24: exact
+  // context of the two paired targets xt, xt+1: adjacent cells (guard cells two deep on both sides keep them adjacent)
+  const int cell = min(max(xs0 - k, -2), a.W) + 2;
+  const float4* colp = L.col + xs0 + 2;
+  const float4 cv0 = colp[0], cv1 = colp[1], cv2 = colp[2];
+  float cl0[kSlots], cl1[kSlots], cs0[kSlots], cs1[kSlots];
+#pragma unroll
+  for (int i = 0; i < kSlots; ++i) {
+    const PixelCtx c = ctx_at(L, cell + i);
+    const float xsf = xs0f + (float)i;
+    const float ix = stream_ix(xt0f + (float)i, sd, Wm1, rcpWm1);
+    const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;   // torch's (x1 - ix), (ix - x0) with x0 = xs
+    float l, s = 0.0f, dlx, dsx = 0.0f;
+    if (NROWS == 1) {
+      l = g.l[0][i] * w0 + g.l[0][i + 1] * w1;
+      dlx = g.l[0][i + 1] - g.l[0][i];
+      if (MIX) {
+        s = g.s[0][i] * w0 + g.s[0][i + 1] * w1;
+        dsx = g.s[0][i + 1] - g.s[0][i];
+      }
+    } else {
+      const float a0 = w0 * r.wA, a1 = w1 * r.wA, b0 = w0 * r.wB, b1 = w1 * r.wB;
+      l = g.l[0][i] * a0 + g.l[0][i + 1] * a1 + g.l[NROWS - 1][i] * b0 + g.l[NROWS - 1][i + 1] * b1;
+      dlx = (g.l[0][i + 1] - g.l[0][i]) * r.wA + (g.l[NROWS - 1][i + 1] - g.l[NROWS - 1][i]) * r.wB;
+      if (MIX) {
+        s = g.s[0][i] * a0 + g.s[0][i + 1] * a1 + g.s[NROWS - 1][i] * b0 + g.s[NROWS - 1][i + 1] * b1;
+        dsx = (g.s[0][i + 1] - g.s[0][i]) * r.wA + (g.s[NROWS - 1][i + 1] - g.s[NROWS - 1][i]) * r.wB;
+      }
+    }
+    const float4 ca = (i == 0) ? cv0 : cv1, cb = (i == 0) ? cv1 : cv2;
+    const float c0 = ca.x * w0 + cb.x * w1, c1 = ca.y * w0 + cb.y * w1, c2 = ca.z * w0 + cb.z * w1;
+    const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    const float m0 = (NROWS == 1) ? w0 : w0 * r.wy, m1 = (NROWS == 1) ? w1 : w1 * r.wy;
+    cl0[i] = pg.g_l * m0; cl1[i] = pg.g_l * m1;
+    cs0[i] = pg.g_s * m0; cs1[i] = pg.g_s * m1;
+    if (want_plane)
+      gacc += pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * (cb.x - ca.x) + pg.gc1 * (cb.y - ca.y) + pg.gc2 * (cb.z - ca.z);
+  }
+  // slot xs receives the left-tap part of its own target and the right-tap part of the target one slot to the left
+  const float pl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_l), __float_as_int(cl1[kSlots - 1]), 0x138, 0xF, 0xF, false));
+  const float out_l0 = cl0[0] + pl, out_l1 = cl0[1] + cl1[0];
+  carry_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1[kSlots - 1]), kWave - 1));   // (an int builtin)
+  const unsigned soff = (unsigned)seg * (kSeg * 4);
+  buf_store2(row_rsrc_bytes(plane_ptr(o.g_logits + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gl_bytes), lane8, soff, out_l0, out_l1);
+  if (MIX) {
+    const float ps = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_s), __float_as_int(cs1[kSlots - 1]), 0x138, 0xF, 0xF, false));
+    const float out_s0 = cs0[0] + ps, out_s1 = cs0[1] + cs1[0];
+    carry_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs1[kSlots - 1]), kWave - 1));
+    buf_store2(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gs_bytes), lane8, soff, out_s0, out_s1);
+  }
+}
+
+// General form for one paired slot xs of plane n (n may differ per lane): the target xt = xs - k with its EXACT
+// floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
+// Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
+template <bool MIX, int NROWS>
+__device__ __forceinline__ float stream_general_slot(const SweepArgs& a, const BwdOut& o, const StreamRow& r,
+                                                     const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
+                                                     float Wm1, float rcpWm1) {
+  const int W = a.W;
+  const int xt = xs - k;
+  on = on && xt >= 0 && xt < W;
+  const ColTap t = make_col_tap((float)xt + sd, Wm1, rcpWm1);
+  const bool v0 = on && t.x0 >= 0 && t.x0 < W, v1 = on && t.x0 + 1 >= 0 && t.x0 + 1 < W;
+  if (!(v0 || v1)) return 0.0f;   // nothing of this target is in view: no samples, no gradient, no disparity term
+  const long rowA = ((long)r.b * a.N + n) * HW + (long)r.yA * W, rowB = ((long)r.b * a.N + n) * HW + (long)r.yB * W;
+  const float la0 = v0 ? a.logits[rowA + t.x0] : 0.0f, la1 = v1 ? a.logits[rowA + t.x0 + 1] : 0.0f;
+  float lb0 = 0.0f, lb1 = 0.0f, sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+  if (NROWS == 2) { lb0 = v0 ? a.logits[rowB + t.x0] : 0.0f; lb1 = v1 ? a.logits[rowB + t.x0 + 1] : 0.0f; }
+  if (MIX) {
+    sa0 = v0 ? a.sigma[rowA + t.x0] : 0.0f; sa1 = v1 ? a.sigma[rowA + t.x0 + 1] : 0.0f;
+    if (NROWS == 2) { sb0 = v0 ? a.sigma[rowB + t.x0] : 0.0f; sb1 = v1 ? a.sigma[rowB + t.x0 + 1] : 0.0f; }
+  }
+  const float wA = (NROWS == 1) ? 1.0f : r.wA, wB = (NROWS == 1) ? 0.0f : r.wB;
+  const float a0 = t.w0 * wA, a1 = t.w1 * wA, b0 = t.w0 * wB, b1 = t.w1 * wB;
+  const float l = la0 * a0 + la1 * a1 + lb0 * b0 + lb1 * b1;
+  const float s = sa0 * a0 + sa1 * a1 + sb0 * b0 + sb1 * b1;
+  const float dlx = (la1 - la0) * wA + (lb1 - lb0) * wB, dsx = (sa1 - sa0) * wA + (sb1 - sb0) * wB;
+  const float4 ca = L.col[min(max(t.x0, -2), L.CW - 4) + 2], cb = L.col[min(max(t.x0 + 1, -2), L.CW - 4) + 2];
+  const float c0 = ca.x * t.w0 + cb.x * t.w1, c1 = ca.y * t.w0 + cb.y * t.w1, c2 = ca.z * t.w0 + cb.z * t.w1;
+  const PixelCtx c = ctx_at(L, xt + 2);
+  const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+  const float wy = (NROWS == 1) ? 1.0f : r.wy;
+  float* gl = o.g_logits ? o.g_logits + ((long)r.b * a.N + n) * HW + (long)r.y * W : nullptr;
+  float* gs = (MIX && o.g_sigma) ? o.g_sigma + ((long)r.b * a.N + n) * HW + (long)r.y * W : nullptr;
+  if (v0) {
+    if (gl) unsafeAtomicAdd(gl + t.x0, pg.g_l * (t.w0 * wy));
+    if (gs) unsafeAtomicAdd(gs + t.x0, pg.g_s * (t.w0 * wy));
+  }
+  if (v1) {
+    if (gl) unsafeAtomicAdd(gl + t.x0 + 1, pg.g_l * (t.w1 * wy));
+    if (gs) unsafeAtomicAdd(gs + t.x0 + 1, pg.g_s * (t.w1 * wy));
+  }
+  return pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * (cb.x - ca.x) + pg.gc1 * (cb.y - ca.y) + pg.gc2 * (cb.z - ca.z);
+}
+
+template <bool MIX, int NROWS>
+__device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, const StreamLds& L) {
+  constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
+  const int W = a.W, N = a.N, HW = a.H * a.W;
+  StreamRow r;
+  r.y = block_row(bwd_rowid(a.B, a.H), a.H);
+  r.b = wg_image(a.B, a.H);
+  r.yA = row.yA; r.yB = (NROWS == 2) ? row.yB : row.yA;
+  r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
+  r.wy = row.wy_main;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + kSeg - 1) / kSeg;
+  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
+  const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);   // 0: the stores become no-ops
+  const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
+  const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
+
+  // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
+  const float* srcb = a.src + (long)r.b * 3 * HW;
+  for (int cidx = threadIdx.x; cidx < L.CW; cidx += blockDim.x) {
+    const int x = cidx - 2;
+    PixelCtx c = zero_pixel_ctx();
+    c.lse2 = 3.0e38f;   // probability 0: a slot whose target is outside the row gets exact zeros
+    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W) {
+      c = make_pixel_ctx<MIX>(a, o, r.b, r.y * W + x, HW);
+      const float* p = srcb + (long)r.yA * W + x;
+      cc = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
+      if (NROWS == 2) {
+        const float* q = srcb + (long)r.yB * W + x;
+        // fl(B*wB + fl(A*wA)): the rounding of the four-tap sum of the target-ordered kernels when the column weights are (1, 0)
+        // — with tgt == src and a zero disparity, sign(c - t) sits on the last ulp (knife edge (d))
+        cc = make_float4(fmaf(q[0], r.wB, cc.x * r.wA), fmaf(q[HW], r.wB, cc.y * r.wA), fmaf(q[2 * HW], r.wB, cc.z * r.wA), 0.0f);
+      }
+    }
+    L.ctx0[cidx] = make_float4(c.t0, c.t1, c.t2, c.lse2);
+    L.ctx1[cidx] = make_float4(c.gr0, c.gr1, c.gr2, c.gdotr);
+    L.ctx2[cidx] = make_float4(c.invS, c.mx, c.A, 0.0f);
+    L.col[cidx] = cc;
+  }
+  if (threadIdx.x == 0) *L.special = 0;
+  __syncthreads();
+  {
+    const float lim = (float)(W + 2), tol = irregular_tol(W);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      const long di = (a.flags & PD_DISP_ROWS) ? ((long)r.b * N + i) * a.H + r.y : (long)r.b * N + i;
+      const float sdr = a.sign * a.plane[di];
+      // PD_MASK_ROWS: a masked plane samples as all-zero features (trainer.py:580) — what a plane shifted out of view does
+      const bool masked = a.mask_rows && a.mask_rows[((long)r.b * N + i) * a.H + r.y] == 0.0f;
+      const float sd = (!masked && sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
+      const float fl = floorf(sd), fr = sd - fl;
+      const int k = (int)fl;
+      const bool inview = fabsf(sd) < (float)(W + 1);
+      const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
+      L.shift[i] = make_int2(__float_as_int(sd), k * 2 + irr);
+      L.red[i] = 0.0f;
+      if (irr || (k < 0 && inview)) *L.special = 1;
+    }
+  }
+  __syncthreads();
+  const int special = __builtin_amdgcn_readfirstlane(*L.special);
+  if (special) {   // irregular planes: their gradient rows are accumulated with atomics, so they start from zero
+    for (int n = 0; n < N; ++n) {
+      if (!(L.shift[n].y & 1)) continue;
+      for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        if (o.g_logits) o.g_logits[((long)r.b * N + n) * HW + (long)r.y * W + x] = 0.0f;
+        if (MIX && o.g_sigma) o.g_sigma[((long)r.b * N + n) * HW + (long)r.y * W + x] = 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- this wave's contiguous range of the row's (plane, segment) list -------------------------------------------
+  const int items = N * nseg;
+  const int i0 = __builtin_amdgcn_readfirstlane((int)((long)items * wave / nwaves));
+  const int i1 = __builtin_amdgcn_readfirstlane((int)((long)items * (wave + 1) / nwaves));
+  const unsigned lane8 = (unsigned)lane * (kSlots * 4);
+  const float lane2f = (float)(lane * kSlots);
+  float carry_l = 0.0f, carry_s = 0.0f, gacc = 0.0f;
+  int n = i0 / nseg, seg = i0 - n * nseg;            // the item being computed
+  int pn = n, pseg = seg;                            // the item being prefetched
+  auto advance = [&](int& nn, int& ss) {
+    ++ss;
+    if (ss == nseg) { ss = 0; ++nn; }
+  };
+  StreamGroup<NROWS> g[D + 1];
+  auto prefetch = [&](StreamGroup<NROWS>& grp) {
+    stream_issue<MIX, NROWS>(grp, a, r, min(pn, N - 1), pseg, lane8, HW);   // past the end: re-load the last plane (unused)
+    advance(pn, pseg);
+  };
+  auto step = [&](const StreamGroup<NROWS>& grp) {
+    const int2 sh = L.shift[n];
+    const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
+    const int kk = __builtin_amdgcn_readfirstlane(sh.y);
+    const int k = kk >> 1;
+    if (seg == 0) carry_l = carry_s = 0.0f;
+    if (kk & 1) {   // irregular plane (wave-uniform branch): exact per-lane floor, atomics into the zero-filled row
+#pragma unroll
+      for (int i = 0; i < kSlots; ++i) {
+        const float gd = stream_general_slot<MIX, NROWS>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
+        if (want_plane) gacc += gd;
+      }
+      carry_l = carry_s = 0.0f;
+    } else {
+      stream_compute<MIX, NROWS>(grp, a, o, r, L, n, seg, k, sd, lane, lane8, lane2f, HW, Wm1, rcpWm1, want_plane, gl_bytes,
+                                 gs_bytes, carry_l, carry_s, gacc);
+    }
+    advance(n, seg);
+    if (want_plane && (seg == 0)) {   // the plane's row is complete for this wave
+      const float v = wave_sum_hi(gacc);
+      if (lane == kWave - 1) lds_add(&L.red[n - 1], v);
+      gacc = 0.0f;
+    }
+  };
+  if (i0 < i1) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) prefetch(g[j]);
+    int it = i0;
+    for (; it + (D + 1) <= i1; it += D + 1) {
+#pragma unroll
+      for (int j = 0; j <= D; ++j) {
+        prefetch(g[(j + D) % (D + 1)]);
+        step(g[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+      if (it + j < i1) {
+        prefetch(g[(j + D) % (D + 1)]);
+        step(g[j]);
+      }
+    }
+    if (seg != 0) {   // the range ends inside a row: hand the carry over, flush the partial disparity sum
+      if (lane == 0) { L.hand[wave * 2] = carry_l; L.hand[wave * 2 + 1] = carry_s; }
+      if (want_plane) {
+        const float v = wave_sum_hi(gacc);
+        if (lane == kWave - 1) lds_add(&L.red[n], v);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  // (1) range boundaries inside a row: the first slot of the next wave's first segment lacks the carry
+  if (wave > 0 && i0 < i1 && lane == 0) {
+    const int ns = i0 / nseg, ss = i0 - ns * nseg;
+    if (ss != 0 && !(L.shift[ns].y & 1)) {
+      const float hl = L.hand[(wave - 1) * 2], hs = L.hand[(wave - 1) * 2 + 1];
+      const long at = ((long)r.b * N + ns) * HW + (long)r.y * W + ss * kSeg;
+      if (o.g_logits && hl != 0.0f) unsafeAtomicAdd(o.g_logits + at, hl);
+      if (MIX && o.g_sigma && hs != 0.0f) unsafeAtomicAdd(o.g_sigma + at, hs);
+    }
+  }
+  // (2) targets without a slot: x0 = -1 (negative shifts; their right tap is column 0) and, on irregular planes, the
+  //     neighbours of the row's ends whose floor(ix) lands inside after all.  One lane per (plane, virtual slot).
+  if (special) {
+    const int s_end = nseg * kSeg;
+    for (int j = threadIdx.x; j < 3 * N; j += blockDim.x) {
+      const int pn2 = j / 3, which = j - pn2 * 3;
+      const int2 sh = L.shift[pn2];
+      const int kk = sh.y, k = kk >> 1;
+      const bool irr = kk & 1;
+      const int xs = (which == 0) ? -1 : ((which == 1) ? -2 : s_end);
+      const bool on = (which == 0) || irr;
+      const float gd = stream_general_slot<MIX, NROWS>(a, o, r, L, pn2, xs, k, __int_as_float(sh.x), on, HW, Wm1, rcpWm1);
+      if (want_plane && gd != 0.0f) atomicAdd(&L.red[pn2], gd);
+    }
+    __syncthreads();
+  }
+  if (want_plane) {
+    const float gix_scale = (Wm1 / 2) * 2.0f / Wm1 * a.sign;  // d ix / d disp through un-normalise, *2, /(W-1)
+    if (a.flags & PD_DISP_ROWS) {  // one disparity per (plane, row): this workgroup owns the whole sum
+      for (int i = threadIdx.x; i < N; i += blockDim.x) o.g_plane[((long)r.b * N + i) * a.H + r.y] = L.red[i] * gix_scale;
+    } else {
+      float* dstp = o.partials + ((long)r.b * a.H + r.y) * N;
+      for (int i = threadIdx.x; i < N; i += blockDim.x) dstp[i] = L.red[i] * gix_scale;
+    }
+  }
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(512, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
+  extern __shared__ float4 lds4[];
+  StreamLds L;
+  const int nseg = (a.W + kSeg - 1) / kSeg;
+  L.CW = nseg * kSeg + 4;
+  L.ctx0 = lds4; L.ctx1 = lds4 + L.CW; L.ctx2 = lds4 + 2 * L.CW; L.col = lds4 + 3 * L.CW;
+  L.shift = reinterpret_cast<int2*>(lds4 + 4 * L.CW);
+  L.red = reinterpret_cast<float*>(L.shift + a.N);
+  L.hand = L.red + a.N;
+  L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
+  if (row.nrows == 2) stream_body<MIX, 2>(a, o, row, L);
+  else                stream_body<MIX, 1>(a, o, row, L);
+}
+
+__global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
+  const int j = blockIdx.x, b = blockIdx.y;   // partials [B][R][M] -> out [B][M]; lanes stride over R; deterministic
+  const float* p = partials + (long)b * R * M + j;
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < R; i += kWave) acc += p[(long)i * M];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[(long)b * M + j] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves) {
+  const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
+  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
+}
+static int rowstream_waves(const pd_sweep_desc* d) {
+  const int items = d->N * ceil_div(d->W, kSeg);
+  const int w = 8;   // 512 threads: two workgroups per CU at 192x640, one at 384x1280
+  return items < w ? items : w;
+}
+
+bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
+  return rowshift_applicable(d) && !(d->flags & PD_RENDER_PROB) && !a.has_mask && (d->W % 2 == 0) &&
+         rowstream_lds_bytes(d, rowstream_waves(d)) <= 160 * 1024;
+}
+
+size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
+
+int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
+  const int nwaves = rowstream_waves(d);
+  dim3 grid(d->H, d->B), block(nwaves * kWave);
+  const size_t shmem = rowstream_lds_bytes(d, nwaves);
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  if (mix) {
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    rowstream_bwd_kernel<true><<<grid, block, shmem, stream>>>(a, o);
+  } else {
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    rowstream_bwd_kernel<false><<<grid, block, shmem, stream>>>(a, o);
+  }
+  int rc = check_launch("rowstream_bwd_kernel");
+  if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
+  reduce_rows_stream_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);
+  return check_launch("reduce_rows_kernel");
+}
+
+}  // namespace pd

@@ -257,6 +257,11 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d);
 
+// Row-stream backward (pd_plane_sweep_rowstream.hip): lanes own aligned source slots, waves stream along plane rows.
+bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a);
+int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
+size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d);
+
 // Four-pixels-per-lane row kernels (pd_plane_sweep_rowquad.hip): same contract as the row-shift ones, wide memory accesses.
 bool rowquad_applicable(const pd_sweep_desc* d, bool dense_mask);
 int rowquad_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,

@@ -1,0 +1,215 @@
+// Probe for the source-ordered ("row-stream") backward: one wave walks a whole source row of one plane segment by
+// segment (no hand-over between waves), lanes own ALIGNED source slots, the per-target-pixel context comes out of LDS
+// at the plane's shift.  Measures what the traffic shape + LDS reads + K dummy VALU instructions per pixel and plane
+// cost, before the real kernel is written.
+//   P  = slots per lane (1: dword stores, 8-byte loads; 2: 8-byte stores, 12-byte loads; 4: 16-byte stores, 16+4-byte loads)
+//   D  = global-load prefetch depth in (plane, segment) iterations; the LDS reads run one iteration ahead
+//   K  = dummy VALU instructions per pixel and plane
+// hipcc --offload-arch=gfx950 -O3 scripts/probes/stream_probe.hip -o scripts/probes/stream_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+__device__ __forceinline__ Rsrc rsrc(const float* p, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000); }
+__device__ __forceinline__ float ld1(Rsrc r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); }
+__device__ __forceinline__ v2f ld2(Rsrc r, unsigned off) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
+__device__ __forceinline__ v3f ld3(Rsrc r, unsigned off) { return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, 0)); }
+__device__ __forceinline__ v4f ld4(Rsrc r, unsigned off) { return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
+__device__ __forceinline__ void st1(Rsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0); }
+__device__ __forceinline__ void st2(Rsrc r, unsigned off, v2f v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)off, 0, 0); }
+__device__ __forceinline__ void st4(Rsrc r, unsigned off, v4f v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); }
+
+template <int P> struct Glb { float a[P + 1], b[P + 1]; };
+template <int P> struct Lds { v4f c0[P], c1[P]; v2f c2[P]; v4f col[P + 1]; };
+
+template <int P> __device__ __forceinline__ void load_run(Rsrc r, unsigned off, float* v) {
+  if (P == 1) { const v2f a = ld2(r, off); v[0] = a.x; v[1] = a.y; }
+  if (P == 2) { const v3f a = ld3(r, off); v[0] = a.x; v[1] = a.y; v[2] = a.z; }
+  if (P == 4) { const v4f a = ld4(r, off); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = ld1(r, off + 16); }
+}
+template <int P> __device__ __forceinline__ void store_run(Rsrc r, unsigned off, const float* v) {
+  if (P == 1) st1(r, off, v[0]);
+  if (P == 2) st2(r, off, v2f{v[0], v[1]});
+  if (P == 4) st4(r, off, v4f{v[0], v[1], v[2], v[3]});
+}
+
+// K VALU instructions on the group's data (4 independent chains)
+template <int K> __device__ __forceinline__ float burn(float x0, float x1, float x2, float x3) {
+#pragma unroll
+  for (int i = 0; i < K / 4; ++i) { x0 = fmaf(x0, 1.0001f, x1); x1 = fmaf(x1, 0.9999f, x2); x2 = fmaf(x2, 1.0002f, x3); x3 = fmaf(x3, 0.9998f, x0); }
+  return x0 + x1 + x2 + x3;
+}
+
+template <int P, int D, int K, int MODE, int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void stream(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ GA,
+                                                 float* __restrict__ GB, const float* __restrict__ ctx_src, const int* __restrict__ kshift,
+                                                 float* __restrict__ out, int N, int H, int W, int Bn) {
+  extern __shared__ v4f lds[];
+  const int RS = W + 4;                 // ctx rows with guard cells
+  v4f* c0 = lds; v4f* c1 = lds + RS; v4f* col = lds + 2 * RS; v2f* c2 = reinterpret_cast<v2f*>(lds + 3 * RS);
+  const int id = blockIdx.x;            // row-major over images: rows of all images, image fastest
+  const int b = id % Bn, y = id / Bn;
+  const long HW = (long)H * W;
+  // stage: 13 floats per pixel from global (target, stash, rgb_rec, g_rgb in the real kernel)
+  for (int x = threadIdx.x; x < RS; x += blockDim.x) {
+    const int xi = x - 2;
+    v4f a = {0, 0, 0, 1e30f}, g = {0, 0, 0, 0}, cc = {0, 0, 0, 0}; v2f h = {0, 0};
+    if (xi >= 0 && xi < W) {
+      const float* p = ctx_src + ((long)b * 13) * HW + (long)y * W + xi;
+      a = v4f{p[0], p[HW], p[2 * HW], p[3 * HW]}; g = v4f{p[4 * HW], p[5 * HW], p[6 * HW], p[7 * HW]};
+      h = v2f{p[8 * HW], p[9 * HW]}; cc = v4f{p[10 * HW], p[11 * HW], p[12 * HW], 0};
+    }
+    c0[x] = a; c1[x] = g; c2[x] = h; col[x] = cc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = WAVES;
+  const int SEG = 64 * P, nseg = (W + SEG - 1) / SEG;
+  // this wave's share of the (plane, segment) list: a contiguous range, balanced to one item
+  const int items = N * nseg;
+  const int i0 = __builtin_amdgcn_readfirstlane(items * wave / nwaves), i1 = __builtin_amdgcn_readfirstlane(items * (wave + 1) / nwaves);
+  float acc = 0.f;
+  const float* Ab = A + (long)b * N * HW + (long)y * W; const float* Bb = Bt + (long)b * N * HW + (long)y * W;
+  float* GAb = GA + (long)b * N * HW + (long)y * W; float* GBb = GB + (long)b * N * HW + (long)y * W;
+  auto issue_g = [&](Glb<P>& g, int it_raw) {
+    const int it = min(it_raw, i1 - 1);
+    const int n = it / nseg, seg = it - n * nseg;
+    const int xs = seg * SEG + lane * P;
+    if (MODE & 1) {
+      load_run<P>(rsrc(Ab + (unsigned)(n * (int)HW), W * 4), xs * 4, g.a);
+      load_run<P>(rsrc(Bb + (unsigned)(n * (int)HW), W * 4), xs * 4, g.b);
+    } else {
+#pragma unroll
+      for (int i = 0; i <= P; ++i) { g.a[i] = 1.f + i; g.b[i] = 2.f + i; }
+    }
+  };
+  auto issue_l = [&](Lds<P>& g, int it_raw) {
+    const int it = min(it_raw, i1 - 1);
+    const int n = it / nseg, seg = it - n * nseg;
+    const int xs = seg * SEG + lane * P;
+    const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+    if (MODE & 4) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int xt = min(max(xs + i - k, -1), W) + 2;
+        g.c0[i] = c0[xt]; g.c1[i] = c1[xt]; g.c2[i] = c2[xt];
+      }
+#pragma unroll
+      for (int i = 0; i <= P; ++i) g.col[i] = col[min(xs + i, W) + 2];
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; ++i) { g.c0[i] = v4f{1, 2, 3, 4}; g.c1[i] = v4f{1, 2, 3, 4}; g.c2[i] = v2f{1, 2}; }
+#pragma unroll
+      for (int i = 0; i <= P; ++i) g.col[i] = v4f{1, 2, 3, 4};
+    }
+  };
+  float carry_a = 0.f, carry_b = 0.f;
+  auto compute = [&](const Glb<P>& g, const Lds<P>& c, int it) {
+    const int n = it / nseg, seg = it - n * nseg;
+    const int xs = seg * SEG + lane * P;
+    if (seg == 0) carry_a = carry_b = 0.f;
+    float oa[P], ob[P], la = 0.f, lb = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const float l = g.a[i] * 0.25f + g.a[i + 1] * 0.75f, s = g.b[i] * 0.25f + g.b[i + 1] * 0.75f;
+      const float cr = c.col[i].x * 0.25f + c.col[i + 1].x * 0.75f, cg = c.col[i].y * 0.25f + c.col[i + 1].y * 0.75f;
+      const float r = burn<K>(l + c.c0[i].x + c.c1[i].x, s + c.c0[i].y + c.c1[i].y + c.c2[i].x, cr + c.c0[i].z + c.c1[i].z, cg + c.c0[i].w + c.c1[i].w + c.c2[i].y);
+      const float c0v = r * 0.25f, c1v = r * 0.75f, d0v = r * 0.5f, d1v = r * 0.125f;
+      if (i == 0) { oa[0] = c0v; ob[0] = d0v; } else { oa[i] = c0v + la; ob[i] = d0v + lb; }
+      la = c1v; lb = d1v;
+      acc += r;
+    }
+    // lane's first slot also receives the previous lane's last right-hand contribution (lane 0: the carried one)
+    const float pa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_a), __float_as_int(la), 0x138, 0xF, 0xF, false));
+    const float pb = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_b), __float_as_int(lb), 0x138, 0xF, 0xF, false));
+    oa[0] += pa; ob[0] += pb;
+    carry_a = __builtin_amdgcn_readlane(la, 63); carry_b = __builtin_amdgcn_readlane(lb, 63);
+    if (MODE & 2) {
+      store_run<P>(rsrc(GAb + (unsigned)(n * (int)HW), W * 4), xs * 4, oa);
+      store_run<P>(rsrc(GBb + (unsigned)(n * (int)HW), W * 4), xs * 4, ob);
+    }
+  };
+  // software pipeline: global loads D iterations ahead (ring of D+1 register groups, statically indexed), LDS reads 1 ahead
+  Glb<P> g[D + 1];
+  Lds<P> c[2];
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue_g(g[j], i0 + j);
+  issue_l(c[0], i0);
+  int it = i0;
+  constexpr int UN = (D + 1) % 2 ? 2 * (D + 1) : (D + 1);   // unroll so that both rings are statically indexed
+  for (; it + UN <= i1; it += UN) {
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      issue_g(g[(j + D) % (D + 1)], it + j + D);
+      issue_l(c[(j + 1) & 1], it + j + 1);
+      compute(g[j % (D + 1)], c[j & 1], it + j);
+    }
+  }
+  // tail (fewer than UN iterations): same schedule with guards
+#pragma unroll
+  for (int j = 0; j < UN; ++j) {
+    if (it + j < i1) {
+      issue_g(g[(j + D) % (D + 1)], it + j + D);
+      issue_l(c[(j + 1) & 1], it + j + 1);
+      compute(g[j % (D + 1)], c[j & 1], it + j);
+    }
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
+
+__global__ void fill(float* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (float)(h & 0xFFFFFF) * (1.0f / 16777216.0f);
+  }
+}
+__global__ void fill_k(int* k, int n, int N, int W) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) k[i] = (int)(300.0f * (W / 640.0f) * powf(2.0f / 300.0f, (float)(i % N) / (N - 1))); }
+
+template <class F> static double time_ms(F f, int iters = 20) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters;
+}
+
+static float *A, *Bt, *GA, *GB, *out, *ctx; static int* ks;
+template <int P, int D, int K, int MODE, int WAVES = 4, int OCC = 4> static void run(int B, int N, int H, int W) {
+  const size_t ldsb = (size_t)(W + 4) * (3 * 16 + 8);
+  CK(hipFuncSetAttribute((const void*)stream<P, D, K, MODE, WAVES, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  const double ms = time_ms([&] { stream<P, D, K, MODE, WAVES, OCC><<<dim3(H * B), WAVES * 64, ldsb>>>(A, Bt, GA, GB, ctx, ks, out, N, H, W, B); });
+  CK(hipGetLastError());
+  const double bytes = (double)B * H * W * 4 * (((MODE & 1) ? 2 * N : 0) + ((MODE & 2) ? 2 * N : 0) + 13);
+  printf("W=%4d P=%d D=%d K=%3d waves=%d occ=%d %s%s%s  %7.3f ms  %7.1f GB/s\n", W, P, D, K, WAVES, OCC, (MODE & 1) ? "L" : "-", (MODE & 2) ? "S" : "-",
+         (MODE & 4) ? "C" : "-", ms, bytes / 1e9 / (ms * 1e-3));
+}
+
+int main() {
+  const int B = 8, N = 49, H = 192, W = 640;
+  const size_t n = (size_t)B * N * H * W;
+  CK(hipMalloc(&A, n * 4 + 4096)); CK(hipMalloc(&Bt, n * 4 + 4096)); CK(hipMalloc(&GA, n * 4 + 4096)); CK(hipMalloc(&GB, n * 4 + 4096));
+  CK(hipMalloc(&ctx, (size_t)B * 13 * H * W * 4)); CK(hipMalloc(&ks, B * N * 4)); CK(hipMalloc(&out, 64));
+  fill<<<4096, 256>>>(A, n, 1u); fill<<<4096, 256>>>(Bt, n, 7u); fill<<<1024, 256>>>(ctx, (size_t)B * 13 * H * W, 3u);
+  fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W);
+  CK(hipDeviceSynchronize());
+  printf("-- memory shape alone, by prefetch depth\n");
+  run<1, 1, 0, 3>(B, N, H, W); run<1, 2, 0, 3>(B, N, H, W); run<1, 4, 0, 3>(B, N, H, W);
+  run<2, 1, 0, 3>(B, N, H, W); run<2, 2, 0, 3>(B, N, H, W); run<2, 4, 0, 3>(B, N, H, W);
+  run<4, 1, 0, 3>(B, N, H, W); run<4, 2, 0, 3>(B, N, H, W); run<4, 4, 0, 3>(B, N, H, W);
+  printf("-- + LDS context + 80 VALU per pixel-plane, by prefetch depth\n");
+  run<1, 1, 80, 7>(B, N, H, W); run<1, 2, 80, 7>(B, N, H, W); run<1, 3, 80, 7>(B, N, H, W); run<1, 4, 80, 7>(B, N, H, W); run<1, 6, 80, 7>(B, N, H, W);
+  run<2, 1, 80, 7>(B, N, H, W); run<2, 2, 80, 7>(B, N, H, W); run<2, 3, 80, 7>(B, N, H, W); run<2, 4, 80, 7>(B, N, H, W);
+  run<4, 1, 80, 7>(B, N, H, W); run<4, 2, 80, 7>(B, N, H, W); run<4, 3, 80, 7>(B, N, H, W);
+  printf("-- 100 / 120 VALU\n");
+  run<1, 4, 100, 7>(B, N, H, W); run<1, 4, 120, 7>(B, N, H, W); run<2, 3, 100, 7>(B, N, H, W); run<2, 3, 120, 7>(B, N, H, W); run<4, 2, 100, 7>(B, N, H, W); run<4, 2, 120, 7>(B, N, H, W);
+  printf("-- occupancy / workgroup size\n");
+  run<1, 4, 100, 7, 4, 3>(B, N, H, W); run<2, 3, 100, 7, 4, 3>(B, N, H, W); run<2, 3, 100, 7, 4, 2>(B, N, H, W); run<4, 2, 100, 7, 4, 2>(B, N, H, W);
+  run<1, 4, 100, 7, 8, 4>(B, N, H, W); run<2, 3, 100, 7, 8, 4>(B, N, H, W); run<2, 3, 100, 7, 2, 4>(B, N, H, W);
+  printf("-- arithmetic + LDS alone\n");
+  run<1, 1, 80, 4>(B, N, H, W); run<1, 1, 100, 4>(B, N, H, W); run<1, 1, 120, 4>(B, N, H, W); run<2, 1, 100, 4>(B, N, H, W);
+  return 0;
+}
