@@ -40,7 +40,23 @@ namespace pd {
 #define PD_STREAM_D1 3   // prefetch depth in (plane, segment) iterations, one live source row
 #endif
 #ifndef PD_STREAM_D2
-#define PD_STREAM_D2 2   // two live source rows (twice the registers per group)
+#define PD_STREAM_D2 1   // two live source rows: twice the registers per group; depth 2 costs the third resident workgroup (90 vs 77 VGPRs)
+#endif
+#ifndef PD_STREAM_WAVES
+#define PD_STREAM_WAVES 8   // waves per row workgroup (512 threads: two workgroups per CU at 192x640, one at 384x1280)
+#endif
+#ifndef PD_STREAM_ABL
+#define PD_STREAM_ABL 0  // timing experiments only (wrong results): 1 no context reads, 2 no per-plane gradient math,
+#endif                   // 4 every row as one source row, 8 no gradient stores, 16 no coordinate chain
+constexpr int kStreamAbl = PD_STREAM_ABL;
+#ifndef PD_STREAM_STORE_AUX
+#define PD_STREAM_STORE_AUX 0   // cache-policy bits of the gradient stores (1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef PD_STREAM_LOAD_AUX
+#define PD_STREAM_LOAD_AUX 0    // same for the tap loads
+#endif
+#ifndef PD_STREAM_GENERAL_INLINE
+#define PD_STREAM_GENERAL_INLINE __forceinline__   // the rare general path: inline or a call (__noinline__)
 #endif
 #ifndef PD_STREAM_OCC
 #define PD_STREAM_OCC 4  // waves per SIMD the register allocator must leave room for
@@ -54,11 +70,11 @@ typedef float v3f __attribute__((ext_vector_type(3)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v3f buf_load3(Rsrc r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, PD_STREAM_LOAD_AUX));
 }
 __device__ __forceinline__ void buf_store2(Rsrc r, unsigned voff, unsigned soff, float x, float y) {
   __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, (int)voff,
-                                        (int)soff, 0);
+                                        (int)soff, PD_STREAM_STORE_AUX);
 }
 
 // frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
@@ -147,9 +163,10 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
   float cl0[kSlots], cl1[kSlots], cs0[kSlots], cs1[kSlots];
 #pragma unroll
   for (int i = 0; i < kSlots; ++i) {
-    const PixelCtx c = ctx_at(L, cell + i);
+    PixelCtx c;
+    if (kStreamAbl & 1) { c = zero_pixel_ctx(); c.t0 = lane2f; c.gr0 = sd; c.A = xs0f; } else c = ctx_at(L, cell + i);
     const float xsf = xs0f + (float)i;
-    const float ix = stream_ix(xt0f + (float)i, sd, Wm1, rcpWm1);
+    const float ix = (kStreamAbl & 16) ? xsf + 0.25f : stream_ix(xt0f + (float)i, sd, Wm1, rcpWm1);
     const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;   // torch's (x1 - ix), (ix - x0) with x0 = xs
     float l, s = 0.0f, dlx, dsx = 0.0f;
     if (NROWS == 1) {
@@ -170,7 +187,9 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
     }
     const float4 ca = (i == 0) ? cv0 : cv1, cb = (i == 0) ? cv1 : cv2;
     const float c0 = ca.x * w0 + cb.x * w1, c1 = ca.y * w0 + cb.y * w1, c2 = ca.z * w0 + cb.z * w1;
-    const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
+    PlaneGrad pg;
+    if (kStreamAbl & 2) { pg.g_l = l + c.t0; pg.g_s = s + c.gr0; pg.gc0 = c0 + c.A; pg.gc1 = c1; pg.gc2 = c2; }
+    else pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
     const float m0 = (NROWS == 1) ? w0 : w0 * r.wy, m1 = (NROWS == 1) ? w1 : w1 * r.wy;
     cl0[i] = pg.g_l * m0; cl1[i] = pg.g_l * m1;
     cs0[i] = pg.g_s * m0; cs1[i] = pg.g_s * m1;
@@ -182,11 +201,13 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
   const float out_l0 = cl0[0] + pl, out_l1 = cl0[1] + cl1[0];
   carry_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1[kSlots - 1]), kWave - 1));   // (an int builtin)
   const unsigned soff = (unsigned)seg * (kSeg * 4);
+  if (!(kStreamAbl & 8) || out_l0 == 123.456f)
   buf_store2(row_rsrc_bytes(plane_ptr(o.g_logits + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gl_bytes), lane8, soff, out_l0, out_l1);
   if (MIX) {
     const float ps = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_s), __float_as_int(cs1[kSlots - 1]), 0x138, 0xF, 0xF, false));
     const float out_s0 = cs0[0] + ps, out_s1 = cs0[1] + cs1[0];
     carry_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs1[kSlots - 1]), kWave - 1));
+    if (!(kStreamAbl & 8) || out_s0 == 123.456f)
     buf_store2(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gs_bytes), lane8, soff, out_s0, out_s1);
   }
 }
@@ -195,7 +216,7 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
 // floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
 // Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
 template <bool MIX, int NROWS>
-__device__ __forceinline__ float stream_general_slot(const SweepArgs& a, const BwdOut& o, const StreamRow& r,
+__device__ PD_STREAM_GENERAL_INLINE float stream_general_slot(const SweepArgs& a, const BwdOut& o, const StreamRow& r,
                                                      const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
                                                      float Wm1, float rcpWm1) {
   const int W = a.W;
@@ -416,7 +437,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
 }
 
 template <bool MIX>
-__global__ __launch_bounds__(512, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
+__global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   StreamLds L;
   const int nseg = (a.W + kSeg - 1) / kSeg;
@@ -427,8 +448,8 @@ __global__ __launch_bounds__(512, PD_STREAM_OCC) void rowstream_bwd_kernel(Sweep
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
   const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
-  if (row.nrows == 2) stream_body<MIX, 2>(a, o, row, L);
-  else                stream_body<MIX, 1>(a, o, row, L);
+  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2>(a, o, row, L);
+  else                                     stream_body<MIX, 1>(a, o, row, L);
 }
 
 __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
@@ -449,7 +470,9 @@ static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves) {
 }
 static int rowstream_waves(const pd_sweep_desc* d) {
   const int items = d->N * ceil_div(d->W, kSeg);
-  const int w = 8;   // 512 threads: two workgroups per CU at 192x640, one at 384x1280
+  // 8 waves per row workgroup while three of them fit a CU's LDS (W <= ~800: 24 waves per CU at the kernel's 77 VGPRs);
+  // wider rows stage more context per workgroup, so they get 16 waves to keep the CU's wave slots filled
+  const int w = rowstream_lds_bytes(d, PD_STREAM_WAVES) * 3 <= 160 * 1024 ? PD_STREAM_WAVES : 2 * PD_STREAM_WAVES;
   return items < w ? items : w;
 }
 

@@ -185,6 +185,67 @@ def test_rowshift_kernels_vs_general_kernels_and_oracle(W, side, disps):
         assert rel_err(fast[k], slow[k]) < 3e-5, (k, rel_err(fast[k], slow[k]))
 
 
+def _stream_tol(W):
+    """pd_plane_sweep_rowstream.hip irregular_tol(W): closer than this to an integer, a shift takes the general path."""
+    return 2.5e-4 + 1.25e-6 * W
+
+
+@pytest.mark.parametrize("W,H,N,side,mix,kw", [
+    # shifts on both sides of the regular / irregular threshold around several integers, and exact integers
+    (640, 6, 12, "r", True, "threshold"),
+    (130, 7, 12, "l", True, "threshold"),
+    (1280, 4, 12, "r", True, "threshold"),
+    # ragged widths: one partial segment, W < one segment, the smallest even width, a width that is not even (falls
+    # back to the row-shift backward)
+    (258, 9, 7, "r", True, dict(disp_min=0.5, disp_max=120.0)),
+    (70, 5, 5, "l", True, dict(disp_min=0.3, disp_max=40.0)),
+    (2, 3, 2, "r", True, dict(disp_min=0.2, disp_max=1.5)),
+    (257, 5, 5, "l", True, dict(disp_min=0.5, disp_max=80.0)),
+    # more items than waves / fewer items than waves, L1 loss, per-row disparities with a horizon mask
+    (640, 3, 1, "r", True, dict(disp_min=5.0, disp_max=5.0)),
+    (130, 3, 2, "r", True, dict(special_disp=[5.0, 9.3], disp_min=0.5, disp_max=9.0)),
+    (384, 8, 63, "r", False, dict(disp_min=0.5, disp_max=200.0)),
+    (200, 33, 12, "r", True, dict(disp_min=0.5, disp_max=60.0, n_xz=4)),
+    (200, 33, 12, "l", False, dict(disp_min=0.5, disp_max=60.0, n_xz=4)),
+])
+def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, mix, kw):
+    """The row-stream backward (pd_plane_sweep_rowstream.hip: lanes own aligned source slots, default) against the
+    target-ordered row-shift backward (PD_IMPL_ROWS1) on the same forward, and against the fp32 oracle: shifts just inside
+    and just outside the threshold that sends a plane down the general path, exact integers, both signs (negative shifts:
+    the targets whose left tap is column -1 come from the epilogue), ragged and tiny widths, range boundaries of the
+    waves inside a row (N * segments not a multiple of the wave count)."""
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    if kw == "threshold":
+        t = _stream_tol(W)
+        ks = [1.0, 7.0, 64.0, float(W // 2)]
+        disps = [ks[0], ks[0] + 0.9 * t, ks[0] + 1.1 * t, ks[1] - 0.9 * t, ks[1] - 1.1 * t, ks[1] + 0.5,
+                 ks[2], ks[2] + 1.1 * t, ks[2] - 1.1 * t, ks[3] + 0.9 * t, ks[3] - 0.9 * t, float(W + 3)]
+        kw = dict(special_disp=disps[:N], disp_min=0.5, disp_max=9.0)
+    kw = dict(kw)
+    case = build_case(B=2, N=N, H=H, W=W, seed=5000 + W + H, sigma_interior=True, **kw)
+    run = dict(target_side=side, use_mixture_loss=mix, automask=True)
+    extra = dict(yz_levels=0, xz_levels=kw.get("n_xz", 0))
+    new = run_product(case, run, opt_extra=extra)
+    ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
+    try:
+        old = run_product(case, run, opt_extra=extra)
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    want = run_oracle(case, run)
+    # same closed form, same coordinates: what differs is the summation order of the four taps / of g_disp.  zero_floor:
+    # with one plane pi = 1 and g_logits is rounding noise around an exact zero
+    zf = 1e-6 if N == 1 else 0.0
+    if N > 1:   # (one plane: pi = 1 exactly, every gradient through the softmax is cancellation noise — each kernel family
+        # then sits 5e-5 from the oracle in its own way; the oracle comparison below is the check)
+        _compare(new, {k: old[k] for k in ("g_logits", "g_sigma")}, tag="stream-vs-shift/W%d" % W, tol=3e-6)
+        _compare(new, {"g_disp_pp": old["g_disp_pp"]}, tag="stream-vs-shift/W%d" % W, tol=5e-5)
+    _compare(new, {k: want[k] for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma")}, tag="rowstream/W%d" % W, zero_floor=zf)
+    _compare(new, {"g_disp_pp": want["g_disp_pp"]}, tag="rowstream/W%d" % W, tol=2e-4)
+
+
 @pytest.mark.parametrize("name", ["disp_mix_xz", "disp_mix_r", "disp_mix_automask", "disp_mix_integer_d"])
 def test_per_row_disparities_use_the_rowshift_kernels(name):
     """opt.yz_levels == 0 promises row-uniform disparity maps: dense maps (xz planes, horizon mask) then go through the
