@@ -13,7 +13,9 @@
  *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous;
  *   - every function returns PD_OK (0) or a PD_ERR_* code; pd_last_error() returns a
  *     thread-local human-readable message for the last non-zero return on this thread;
- *   - no global mutable state: safe to call from any thread (e.g. the autograd thread).
+ *   - no global mutable state: safe to call from any thread (e.g. the autograd thread).  The few process-environment
+ *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS) are read ONCE, when the library is first
+ *     used, never on the launch path; kernel selection per call goes through pd_sweep_desc.impl.
  */
 #ifndef PLANEDEPTH_HIP_H
 #define PLANEDEPTH_HIP_H
@@ -70,23 +72,29 @@ enum pd_sweep_flags {
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
 
-/* Kernel selection.  The row-shift kernels apply to PD_WARP_DISP with per-plane scalar disparities; the general
+/* Kernel selection.  The row kernels apply to PD_WARP_DISP with per-plane or per-row disparities (forward:
+ * pd_plane_sweep_rowshift.hip, target-ordered; backward: pd_plane_sweep_rowstream.hip, source-ordered); the general
  * kernels handle everything (and are the cross-check for the specialised ones in the tests). */
 enum pd_sweep_impl {
-  PD_IMPL_AUTO = 0,      /* row-shift kernels where they apply, exact footprints (default) */
+  PD_IMPL_AUTO = 0,      /* row kernels where they apply, exact footprints (default) */
   PD_IMPL_GENERAL = 1,   /* general kernels only (the cross-check in the tests) */
   PD_IMPL_FAST_ROWS = 2  /* as AUTO, but a second source row whose bilinear weight is below 2^-16 (fp32 noise of the
                             reference's y round trip, <= 6e-6) is dropped: ~11% faster, results within 1e-4 of the
                             tensors' range on random inputs instead of 1e-6 (opt-in) */
   ,
-  PD_IMPL_TILE = 3       /* as GENERAL, and homography_warp's backward runs the owned-tile kernel (pd_plane_sweep_tile.hip:
+  PD_IMPL_TILE = 3       /* EXPERIMENTS BUILD ONLY (-DPD_EXPERIMENTS, pd_experiments() == 1; otherwise PD_ERR_UNSUPPORTED):
+                            as GENERAL, and homography_warp's backward runs the owned-tile kernel (pd_plane_sweep_tile.hip:
                             LDS accumulators per source tile, plain stores, no zero-fill) instead of the atomic scatter.
                             Exact and atomic-free in HBM, but 2-2.5x SLOWER on gfx950 (ds_add_f32 costs ~110 cycles per
                             wave instruction: DESIGN.md 3.4.6) - kept as an in-suite cross-check and as the record of
                             that measurement */
   ,
-  PD_IMPL_ROWS1 = 4      /* as AUTO, but the row kernels with ONE pixel per lane (pd_plane_sweep_rowshift.hip, the round-1
-                            headline kernels) instead of the four-pixels-per-lane ones: cross-check and A/B runs */
+  PD_IMPL_ROWS1 = 4      /* as AUTO, but the backward is the target-ordered row-shift kernel (pd_plane_sweep_rowshift.hip,
+                            one pixel per lane, the headline backward of rounds 1-2) instead of the source-ordered
+                            row-stream kernel (pd_plane_sweep_rowstream.hip): cross-check and A/B runs */
+  ,
+  PD_IMPL_UNIFORM_DIRECT = 5 /* as AUTO, but pass 2 of the plane-uniform backward gathers directly from the scratch instead
+                            of staging it through LDS (the form large rotations fall back to anyway): cross-check */
 };
 
 typedef struct pd_sweep_desc {
@@ -99,6 +107,10 @@ typedef struct pd_sweep_desc {
 
 int pd_version(void);
 const char* pd_last_error(void);
+/* 1 if the library was built with -DPD_EXPERIMENTS: the kernels measured SLOWER than the defaults (four-pixels-per-lane
+ * row kernels, owned-tile backward, one-kernel plane-uniform backward) are then compiled in and selectable
+ * (PD_IMPL_TILE; PD_QUAD_FWD / PD_QUAD_BWD / PD_UNI_FUSED in the environment).  The product library returns 0. */
+int pd_experiments(void);
 
 /* 1 if this descriptor is served by the row-shift kernels (PD_WARP_DISP, scalar or per-row disparities), else 0. */
 /* 1 if pd_plane_sweep_bwd honours PD_BWD_ACCUMULATE for this descriptor (see the flag), else 0. */
@@ -341,12 +353,9 @@ int pd_grid_sample_bwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding
  * Diagnostics (used by tests/ and scripts/, not by the product path).
  *   pd_selftest_division        counts, over `count` samples lo + i*step, where the row kernels' fast division by W-1
  *                               (refined reciprocal) differs from the IEEE quotient; *d_mismatches (device int) += count.
- *   pd_debug_rowquad_occupancy  out[0], out[1] = resident workgroups per CU of the opt-in row-quad forward / backward
- *                               kernels for a row of W pixels and N planes (hipOccupancyMaxActiveBlocksPerMultiprocessor).
  *   pd_debug_poison_lds, pd_debug_count_lds_nans   see below (PD_DEBUG_POISON_LDS=1 makes the Python layer poison before every launch).
  */
 int pd_selftest_division(float Wm1, int count, float lo, float step, int* d_mismatches, pd_stream_t stream);
-int pd_debug_rowquad_occupancy(int W, int N, int* out);
 /* Fills the LDS of the device's CUs with NaNs (a kernel that reads shared memory it never wrote then yields NaNs). */
 int pd_debug_poison_lds(pd_stream_t stream);
 /* *d_count += the NaNs 2048 workgroups find in 32 KB of shared memory they never wrote (checks that the poison sticks). */

@@ -18,7 +18,7 @@ PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
 PD_HMAT_PLANES, PD_HMAT_UNIFORM, PD_HMAT_STEREO_ROWS = 0, 1, 2
-PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1 = 0, 1, 2, 3, 4
+PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1, PD_IMPL_UNIFORM_DIRECT = 0, 1, 2, 3, 4, 5
 
 
 class SweepDesc(ctypes.Structure):
@@ -62,7 +62,7 @@ SIGNATURES = {
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
     "pd_selftest_division": (_I, [_F, _I, _F, _F, _P, _P]),
-    "pd_debug_rowquad_occupancy": (_I, [_I, _I, _P]),
+    "pd_experiments": (_I, []),
     "pd_debug_poison_lds": (_I, [_P]),
     "pd_debug_count_lds_nans": (_I, [_P, _P]),
     "pd_masked_photometric_fwd": (_I, [_I] * 4 + [_P] * 9),

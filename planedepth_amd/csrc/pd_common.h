@@ -15,6 +15,17 @@ constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Process-environment tuning / A-B switches.  They are read ONCE, when the library is first used (pd_version() or the
+// first launch), never on the launch path: an entry point's behaviour cannot change between two calls of a process, and
+// workspace sizing and launch always agree.  Kernel selection that tests need per call goes through pd_sweep_desc.impl.
+struct Switches {
+  bool no_rowpair;    // PD_NO_ROWPAIR=1: forward without row pairs
+  bool pp_rows_off;   // PD_PP_ROWS=0: post-process kernels in per-pixel gather form
+  int row_waves;      // PD_ROW_WAVES=n: waves per row workgroup of the row-shift kernels (0 = default)
+  int uni_chunk;      // PD_UNI_CHUNK=n: images per launch of the plane-uniform backward passes (0 = whole batch)
+};
+const Switches& switches();
+
 #define PD_REQUIRE(cond, ...)        \
   do {                               \
     if (!(cond)) {                   \

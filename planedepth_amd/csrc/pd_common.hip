@@ -1,5 +1,6 @@
 // Host-side plumbing shared by every entry point: thread-local error text, launch check, version.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "pd_common.h"
 
@@ -14,6 +15,19 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+const Switches& switches() {
+  static const Switches sw = [] {   // C++11: initialised once, thread-safe
+    Switches v;
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
+    v.no_rowpair = getenv("PD_NO_ROWPAIR") != nullptr;
+    v.pp_rows_off = num("PD_PP_ROWS") == 0;
+    v.row_waves = num("PD_ROW_WAVES") > 0 ? num("PD_ROW_WAVES") : 0;
+    v.uni_chunk = num("PD_UNI_CHUNK") > 0 ? num("PD_UNI_CHUNK") : 0;
+    return v;
+  }();
+  return sw;
+}
+
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess) return PD_OK;
@@ -23,7 +37,14 @@ int check_launch(const char* what) {
 
 }  // namespace pd
 
-extern "C" int pd_version(void) { return 200; /* 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
+extern "C" int pd_experiments(void) {
+#ifdef PD_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+extern "C" int pd_version(void) { (void)pd::switches(); return 210; /* 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
 
 // Diagnostics: fill the LDS of (as good as) every CU with NaNs, so that a kernel that reads shared memory it never wrote

@@ -418,7 +418,7 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   // row pairs need one scalar disparity per plane (the sampling column is then the same in both rows) and no per-pixel
   // or per-row mask; PD_NO_ROWPAIR=1 (environment) switches them off for A/B runs
   a.pairs = (d->mode == PD_WARP_DISP && !(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS | PD_MASK_ROWS | PD_RENDER_PROB)) &&
-             padding_mask == nullptr && !a.fast_rows && !getenv("PD_NO_ROWPAIR")) ? 1 : 0;
+             padding_mask == nullptr && !a.fast_rows && !switches().no_rowpair) ? 1 : 0;
   a.has_mask = (d->mode == PD_WARP_DISP && padding_mask != nullptr && !mask_rows) ? 1 : 0;
   a.src = src; a.tgt = tgt; a.logits = logits; a.sigma = sigma;
   a.plane = plane; a.plane_aux = plane_aux; a.inv_K3 = inv_K3;
@@ -431,7 +431,7 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
 }
 
 static bool wants_rowshift(const pd_sweep_desc* d) {
-  return d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_ROWS1;
+  return d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_ROWS1 || d->impl == PD_IMPL_UNIFORM_DIRECT;
 }
 
 extern "C" int pd_sweep_uses_rowshift(const pd_sweep_desc* d) {
@@ -442,7 +442,10 @@ extern "C" int pd_sweep_bwd_accumulates(const pd_sweep_desc* d) {
   if (!d) return 0;
   if (wants_rowshift(d) && rowshift_applicable(d)) return 0;   // owner-computes ring stores: no read-modify-write form
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) return 1;
-  return tile_bwd_applicable(d) ? 0 : 1;                       // the atomic scatter accumulates by nature
+#ifdef PD_EXPERIMENTS
+  if (tile_bwd_applicable(d)) return 0;
+#endif
+  return 1;                                                    // the atomic scatter accumulates by nature
 }
 
 extern "C" size_t pd_sweep_stash_floats(const pd_sweep_desc* d) {
@@ -459,7 +462,11 @@ extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   const size_t K = (d->mode == PD_WARP_DISP) ? 1 : 9;
   const size_t general = (size_t)d->B * bwd_blocks(d->H * d->W) * d->N * K;
   const size_t rows = rowshift_applicable(d) ? rowshift_bwd_workspace_floats(d) : 0;
+#ifdef PD_EXPERIMENTS
   const size_t tiles = tile_bwd_applicable(d) ? tile_bwd_workspace_floats(d) : 0;
+#else
+  const size_t tiles = 0;
+#endif
   const size_t uni = (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) ? uniform_bwd_workspace_floats(d) : 0;
   size_t m = general > rows ? general : rows;
   m = m > tiles ? m : tiles;
@@ -492,12 +499,10 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
     if (hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
   }
   if (wants_rowshift(d) && rowshift_applicable(d)) {
-    // The wide-access kernels (2 / 4 pixels per lane) are correct (tests/test_gpu_parity.py::test_rowquad_*) and their
-    // forward is faster in an isolated launch loop (0.109 vs 0.127 ms), but INSIDE the training step it is slower
-    // (0.149 vs 0.132 ms, 300-step A/B on one box: 20.9 k vs 21.4 k images/s): without row pairs it re-reads 10 % more
-    // while the memory system is still draining the backward's gradient writes.  Opt-in: PD_QUAD_FWD / PD_QUAD_BWD.
+#ifdef PD_EXPERIMENTS   // wide-access forward (2 / 4 pixels per lane): faster isolated, slower inside the step
     if (rowquad_applicable(d, a.has_mask != 0) && getenv("PD_QUAD_FWD"))
       return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
+#endif
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
   }
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM))
@@ -520,7 +525,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   const bool dense = (d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)) != 0;
   PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
-  PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_ROWS1, "unknown impl %d", d->impl);
+  PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_UNIFORM_DIRECT, "unknown impl %d", d->impl);
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   const bool accumulate = (d->flags & PD_BWD_ACCUMULATE) != 0;
@@ -533,21 +538,29 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
   if (wants_rowshift(d) && rowshift_applicable(d)) {
     PD_REQUIRE(workspace, "the row-shift backward needs workspace (pd_sweep_bwd_workspace_floats)");
-    // same VALU work per pixel as the one-pixel-per-lane backward (which is VALU-bound), lower occupancy: slower. Opt-in.
+#ifdef PD_EXPERIMENTS
     if (rowquad_applicable(d, ak.has_mask != 0) && getenv("PD_QUAD_BWD")) return rowquad_bwd(d, ak, o, stream);
+#endif
     // default: lanes own aligned source slots, waves stream along plane rows (pd_plane_sweep_rowstream.hip);
     // PD_IMPL_ROWS1 keeps the target-ordered row-shift backward (cross-check, A/B)
-    if (d->impl != PD_IMPL_ROWS1 && rowstream_bwd_applicable(d, ak) && !getenv("PD_NO_ROWSTREAM")) return rowstream_bwd(d, ak, o, stream);
+    if (d->impl != PD_IMPL_ROWS1 && rowstream_bwd_applicable(d, ak)) return rowstream_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
   }
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) {
     PD_REQUIRE(workspace, "the plane-uniform backward needs workspace (pd_sweep_bwd_workspace_floats)");
     return uniform_bwd(d, ak, o, workspace, stream);
   }
+#ifdef PD_EXPERIMENTS
   if (tile_bwd_applicable(d)) {   // PD_IMPL_TILE: source tiles owned by workgroups, no atomics, no zero-fill
     PD_REQUIRE(workspace, "the tile backward needs workspace (pd_sweep_bwd_workspace_floats)");
     return tile_bwd(d, ak, o, workspace, stream);
   }
+#else
+  if (d->impl == PD_IMPL_TILE) {
+    set_error("PD_IMPL_TILE (the owned-tile backward) is built with -DPD_EXPERIMENTS only: it is slower than the default kernels");
+    return PD_ERR_UNSUPPORTED;
+  }
+#endif
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;
   dim3 grid(bwd_blocks(HW), d->B);

@@ -17,6 +17,7 @@
 // frac(sign * d) is within ~1e-4 of an integer, so "pixel i of the lane taps column x0 + i" is CHECKED per wave and plane
 // (a vote); waves where it fails (and the one wave per plane that straddles the left image border when sign < 0) run
 // that plane through per-pixel loads and an LDS routing buffer — the general path, rare by construction.
+#ifdef PD_EXPERIMENTS   // measured slower than the default kernels: built with -DPD_EXPERIMENTS only (scripts/build_variants.sh)
 #include "pd_rowshift_common.h"
 
 namespace pd {
@@ -910,3 +911,5 @@ extern "C" int pd_debug_rowquad_occupancy(int W, int N, int* out) {
   out[0] = nf; out[1] = nb; out[2] = bf; out[3] = bb;
   return 0;
 }
+
+#endif  // PD_EXPERIMENTS

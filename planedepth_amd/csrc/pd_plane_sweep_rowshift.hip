@@ -911,8 +911,7 @@ __global__ void div_check_kernel(float Wm1, int count, float lo, float step, int
 // Waves per row-workgroup (each wave walks its share of the row's 64-lane segments).
 static int row_threads(int W) {
   const int nseg = ceil_div(W, kWave);
-  if (const char* e = getenv("PD_ROW_WAVES")) {  // tuning hook
-    const int w = atoi(e);
+  if (const int w = switches().row_waves) {  // tuning hook (PD_ROW_WAVES, read once)
     if (w >= 1 && w <= kRowThreadsMax / kWave) return (w < nseg ? w : nseg) * kWave;   // the kernels' launch bound
   }
   // Measured on MI355X (W=640, 10 segments): 4, 5, 8 and 10 waves per workgroup are within 3% of each other, 1-2

@@ -25,6 +25,7 @@
 // The gradient of the homography entries is accumulated per thread over the pixels whose (clamped) top-left tap lies
 // in the tile — a unique owner per target pixel and plane — reduced per workgroup and plane, and finished by the
 // deterministic second-stage reduction the other kernels use.
+#ifdef PD_EXPERIMENTS   // measured slower than the default kernels: built with -DPD_EXPERIMENTS only (scripts/build_variants.sh)
 #include "pd_sweep_geom.h"
 
 namespace pd {
@@ -312,3 +313,5 @@ int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float*
 }
 
 }  // namespace pd
+
+#endif  // PD_EXPERIMENTS

@@ -643,6 +643,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
 // The kernel serves the regular case only (box <= 1024 pixels, gather lists <= 12 entries).  A
 // workgroup that meets anything else raises a device flag; the two-pass kernels, launched behind it, return at once
 // unless that flag is set and otherwise recompute the whole launch (large rotations, zooms: rare, exact either way).
+#ifdef PD_EXPERIMENTS   // measured slower than the two-pass form: not in the product library
 #ifndef PD_FUSE_K
 #define PD_FUSE_K 12
 #endif
@@ -821,6 +822,8 @@ __global__ __launch_bounds__(kFuseThreads) void uniform_bwd_fused_kernel(SweepAr
   }
 }
 
+#endif  // PD_EXPERIMENTS
+
 // partial sums of the kernels that ran: the fused kernel's unless it raised the flag
 __global__ void uniform_reduce_kernel(const float* __restrict__ part_fused, int nblk_fused, const float* __restrict__ part_two,
                                       int nblk_two, const int* __restrict__ irregular_flag, float* __restrict__ out, int M) {
@@ -842,10 +845,7 @@ static size_t ualign4(size_t floats) { return (floats + 3) & ~(size_t)3; }
 // images per launch of the two backward passes: enough workgroups to fill the chip, a scratch that still fits the
 // 256 MB memory-side cache (2 x N x H x W floats per image)
 static int uniform_chunk(const pd_sweep_desc* d) {
-  if (const char* e = getenv("PD_UNI_CHUNK")) {
-    const int c = atoi(e);
-    if (c >= 1) return c < d->B ? c : d->B;
-  }
+  if (const int c = switches().uni_chunk) return c < d->B ? c : d->B;   // PD_UNI_CHUNK, read once
   const size_t per_image = (size_t)2 * d->N * d->H * d->W * sizeof(float);
   (void)per_image;   // measured at 8x49x192x640: 1 / 2 / 4 / 8 images per launch -> 2.16 / 1.83 / 1.42 / 0.99 ms: parallelism
   return d->B;        // beats cache residency, so the whole batch goes in one launch per pass
@@ -888,14 +888,24 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
   const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
   const bool render = (d->flags & PD_RENDER_PROB) != 0;
-  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !render;
+#ifdef PD_EXPERIMENTS
+  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !render;   // experiments build only
+#else
+  const bool fused = false;
+#endif
+#ifdef PD_EXPERIMENTS
   const int tiles_x = ceil_div(d->W, kFuseC), ntiles = tiles_x * ceil_div(d->H, kFuseR);
+#else
+  const int ntiles = 0;
+#endif
+#ifdef PD_EXPERIMENTS
   if (!rc && fused) {   // regular case: per-plane gradients handed over through LDS
     dim3 grid(ntiles, d->B);
     if (mix) uniform_bwd_fused_kernel<true><<<grid, kFuseThreads, 0, stream>>>(ak, o, prep, part_fused, tw, tiles_x, irregular);
     else     uniform_bwd_fused_kernel<false><<<grid, kFuseThreads, 0, stream>>>(ak, o, prep, part_fused, tw, tiles_x, irregular);
     rc = check_launch("uniform_bwd_fused_kernel");
   }
+#endif
   const int* run_flag = fused ? irregular : nullptr;   // the two-pass kernels return at once unless the fused one gave up
   const int chunk = uniform_chunk(d);
   for (int b0 = 0; b0 < d->B && !rc; b0 += chunk) {
@@ -904,8 +914,8 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
     const int stiles_x = ceil_div(d->W, kStageW);
     dim3 sgrid(stiles_x * ceil_div(d->H, kStageH), nb);
     // pass 2 with the scratch staged through LDS unless the fused kernel is selected (its run_flag protocol belongs to
-    // the direct-gather kernel) or PD_UNI_DIRECT asks for the direct gather
-    const bool staged = !fused && !getenv("PD_UNI_DIRECT");
+    // the direct-gather kernel) or PD_IMPL_UNIFORM_DIRECT asks for the direct gather (cross-check)
+    const bool staged = !fused && d->impl != PD_IMPL_UNIFORM_DIRECT;
     if (mix) {
       if (render) uniform_bwd_pass1_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       else        uniform_bwd_pass1_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);

@@ -276,8 +276,7 @@ __global__ __launch_bounds__(kWave) void warp_sum_rows_kernel(WarpArgs a, float 
 
 // the row kernels need 32-bit byte offsets inside a row and grid dimensions within the launch limits
 static bool rows_applicable(const WarpArgs& a, int B) {
-  static const bool off = getenv("PD_PP_ROWS") && atoi(getenv("PD_PP_ROWS")) == 0;   // A/B hook
-  return !off && !a.dense && a.H <= 65535 && B <= 65535 && a.W <= (1 << 24);
+  return !switches().pp_rows_off && !a.dense && a.H <= 65535 && B <= 65535 && a.W <= (1 << 24);
 }
 
 static int warp_args(WarpArgs& a, int B, int N, int H, int W, float sign, int flags, const float* planes,

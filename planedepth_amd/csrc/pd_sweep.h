@@ -262,6 +262,7 @@ bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a);
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d);
 
+#ifdef PD_EXPERIMENTS
 // Four-pixels-per-lane row kernels (pd_plane_sweep_rowquad.hip): same contract as the row-shift ones, wide memory accesses.
 bool rowquad_applicable(const pd_sweep_desc* d, bool dense_mask);
 int rowquad_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
@@ -273,6 +274,7 @@ size_t rowquad_bwd_workspace_floats(const pd_sweep_desc* d);
 bool tile_bwd_applicable(const pd_sweep_desc* d);
 size_t tile_bwd_workspace_floats(const pd_sweep_desc* d);
 int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+#endif  // PD_EXPERIMENTS
 // Plane-uniform homography (pd_plane_sweep_uniform.hip, PD_HOMO_UNIFORM)
 int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
 int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);

@@ -185,6 +185,14 @@ def test_rowshift_kernels_vs_general_kernels_and_oracle(W, side, disps):
         assert rel_err(fast[k], slow[k]) < 3e-5, (k, rel_err(fast[k], slow[k]))
 
 
+def _need_experiments():
+    """The kernels that lost their A/B runs (row-quad, owned-tile, one-kernel plane-uniform backward) are compiled with
+    -DPD_EXPERIMENTS only (scripts/build_variants.sh); the product library does not carry them."""
+    from planedepth_amd import _capi as C
+    if not C.load().pd_experiments():
+        pytest.skip("built without -DPD_EXPERIMENTS: this kernel is not part of the product library")
+
+
 def _stream_tol(W):
     """pd_plane_sweep_rowstream.hip irregular_tol(W): closer than this to an integer, a shift takes the general path."""
     return 2.5e-4 + 1.25e-6 * W
@@ -201,6 +209,13 @@ def _stream_tol(W):
     (70, 5, 5, "l", True, dict(disp_min=0.3, disp_max=40.0)),
     (2, 3, 2, "r", True, dict(disp_min=0.2, disp_max=1.5)),
     (257, 5, 5, "l", True, dict(disp_min=0.5, disp_max=80.0)),
+    # the shapes the row-quad experiments were checked on: whole and ragged segments, both signs, integer and
+    # almost-integer shifts, shifts beyond the row
+    (640, 12, 9, "r", True, dict(disp_min=2.0, disp_max=300.0)),
+    (70, 11, 10, "r", True, dict(special_disp=[0.0, 1.0, 2.0, 1.9999999, 3.0000002, 7.5, 68.9999, 69.0, 75.0, 1e6], disp_min=0.5, disp_max=9.0)),
+    (130, 7, 9, "l", True, dict(special_disp=[0.25, 1.0, 63.0, 64.0, 64.00001, 65.5, 127.99999, 129.0, 200.0], disp_min=0.5, disp_max=9.0)),
+    (300, 8, 8, "r", False, dict(special_disp=[299.99997, 2.0000002, 1.9999998, 0.99999994, 100.0, 33.333332, 255.0, 256.00003], disp_min=0.5, disp_max=9.0)),
+    (1280, 6, 4, "r", True, dict(disp_min=2.0, disp_max=300.0)),
     # more items than waves / fewer items than waves, L1 loss, per-row disparities with a horizon mask
     (640, 3, 1, "r", True, dict(disp_min=5.0, disp_max=5.0)),
     (130, 3, 2, "r", True, dict(special_disp=[5.0, 9.3], disp_min=0.5, disp_max=9.0)),
@@ -226,7 +241,7 @@ def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, m
         kw = dict(special_disp=disps[:N], disp_min=0.5, disp_max=9.0)
     kw = dict(kw)
     case = build_case(B=2, N=N, H=H, W=W, seed=5000 + W + H, sigma_interior=True, **kw)
-    run = dict(target_side=side, use_mixture_loss=mix, automask=True)
+    run = dict(target_side=side, use_mixture_loss=mix, automask=0.0 not in kw.get("special_disp", ()))   # knife edge (d)
     extra = dict(yz_levels=0, xz_levels=kw.get("n_xz", 0))
     new = run_product(case, run, opt_extra=extra)
     ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
@@ -1326,6 +1341,7 @@ def test_tile_backward_equals_atomic_backward(B, N, H, W, mix):
     against the atomic scatter on homographies far from the identity (rotation, zoom, shear, perspective, large shifts,
     planes facing away), ragged sizes (W not a multiple of 4 or 64, images smaller than one tile).  Two independent
     adjoints of the same gather: they must agree to summation order."""
+    _need_experiments()
     from planedepth_amd import _capi as C
     from planedepth_amd import ops
     from planedepth_amd.synthetic import intrinsics
@@ -1375,6 +1391,7 @@ def test_rowquad_kernels_equal_rowshift_kernels(W, H, N, side, kw, mix, automask
     """The four-pixels-per-lane kernels (pd_plane_sweep_rowquad.hip: 16-byte loads and stores) against the
     one-pixel-per-lane row-shift kernels (PD_IMPL_ROWS1) on the same inputs: whole and ragged segments, both signs,
     integer and almost-integer shifts (the general routing path), shifts beyond the row, xz planes."""
+    _need_experiments()
     from gpu_cases import run_product
     from planedepth_amd import _capi as C
     from planedepth_amd import ops
@@ -1749,14 +1766,14 @@ def test_plane_uniform_homography_kernels_equal_the_general_ones(B, N, H, W, mix
     zooms that push the per-source-pixel gather list past its 8 register slots (the follow-up re-scan kernel)."""
     from planedepth_amd import ops
     from planedepth_amd.synthetic import intrinsics
-    # backward variants: pass 2 with the scratch staged through LDS (default), the direct-gather pass 2 (PD_UNI_DIRECT), the
-    # one-kernel LDS hand-over form (PD_UNI_FUSED, opt-in; irregular launches fall through to the two-pass kernels)
+    # backward variants: pass 2 with the scratch staged through LDS (default), the direct-gather pass 2
+    # (PD_IMPL_UNIFORM_DIRECT), the one-kernel LDS hand-over form (PD_UNI_FUSED: experiments builds only)
+    from planedepth_amd import _capi as C
     monkeypatch.delenv("PD_UNI_FUSED", raising=False)
-    monkeypatch.delenv("PD_UNI_DIRECT", raising=False)
     if bwd == "fused":
+        _need_experiments()
         monkeypatch.setenv("PD_UNI_FUSED", "1")
-    elif bwd == "direct":
-        monkeypatch.setenv("PD_UNI_DIRECT", "1")
+    monkeypatch.setattr(ops, "SWEEP_IMPL", C.PD_IMPL_UNIFORM_DIRECT if bwd == "direct" else C.PD_IMPL_AUTO)
     g = torch.Generator().manual_seed(900 + W + N)
     dev = "cuda"
     src, tgt = torch.rand(B, 3, H, W, generator=g).to(dev), torch.rand(B, 3, H, W, generator=g).to(dev)
