@@ -62,13 +62,26 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def three_way(got, ref32, exact, factor=2.0, tol=1e-4):
+# Absolute caps against the fp64 evaluation of the reference's formulas, next to the relative three-way bound: where the
+# reference's own fp32 run is 1e-2 away from fp64 (torch.inverse at cond(H) ~ 1e4) the relative bound alone would let a
+# kernel error of several percent through.  The product forms its matrices in fp64 and rounds once, so only the per-pixel
+# fp32 chain separates it from the fp64 oracle: measured <= 2.4e-4 (forward tensors) / 6.4e-4 (gradients) over every
+# homography test of the suite (profiles/r03_parity.md); the caps leave a factor of ~2-3.
+FWD_CAP, GRAD_CAP = 5e-4, 2e-3
+
+
+def cap_for(key):
+    return GRAD_CAP if key.startswith("g_") else FWD_CAP
+
+
+def three_way(got, ref32, exact, factor=2.0, tol=1e-4, cap=None):
     """The parity bar where two fp32 evaluations of the reference's formulas legitimately differ by more than 1e-4
     (fp32 matrix inverses, 1/sigma^3-type amplification, bilinear derivatives through fp32 coordinates): the product must
     be as close to the fp64 evaluation as the reference's own fp32 arithmetic is — err(got, fp64) <= factor *
-    err(ref32, fp64) + tol.  Returns (ok, err_got, err_ref)."""
+    err(ref32, fp64) + tol — and, where ``cap`` is given, no further from it than that absolute amount.
+    Returns (ok, err_got, err_ref)."""
     e_got, e_ref = rel_err(got, exact.float()), rel_err(ref32, exact.float())
-    return e_got <= factor * e_ref + tol, e_got, e_ref
+    return e_got <= factor * e_ref + tol and (cap is None or e_got <= cap), e_got, e_ref
 
 
 def elementwise_report(a, b, rtol=1e-4, floor=1e-4):

@@ -22,10 +22,10 @@ NOT_YET = set()
 ILL_CONDITIONED = {"homo_mix_stereo": {"g_Rt"}}
 
 
-def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0):
+def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0, caps=True):
     """Three-way bound (cases.three_way) of a product result against the oracle in fp32 (the reference's arithmetic) and
-    in fp64 (the same formulas, exact to ~1e-13)."""
-    from cases import three_way
+    in fp64 (the same formulas, exact to ~1e-13), plus the absolute caps against fp64 (cases.FWD_CAP / GRAD_CAP)."""
+    from cases import cap_for, three_way
     ref32, exact = run_oracle(case, run), run_oracle(case, run, dtype=torch.float64)
     for k, w in exact.items():
         if k not in got or (keys and k not in keys) or k in skip:
@@ -33,7 +33,7 @@ def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0):
         if float(w.abs().max()) == 0.0:
             assert float(got[k].abs().max()) < 1e-6, (tag, k)
             continue
-        ok, e_got, e_ref = three_way(got[k], ref32[k], w)
+        ok, e_got, e_ref = three_way(got[k], ref32[k], w, cap=cap_for(k) if caps else None)
         assert ok, (tag, k, e_got, e_ref)
 
 
@@ -98,7 +98,9 @@ def test_random_cases_vs_oracle(seed, kw, run):
     case = build_case(seed=seed, sigma_interior=True, **kw)
     got = run_product(case, run)
     if run.get("warp_type") == "homography_warp":
-        _compare3(got, case, run, tag="seed%d" % seed, skip=("g_Rt",))
+        # g_Rt only where every sample sits on an integer row (the stereo pose: d bilinear / dy is discontinuous there,
+        # ILL_CONDITIONED above); a pose with a rotation has a well-defined pose gradient and is held to the same bar
+        _compare3(got, case, run, tag="seed%d" % seed, skip=("g_Rt",) if kw.get("stereo_T", True) else ())
     else:
         _compare(got, run_oracle(case, run), tag="seed%d" % seed)
 
@@ -955,7 +957,7 @@ def test_trainer_mono_fixture_through_patch_trainer(tag, stereo_constant, monkey
     horizon mask, per-plane distances) -> Trainer.predict_poses (Rt with zero translation and Rt[3,3] = 0, F8) ->
     Trainer.pred_novel_images over target_sides ["r", -1, 1] -> Trainer.compute_losses — through a stub class that
     adopted the product methods with patch_trainer."""
-    from cases import load_trainer_fixture, run_oracle_trainer
+    from cases import cap_for, load_trainer_fixture, run_oracle_trainer
     from gpu_cases import run_product_trainer
     from planedepth_amd import ops
     z, meta = load_trainer_fixture(tag)
@@ -993,7 +995,32 @@ def test_trainer_mono_fixture_through_patch_trainer(tag, stereo_constant, monkey
         ref_vs_exact = rel_err(w, exact[k].float())
         got_vs_exact = rel_err(v, exact[k].float())
         assert got_vs_exact < 2.0 * ref_vs_exact + TOL, (tag, k, e, got_vs_exact, ref_vs_exact)
+        if not (k == "g_Rt_r"):   # (stereo pose: every sample on an integer row, ILL_CONDITIONED) — the absolute cap
+            assert got_vs_exact < cap_for(k), (tag, k, got_vs_exact, cap_for(k))
     print(tag, {k: "%.1e" % e for k, e in worst.items()})
+
+
+@pytest.mark.parametrize("tag", ["homo3", "homo_nostereo_l1"])
+def test_trainer_mono_fixture_reference_arithmetic_route(tag, monkeypatch):
+    """PD_TORCH_HOMOGRAPHY=1: the matrices formed as the reference forms them (the stock fp32 torch chain with
+    torch.inverse, layers.py:206-219) instead of the fp64 kernel — the strict route, against the reference-captured
+    fixture itself.  What still separates the two is the inverse's backend (rocSOLVER here, LAPACK where the fixture
+    was captured) times cond(H) ~ 1e3: the measured distances are printed and held to the caps; profiles/r03_parity.md
+    lists them per tensor next to the default route's."""
+    from cases import cap_for, load_trainer_fixture
+    from gpu_cases import run_product_trainer
+    from planedepth_amd import ops
+    z, meta = load_trainer_fixture(tag)
+    monkeypatch.setattr(ops, "TORCH_HOMOGRAPHY", True)
+    got = run_product_trainer(z, meta, stereo_constant=False)
+    worst = {}
+    for k, v in got.items():
+        w = z[k]
+        if float(w.abs().max()) == 0.0 or k == "g_Rt_r":     # (stereo pose: ILL_CONDITIONED)
+            continue
+        worst[k] = rel_err(v, w)
+        assert worst[k] < 2.5 * cap_for(k), (tag, k, worst[k])
+    print(tag, "PD_TORCH_HOMOGRAPHY vs reference fixture", {k: "%.1e" % e for k, e in worst.items()})
 
 
 @pytest.mark.parametrize("tag,stereo_constant", [("homo3", True), ("homo3", False), ("homo_nostereo_l1", False)])
@@ -1083,6 +1110,12 @@ def _mono_fullsize_case(N_xy=49, N_xz=14, B=1, H=192, W=640, seed=77):
                 K=K, inv_K=inv_K, Rt=Rt, gw=gw)
 
 
+# Absolute caps at 192x640 (x up to 639: one ulp of the fp32 coordinate is 6e-5 px, and the reference's chain
+# x/(W-1) -> ... -> *(W-1) is reproduced operation by operation): measured distances of the product from the fp64
+# evaluation, with a factor ~2 (profiles/r03_parity.md).  A kernel error of a percent fails these by an order of magnitude.
+FULLSIZE_CAPS = dict(rgb_rec=6e-4, ph_map=1.5e-3, g_logits=1.5e-3, g_sigma=5e-3, g_H=4e-2, g_distance=3e-3)
+
+
 @pytest.mark.parametrize("mix,automask", [(True, True), (False, False)])
 def test_homography_fullsize_63_planes_pinned_matrices(mix, automask):
     """192x640, 49 + 14 planes (ground planes with non-frontal normals: the facing test (K^-1 p).(R n) > 0 of
@@ -1137,6 +1170,8 @@ def test_homography_fullsize_63_planes_pinned_matrices(mix, automask):
             continue
         e_got, e_ref = rel_err(v, o64[k]), rel_err(o32[k], o64[k])
         assert e_got < 1.5 * e_ref + TOL, (k, e_got, e_ref, rel_err(v, o32[k]))
+        assert e_got < FULLSIZE_CAPS[k], (k, e_got, FULLSIZE_CAPS[k])   # absolute, against fp64
+        print(k, "product %.1e reference-fp32 %.1e (vs fp64)" % (e_got, e_ref))
 
 
 @pytest.mark.parametrize("B,N_xy,N_xz,H,W,mix,automask", [(1, 49, 14, 192, 640, True, True), (2, 5, 3, 24, 80, True, False),
@@ -1147,6 +1182,7 @@ def test_stereo_homography_as_row_shifts(B, N_xy, N_xz, H, W, mix, automask):
     general per-plane-homography kernels and the fp64 oracle, end to end from (distance, norm, T, K): rgb_rec, ph_map and
     every gradient the trainer needs (logits, sigma, distance).  Three-way bound as above: the shortcut must be as close
     to the fp64 evaluation as the general fp32 kernels are."""
+    from cases import cap_for
     from oracle import planedepth_oracle as orc
     from planedepth_amd import ops
     from planedepth_amd.synthetic import small_pose
@@ -1193,6 +1229,8 @@ def test_stereo_homography_as_row_shifts(B, N_xy, N_xz, H, W, mix, automask):
         # the fp64 evaluation; the general kernels (fed matrices rounded once from fp64) are reported next to it
         e_rows, e_gen, e_ref = rel_err(v, exact[k]), rel_err(general[k], exact[k]), rel_err(ref32[k], exact[k])
         assert e_rows < 1.5 * max(e_ref, e_gen) + TOL, (k, e_rows, e_gen, e_ref, rel_err(v, general[k]))
+        cap = FULLSIZE_CAPS[k] if H >= 100 else cap_for(k)      # absolute, against fp64
+        assert e_rows < cap and e_gen < cap, (k, e_rows, e_gen, cap)
         print(k, "rows %.1e general %.1e reference-fp32 %.1e" % (e_rows, e_gen, e_ref))
 
 
