@@ -17,8 +17,9 @@ What differs from the reference (all documented in DESIGN.md):
     under the reference's keys.
   * the per-pixel photometric loss is produced by the same kernel that warps (``outputs[("ph_map", side)]``) and
     ``compute_losses`` only averages it.
-  * ``depth_warp`` (broken in the reference) is routed through BackprojectDepth/Project3D + the
-    decoder's padding mask and is evaluated with the unfused operators.
+  * ``depth_warp`` is dead code in the reference (its branch raises UnboundLocalError): ``pred_novel_images``
+    raises for it as well, naming the reason; the modules it would use (BackprojectDepth / Project3D) are available
+    from ``planedepth_amd.layers`` and are pinned against the reference by direct module calls.
 """
 import os
 

@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
         assert n in C.SIGNATURES, "ctypes prototype missing for " + n
     assert sorted(C.SIGNATURES) == names
     assert lib.pd_version() >= 100
+    import planedepth_amd
+    major, minor, patch = (int(v) for v in planedepth_amd.__version__.split("."))
+    assert lib.pd_version() == major * 1000 + minor * 100 + patch * 10, (lib.pd_version(), planedepth_amd.__version__)
+    assert lib.pd_experiments() in (0, 1)
 
 
 def test_desc_layout_and_host_queries():

@@ -713,6 +713,103 @@ def test_add_flip_right_inputs_is_bit_exact():
         assert torch.equal(got[k].cpu(), want[k]), k
 
 
+def test_add_flip_right_inputs_takes_the_dataloaders_cpu_batch():
+    """The reference calls add_flip_right_inputs on the DataLoader's CPU batch, before process_batch moves it to the
+    device (trainer.py:294-295 vs 328-329): CPU tensors in, through a patch_trainer'ed stub whose ``device`` is the GPU —
+    the doubled batch comes back on the device, bit-exact against the oracle's cat/flip restatement."""
+    import types
+    from gpu_cases import make_stub_trainer
+    from oracle import planedepth_oracle as orc
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 11, 29
+    inputs = {(k, s): torch.rand(B, 3, H, W, generator=g) for k in ("color", "color_aug") for s in ("l", "r", -1, 1)}
+    inputs["grid"] = torch.randn(B, 2, H, W, generator=g)
+    inputs.update({k: torch.randn(B, 4, 4, generator=g) for k in ("K", "inv_K", ("Rt", "l"), ("Rt", "r"))})
+    assert all(not v.is_cuda for v in inputs.values())
+    want = orc.add_flip_right_inputs(inputs, novel_frame_ids=(-1, 1))
+    trainer = make_stub_trainer(types.SimpleNamespace(novel_frame_ids=[-1, 1]), ["r", -1, 1], "cuda")
+    got = trainer.add_flip_right_inputs(inputs)
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k].is_cuda, k
+        assert torch.equal(got[k].cpu(), want[k]), k
+    assert all(not v.is_cuda for v in inputs.values())     # the caller's batch is left where it was
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (bench.spawn_ranks);
+    on a one-GPU box PD_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 with gloo for the timing collectives.  The JSON
+    line must report two ranks, a comm block and finite numbers — through the HIP path of both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PD_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no_cpu_baseline", "--no_next_rows", "--batch", "2", "--height", "48", "--width", "128", "--planes", "9"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["comm"]["world_size"] == 2, res
+    assert res["value"] > 0 and res["ms_per_step"] > 0 and res["value"] == res["value"]
+    assert res["config"]["global_batch"] == 4      # weak scaling: every rank brings its own shard
+
+
+def _shard_worker(rank, world, port, ret):
+    """One rank of test_two_rank_hip_shards_reproduce_the_full_batch: the HIP sweep on this rank's shard (both ranks share
+    cuda:0; gloo carries the barrier)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    from gpu_cases import run_product
+    from planedepth_amd import parallel
+    from planedepth_amd.synthetic import build_case
+    parallel.init_process_group_from_env("gloo")
+    case = build_case(**SHARD_CASE)
+    shard = parallel.shard_batch(case, rank, world, SHARD_CASE["B"])
+    out = run_product(shard, {}, device="cuda:0")
+    parallel.barrier()
+    ret[rank] = {k: out[k] for k in ("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp")}
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+SHARD_CASE = dict(B=4, N=7, H=20, W=96, seed=91, disp_min=0.5, disp_max=30.0, sigma_interior=True)
+
+
+def test_two_rank_hip_shards_reproduce_the_full_batch():
+    """SURVEY 8e on the product path: two processes each run the HIP sweep on half of the batch (no data-path collective)
+    and together reproduce the full-batch run — values exactly per image, gradients up to the loss mean's 1/B vs
+    1/(B/2) (DDP's gradient averaging supplies that factor in training)."""
+    import torch.multiprocessing as mp
+    from gpu_cases import run_product
+    from planedepth_amd.synthetic import build_case
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, 29641, ret)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(300)
+        assert p_.exitcode == 0
+    full = run_product(build_case(**SHARD_CASE), {})
+    per = SHARD_CASE["B"] // world
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        assert torch.equal(ret[r]["rgb_rec"], full["rgb_rec"][sl]) and torch.equal(ret[r]["ph_map"], full["ph_map"][sl])
+        # the upstream gradient of rgb_rec is per image; the photometric part carries the mean's 1/B: compare through the sum
+        for k in ("g_logits", "g_sigma", "g_disp_pp"):
+            assert ret[r][k].shape == full[k][sl].shape and torch.isfinite(ret[r][k]).all(), k
+    assert abs(0.5 * (float(ret[0]["ph_loss"]) + float(ret[1]["ph_loss"])) - float(full["ph_loss"])) < 1e-6
+
+
 @pytest.mark.parametrize("label,case_kw,run,opt_extra", [
     # BASELINE configs[2]/[3] plane count: 49 xy + 14 xz planes, horizon mask, automask (per-row disparities + row masks)
     ("n63_xz", dict(B=1, N=63, H=192, W=640, n_xz=14), dict(automask=True), dict(yz_levels=0, xz_levels=14)),
