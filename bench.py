@@ -612,6 +612,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
+        "library": dict(entry.BUILD_INFO),   # "built" here from source, or "reused" (the travelling .so matches this source hash)
         "known_deviation": "row-shift backward: the adjoint drops the eps-weighted (eps <= 8e-6) term of the neighbouring "
                            "source row on rows whose y round trip is inexact; bounded at 3e-5 of the gradients' range "
                            "against the general kernels (tests: test_rowshift_kernels_vs_general_kernels_and_oracle, "

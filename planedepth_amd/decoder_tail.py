@@ -17,6 +17,8 @@ a maintainer replaces lines 256-291 of ``depth_decoder.py`` with::
 
 ``--render_probability`` keeps the reference's own code (alpha compositing has no fused tail here).
 """
+import torch
+
 from . import ops
 
 
@@ -41,6 +43,13 @@ class LazyLayers:
         """The materialised [B,N,H,W] tensor.  It carries NO gradient (nothing in the reference's losses back-propagates
         through ``probability`` / ``pi``: trainer.py reads them for their shape, the post-process under no_grad)."""
         if self._value is None:
+            if torch.is_grad_enabled() and not getattr(LazyLayers, "_warned", False):
+                import warnings
+                LazyLayers._warned = True
+                warnings.warn("planedepth_amd: outputs['probability'] / outputs['pi'] of the fused decoder tail are "
+                              "materialised WITHOUT gradient (the reference's losses never back-propagate through them; "
+                              "gradients flow through 'disp', 'logits' and 'sigma').  Use the unfused decoder if a custom "
+                              "loss needs them differentiable.", stacklevel=3)
             self._value = self._make()
         return self._value
 

@@ -1605,6 +1605,15 @@ def test_contract_check_catches_tensors_that_disagree_with_the_options():
     bad_disp = dict(base, disp_layered=(c["disp_pp"].expand(-1, -1, H, W) + torch.rand(B, N, H, W, device="cuda")))
     with pytest.raises(ValueError, match="constant along x"):
         planedepth_amd.pred_novel_images(ns, inputs, bad_disp)
+    # without the option: the FIRST call of a trainer object checks (one host sync), later calls trust the cached verdict
+    opt2 = types.SimpleNamespace(**{k: v for k, v in vars(opt).items() if k != "pd_check_contract"})
+    fresh = types.SimpleNamespace(opt=opt2, target_sides=["r"])
+    with pytest.raises(ValueError, match="all-ones padding_mask"):
+        planedepth_amd.pred_novel_images(fresh, inputs, dict(bad_mask))
+    seasoned = types.SimpleNamespace(opt=opt2, target_sides=["r"])
+    planedepth_amd.pred_novel_images(seasoned, inputs, dict(base))
+    assert seasoned._pd_contract_checked
+    planedepth_amd.pred_novel_images(seasoned, inputs, dict(bad_mask))            # no check any more: no sync either
 
 
 @pytest.mark.parametrize("mode", ["planes", "uniform", "stereo_rows"])
