@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_next_rows", action="store_true", help="skip the timings of the SURVEY 8f operators")
     ap.add_argument("--no_ddp_step", action="store_true", help="skip the end-to-end DDP training-step block")
+    ap.add_argument("--ddp_model", default="r18", choices=["r18", "r50"],
+                    help="stand-in depth network of the ddp_step block: ResNet-18-shaped (59.6 MB of gradients, BASELINE configs[1]) "
+                         "or ResNet-50 + dense-ASPP-shaped (156.6 MB, configs[2])")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -351,6 +354,87 @@ def next_rows_times(args, device, iters=10):
     }
 
 
+def resnet_shaped_depth_net(kind, n_planes):
+    """Stand-in for the reference's depth network with the REAL gradient volume: torchvision is not in the
+    image, so the ResNet is restated with stock nn.Conv2d / nn.BatchNorm2d blocks (BasicBlock stacks [2,2,2,2] for "r18",
+    Bottleneck stacks [3,4,6,3] for "r50") under a monodepth-style skip decoder (networks/depth_decoder.py:30-60:
+    num_ch_dec = [16,32,64,128,256]) that ends in the decoder's three heads.  r18: 14.9 M parameters = 59.6 MB of fp32
+    gradients; r50 adds a dense-ASPP-sized block on the bottleneck: 39.2 M = 156.6 MB.  Random init, synthetic inputs:
+    what is measured is the step's structure and its gradient all-reduce, not accuracy."""
+    import torch.nn as nn
+
+    def cbr(ci, co, k=3, s=1):
+        return nn.Sequential(nn.Conv2d(ci, co, k, s, k // 2, bias=False), nn.BatchNorm2d(co), nn.ReLU(inplace=True))
+
+    class Basic(nn.Module):
+        def __init__(self, ci, co, s):
+            super().__init__()
+            self.a, self.b = cbr(ci, co, 3, s), nn.Sequential(nn.Conv2d(co, co, 3, 1, 1, bias=False), nn.BatchNorm2d(co))
+            self.sc = None if (s == 1 and ci == co) else nn.Sequential(nn.Conv2d(ci, co, 1, s, bias=False), nn.BatchNorm2d(co))
+
+        def forward(self, x):
+            return torch.relu(self.b(self.a(x)) + (x if self.sc is None else self.sc(x)))
+
+    class Bottle(nn.Module):
+        def __init__(self, ci, co, s):
+            super().__init__()
+            m = co // 4
+            self.a, self.b = cbr(ci, m, 1), cbr(m, m, 3, s)
+            self.c = nn.Sequential(nn.Conv2d(m, co, 1, bias=False), nn.BatchNorm2d(co))
+            self.sc = None if (s == 1 and ci == co) else nn.Sequential(nn.Conv2d(ci, co, 1, s, bias=False), nn.BatchNorm2d(co))
+
+        def forward(self, x):
+            return torch.relu(self.c(self.b(self.a(x))) + (x if self.sc is None else self.sc(x)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            deep = kind == "r50"
+            block, depths, mul = (Bottle, [3, 4, 6, 3], 4) if deep else (Basic, [2, 2, 2, 2], 1)
+            self.stem = cbr(3, 64, 7, 2)
+            self.pool = nn.MaxPool2d(3, 2, 1)
+            chans, ci, stages = [64 * mul, 128 * mul, 256 * mul, 512 * mul], 64, []
+            for i, (co, d) in enumerate(zip(chans, depths)):
+                stages.append(nn.Sequential(*[block(ci if j == 0 else co, co, (2 if (j == 0 and i > 0) else 1)) for j in range(d)]))
+                ci = co
+            self.stages = nn.ModuleList(stages)
+            enc = [64] + chans
+            self.aspp = None
+            if deep:   # DenseASPP-sized context block on the bottleneck (networks/depth_decoder.py with --use_denseaspp)
+                self.aspp = nn.Sequential(cbr(enc[-1], 512, 1), *[cbr(512, 512, 3) for _ in range(2)], cbr(512, enc[-1], 1))
+            dec = [16, 32, 64, 128, 256]
+            self.neck = None if deep else nn.Sequential(nn.Conv2d(256, 256, 3, 1, 1), nn.ELU(inplace=True))   # (brings r18 to 59.7 MB)
+            self.up0, self.up1 = nn.ModuleList(), nn.ModuleList()
+            for i in range(4, -1, -1):
+                cin = enc[-1] if i == 4 else dec[i + 1]
+                self.up0.append(nn.Sequential(nn.Conv2d(cin, dec[i], 3, 1, 1), nn.ELU(inplace=True)))
+                self.up1.append(nn.Sequential(nn.Conv2d(dec[i] + (enc[i - 1] if i > 0 else 0), dec[i], 3, 1, 1), nn.ELU(inplace=True)))
+            self.dispconv = nn.Conv2d(16, n_planes, 3, 1, 1)
+            self.sigmaconv = nn.Conv2d(16, n_planes, 3, 1, 1)
+            self.residualconv = nn.Conv2d(16, n_planes, 1)
+
+        def forward(self, x):
+            x = (x - 0.45) / 0.225
+            f = [self.stem(x)]
+            y = self.pool(f[0])
+            for st in self.stages:
+                y = st(y)
+                f.append(y)
+            x = f[-1] if self.aspp is None else f[-1] + self.aspp(f[-1])
+            for k, i in enumerate(range(4, -1, -1)):
+                x = self.up0[k](x)
+                if k == 0 and self.neck is not None:
+                    x = self.neck(x)
+                x = nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+                if i > 0:
+                    x = torch.cat([x, f[i - 1]], 1)
+                x = self.up1[k](x)
+            res = torch.sigmoid(self.residualconv(x).mean((2, 3), keepdim=True)) - 0.5      # depth_decoder.py:151
+            return self.dispconv(x), self.sigmaconv(x), res
+
+    return Net()
+
+
 def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     """End-to-end training step with the reference's structure (trainer.py:278-323) on synthetic KITTI-like inputs made
     ON the device: add_flip_right_inputs (B/2 -> B) -> a stand-in conv encoder/decoder wrapped in
@@ -368,29 +452,12 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     if B % 2:
         return {"skipped": "--flip_right doubling needs an even per-GPU batch"}
 
-    class StandInDepthNet(nn.Module):   # out of scope of the hot path: just something with parameters and convolutions
-        def __init__(self, n_planes, ch=24):
-            super().__init__()
-            act = nn.ELU(inplace=True)
-            self.down = nn.ModuleList([nn.Sequential(nn.Conv2d(ci, co, 3, 2, 1), act) for ci, co in
-                                       ((3, ch), (ch, 2 * ch), (2 * ch, 4 * ch), (4 * ch, 8 * ch))])
-            self.up = nn.ModuleList([nn.Sequential(nn.Conv2d(ci, co, 3, 1, 1), act) for ci, co in
-                                     ((8 * ch, 4 * ch), (4 * ch, 2 * ch), (2 * ch, ch), (ch, 16))])
-            self.dispconv = nn.Conv2d(16, n_planes, 3, 1, 1)
-            self.sigmaconv = nn.Conv2d(16, n_planes, 3, 1, 1)
-            self.residualconv = nn.Conv2d(16, n_planes, 1)
-
-        def forward(self, x):
-            x = (x - 0.45) / 0.225
-            for m in self.down:
-                x = m(x)
-            for m in self.up:
-                x = m(nn.functional.interpolate(x, scale_factor=2, mode="nearest"))
-            res = torch.sigmoid(self.residualconv(x).mean((2, 3), keepdim=True)) - 0.5      # depth_decoder.py:151
-            return self.dispconv(x), self.sigmaconv(x), res
-
+    model_kind = args.ddp_model
     torch.manual_seed(100 + rank)
-    model = StandInDepthNet(N).to(device)
+    model = resnet_shaped_depth_net(model_kind, N)
+    if world > 1 or os.environ.get("PD_BENCH_SYNC_BN"):
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)                          # trainer.py:98
+    model = model.to(device)
     own_group = False
     if not dist.is_initialized():          # single GPU: a one-rank group, so that the step really runs under DDP
         import socket
@@ -462,14 +529,31 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
              "ms_per_step_without_gradient_sync": round(t_nosync * 1e3, 3),
              "sweep_fwd_ms": round(hot["fwd"], 4), "sweep_bwd_ms": round(hot["bwd"], 4),
              "hot_path_share_of_step": round((hot["fwd"] + hot["bwd"]) * 1e-3 / t_step, 4),
-             "network": "stand-in conv U-net, %d parameters (%.1f MB fp32 gradients), DistributedDataParallel(find_unused_parameters=True)"
-                        % (n_params, n_params * 4 / 1e6),
+             "network": "%s-shaped stand-in (stock Conv2d/BatchNorm2d blocks + skip decoder + the decoder's three heads), %d "
+                        "parameters = %.1f MB of fp32 gradients (SURVEY C1: 59.6 / 156.6 MB), %s, "
+                        "DistributedDataParallel(find_unused_parameters=True) as trainer.py:98-99"
+                        % ("ResNet-18" if model_kind == "r18" else "ResNet-50 + dense-ASPP", n_params, n_params * 4 / 1e6,
+                           "SyncBatchNorm" if any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()) else
+                           "BatchNorm2d (one rank: convert_sync_batchnorm applies from 2 ranks on)"),
              "batch_per_gpu": B, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
              "structure": "flip_right doubling -> DDP(conv net) -> fused decoder tail -> plane sweep -> losses -> backward -> Adam"}
     if world > 1:
         exposed = max(t_step - t_nosync, 0.0)
         block.update(allreduce_alone_ms=round(t_allreduce * 1e3, 3), allreduce_exposed_ms=round(exposed * 1e3, 3),
-                     allreduce_hidden_share=round(1.0 - min(exposed / t_allreduce, 1.0), 3) if t_allreduce > 0 else None)
+                     allreduce_hidden_share=round(1.0 - min(exposed / t_allreduce, 1.0), 3) if t_allreduce > 0 else None,
+                     bucket_cap_mb=25)
+        # xGMI rings are per-link bound: how much of the gradient all-reduce stays exposed as the bucket size changes
+        by_bucket = {}
+        for cap in (10, 50, 100):
+            del ddp
+            ddp = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True,
+                                                      bucket_cap_mb=cap)
+            for _ in range(2):
+                step()
+            t_cap = parallel_max(timed(step, 5), device)
+            by_bucket[str(cap)] = {"ms_per_step": round(t_cap * 1e3, 3),
+                                   "allreduce_exposed_ms": round(max(t_cap - t_nosync, 0.0) * 1e3, 3)}
+        block["by_bucket_cap_mb"] = by_bucket
     else:
         block["allreduce_hidden_share"] = None   # one rank: nothing to overlap; measured from --gpus 2 upwards
     del ddp
