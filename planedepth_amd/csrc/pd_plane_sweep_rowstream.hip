@@ -24,7 +24,7 @@
 // header): planes with frac(s*d) closer than kIrrTol(W) to an integer ("irregular", decided when the shifts are
 // staged) take a general per-lane path instead — exact floor(ix) per target, gradient rows zero-filled up front,
 // contributions added with atomics (two addends per slot: the order cannot change the sum).  For every other plane
-// the premise holds with a margin of 3x the worst-case rounding error of the chain (bound in DESIGN.md 3.6).
+// the premise holds with a margin of 2.4-3x the worst-case rounding error of the chain (bound in DESIGN.md 3.6.3).
 // Targets whose left tap is column -1 (negative shifts) have no slot: a short epilogue serves them (lanes = planes).
 //
 // Vertical: rows whose y round trip is inexact blend two source rows (weights 1-eps, eps); values and per-pixel
@@ -79,7 +79,8 @@ __device__ __forceinline__ void buf_store2(Rsrc r, unsigned voff, unsigned soff,
 
 // frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
 // chain against exact arithmetic: fl(x + sd) <= ulp(2W)/2, the division, the two additions and the product by W-1
-// each <= ulp(.)/2 scaled by W-1 — 4.2e-7 * W in total for W <= 4096; the threshold keeps a factor of ~3.
+// each <= ulp(.)/2 scaled by W-1 — 5.4e-7 * W in total (3.1e-4 at W = 640); the threshold keeps a factor of 2.4-3
+// up to W = 4096.
 __device__ __forceinline__ float irregular_tol(int W) { return 2.5e-4f + 1.25e-6f * (float)W; }
 
 struct StreamLds {

@@ -1,4 +1,4 @@
-"""Measured parity of the product path per configuration and tensor -> markdown (profiles/r02_parity.md).
+"""Measured parity of the product path per configuration and tensor -> markdown (profiles/r03_parity.md).
 
 Columns: normalised max error (max|a-b| / max|b|) of the product against the reference-captured fixture (or, where no
 fixture exists at that size, the oracle's fp32 evaluation = the reference's arithmetic), against the oracle's fp64
@@ -53,6 +53,18 @@ for tag in ("homo3", "homo_nostereo_l1", "disp_xz"):
         add("trainer_mono %s%s" % (tag, " (stereo pose constant: row-shift view)" if const else ""), "reference-captured",
             got, z, run_oracle_trainer(z, meta, dtype=torch.float64))
 
+# the strict route (PD_TORCH_HOMOGRAPHY: the reference's fp32 torch.inverse chain) against the same reference-captured fixtures
+from planedepth_amd import ops  # noqa: E402
+ops.TORCH_HOMOGRAPHY = True
+try:
+    for tag in ("homo3", "homo_nostereo_l1"):
+        z, meta = load_trainer_fixture(tag)
+        got = run_product_trainer(z, meta, stereo_constant=False)
+        add("trainer_mono %s, strict route (PD_TORCH_HOMOGRAPHY=1)" % tag, "reference-captured", got, z,
+            run_oracle_trainer(z, meta, dtype=torch.float64))
+finally:
+    ops.TORCH_HOMOGRAPHY = False
+
 for label, kw, run, extra in (("192x640x49 mixture", {}, {}, None),
                               ("192x640x49 mixture automask", {}, dict(automask=True), None),
                               ("192x640x49 L1", {}, dict(use_mixture_loss=False), None),
@@ -67,7 +79,7 @@ out = ["| configuration | compared with | tensor | vs reference fp32 | vs fp64 |
        "|---|---|---|---|---|---|---|"]
 for r in rows:
     out.append("| %s | %s | %s | %s | %s | %s | %.2e |" % (r[0], r[1], r[2], fmt(r[3]), fmt(r[4]), fmt(r[5]), r[6]))
-path = os.path.join(ROOT, "gpurun_out", "r2", "r02_parity.md")
+path = os.path.join(ROOT, "gpurun_out", "r3", "r03_parity.md")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 open(path, "w").write("\n".join(out) + "\n")
 print("\n".join(out[:12]))

@@ -188,7 +188,7 @@ template <int P, int D, int K, int MODE, int WAVES = 4, int OCC = 4> static void
          (MODE & 4) ? "C" : "-", ms, bytes / 1e9 / (ms * 1e-3));
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int B = 8, N = 49, H = 192, W = 640;
   const size_t n = (size_t)B * N * H * W;
   CK(hipMalloc(&A, n * 4 + 4096)); CK(hipMalloc(&Bt, n * 4 + 4096)); CK(hipMalloc(&GA, n * 4 + 4096)); CK(hipMalloc(&GB, n * 4 + 4096));
@@ -196,6 +196,12 @@ int main() {
   fill<<<4096, 256>>>(A, n, 1u); fill<<<4096, 256>>>(Bt, n, 7u); fill<<<1024, 256>>>(ctx, (size_t)B * 13 * H * W, 3u);
   fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W);
   CK(hipDeviceSynchronize());
+  if (argc > 1) {   // calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (scripts/gpu_r3_profile.sh): the row-stream
+    // backward's access shape (12-byte aligned loads, 8-byte aligned stores), loads alone and loads + stores
+    run<2, 2, 0, 1>(B, N, H, W); run<2, 2, 0, 3>(B, N, H, W);
+    printf("known bytes per launch: tap loads %.0f, context staging %.0f, stores %.0f\n", 2.0 * n * 4, 13.0 * B * H * W * 4, 2.0 * n * 4);
+    return 0;
+  }
   printf("-- memory shape alone, by prefetch depth\n");
   run<1, 1, 0, 3>(B, N, H, W); run<1, 2, 0, 3>(B, N, H, W); run<1, 4, 0, 3>(B, N, H, W);
   run<2, 1, 0, 3>(B, N, H, W); run<2, 2, 0, 3>(B, N, H, W); run<2, 4, 0, 3>(B, N, H, W);
