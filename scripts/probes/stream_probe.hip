@@ -188,6 +188,99 @@ template <int P, int D, int K, int MODE, int WAVES = 4, int OCC = 4> static void
          (MODE & 4) ? "C" : "-", ms, bytes / 1e9 / (ms * 1e-3));
 }
 
+
+// ---- forward shape: TARGET-ordered (the softmax state lives with the target pixel), two target pixels per lane, the
+// taps of plane n at xt + k_n: one 12-byte load per tensor at 4-byte alignment, colour taps out of LDS at the same
+// shift, K VALU per pixel-plane; waves = (segment, plane half), the second half parks its state for the first.
+template <int D, int K, int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void fwdstream(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                             const float* __restrict__ ctx_src, const int* __restrict__ kshift,
+                                                             float* __restrict__ outp, int N, int H, int W, int Bn) {
+  extern __shared__ v4f lds[];
+  const int RS = W + 8;
+  v4f* col = lds;                 // [RS] colour row with guard cells
+  float* park = reinterpret_cast<float*>(lds + RS);   // [nseg][8][128]
+  const int id = blockIdx.x, b = id % Bn, y = id / Bn;
+  const long HW = (long)H * W;
+  for (int x = threadIdx.x; x < RS; x += blockDim.x) {
+    const int xi = x - 4;
+    v4f cc = {0, 0, 0, 0};
+    if (xi >= 0 && xi < W) { const float* p = ctx_src + ((long)b * 13) * HW + (long)y * W + xi; cc = v4f{p[0], p[HW], p[2 * HW], 0}; }
+    col[x] = cc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + 127) / 128, split = WAVES / nseg;       // waves per segment
+  const int seg = wave / split, part = wave - seg * split;
+  const int n0 = N * part / split, n1 = N * (part + 1) / split;
+  const int xt = seg * 128 + lane * 2;
+  const float* Ab = A + (long)b * N * HW + (long)y * W; const float* Bb = Bt + (long)b * N * HW + (long)y * W;
+  const float* tp = ctx_src + ((long)b * 13 + 3) * HW + (long)y * W + min(xt, W - 2);
+  float t[6] = {tp[0], tp[1], tp[HW], tp[HW + 1], tp[2 * HW], tp[2 * HW + 1]};
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  struct G { float a[3], b[3]; };
+  auto issue = [&](G& g, int n_raw) {
+    const int n = min(n_raw, n1 - 1);
+    const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+    const unsigned off = (unsigned)(xt + k) * 4;
+    const v3f va = ld3(rsrc(Ab + (unsigned)(n * (int)HW), W * 4), off), vb = ld3(rsrc(Bb + (unsigned)(n * (int)HW), W * 4), off);
+    g.a[0] = va.x; g.a[1] = va.y; g.a[2] = va.z; g.b[0] = vb.x; g.b[1] = vb.y; g.b[2] = vb.z;
+  };
+  auto compute = [&](const G& g, int n) {
+    const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+    const v4f* cp = col + min(max(xt + k, -4), W + 1) + 4;
+    const v4f c0 = cp[0], c1 = cp[1], c2 = cp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float l = g.a[i] * 0.25f + g.a[i + 1] * 0.75f, s = g.b[i] * 0.25f + g.b[i + 1] * 0.75f;
+      const v4f ca = i ? c1 : c0, cb = i ? c2 : c1;
+      const float cr = ca.x * 0.25f + cb.x * 0.75f, cg = ca.y * 0.25f + cb.y * 0.75f, cbl = ca.z * 0.25f + cb.z * 0.75f;
+      const float r = burn<K>(l + t[i], s + t[2 + i], cr + t[4 + i], cg + cbl);
+      acc[i * 8 + 0] += r; acc[i * 8 + 1] += l; acc[i * 8 + 2] += s * r; acc[i * 8 + 3] += cr * r;
+      acc[i * 8 + 4] += cg * r; acc[i * 8 + 5] += cbl * r; acc[i * 8 + 6] += r * l; acc[i * 8 + 7] += r * s;
+    }
+  };
+  G g[D + 1];
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue(g[j], n0 + j);
+  int n = n0;
+  for (; n + (D + 1) <= n1; n += D + 1) {
+#pragma unroll
+    for (int j = 0; j <= D; ++j) { issue(g[(j + D) % (D + 1)], n + j + D); compute(g[j], n + j); }
+  }
+#pragma unroll
+  for (int j = 0; j <= D; ++j) if (n + j < n1) { issue(g[(j + D) % (D + 1)], n + j + D); compute(g[j], n + j); }
+  if (part > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) park[((seg * (split - 1) + part - 1) * 16 + i) * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (part == 0) {
+    for (int p2 = 1; p2 < split; ++p2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += park[((seg * (split - 1) + p2 - 1) * 16 + i) * 64 + lane];
+    if (xt < W) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v2f v = {acc[c], acc[8 + c]};
+        *reinterpret_cast<v2f*>(outp + ((long)b * 8 + c) * HW + (long)y * W + xt) = v;
+      }
+    }
+  }
+}
+
+template <int D, int K, int WAVES, int OCC> static void runf(int B, int N, int H, int W) {
+  const int nseg = (W + 127) / 128, split = WAVES / nseg;
+  const size_t ldsb = (size_t)(W + 8) * 16 + (size_t)nseg * (split - 1) * 16 * 64 * 4 + 64;
+  CK(hipFuncSetAttribute((const void*)fwdstream<D, K, WAVES, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  const double ms = time_ms([&] { fwdstream<D, K, WAVES, OCC><<<dim3(H * B), WAVES * 64, ldsb>>>(A, Bt, ctx, ks, GA, N, H, W, B); });
+  CK(hipGetLastError());
+  const double bytes = (double)B * H * W * 4 * (2 * N + 9 + 8);
+  printf("FWD W=%4d D=%d K=%3d waves=%d occ=%d lds=%zu  %7.3f ms  %7.1f GB/s\n", W, D, K, WAVES, OCC, ldsb, ms, bytes / 1e9 / (ms * 1e-3));
+}
+
 int main(int argc, char** argv) {
   const int B = 8, N = 49, H = 192, W = 640;
   const size_t n = (size_t)B * N * H * W;
@@ -196,6 +289,12 @@ int main(int argc, char** argv) {
   fill<<<4096, 256>>>(A, n, 1u); fill<<<4096, 256>>>(Bt, n, 7u); fill<<<1024, 256>>>(ctx, (size_t)B * 13 * H * W, 3u);
   fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W);
   CK(hipDeviceSynchronize());
+  if (argc > 1 && argv[1][0] == 'f') {   // forward shape
+    runf<2, 0, 10, 5>(B, N, H, W); runf<3, 0, 10, 5>(B, N, H, W); runf<2, 40, 10, 5>(B, N, H, W); runf<3, 40, 10, 5>(B, N, H, W);
+    runf<3, 60, 10, 5>(B, N, H, W); runf<2, 60, 10, 5>(B, N, H, W); runf<3, 40, 5, 5>(B, N, H, W); runf<3, 60, 5, 5>(B, N, H, W);
+    runf<3, 40, 10, 4>(B, N, H, W); runf<3, 60, 10, 4>(B, N, H, W); runf<3, 40, 15, 5>(B, N, H, W); runf<1, 40, 10, 5>(B, N, H, W);
+    return 0;
+  }
   if (argc > 1) {   // calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (scripts/gpu_r3_profile.sh): the row-stream
     // backward's access shape (12-byte aligned loads, 8-byte aligned stores), loads alone and loads + stores
     run<2, 2, 0, 1>(B, N, H, W); run<2, 2, 0, 3>(B, N, H, W);
