@@ -706,9 +706,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
         "library": dict(entry.BUILD_INFO),   # "built" here from source, or "reused" (the travelling .so matches this source hash)
-        "known_deviation": "row-shift backward: the adjoint drops the eps-weighted (eps <= 8e-6) term of the neighbouring "
-                           "source row on rows whose y round trip is inexact; bounded at 3e-5 of the gradients' range "
-                           "against the general kernels (tests: test_rowshift_kernels_vs_general_kernels_and_oracle, "
+        "known_deviation": "row kernels' backward (row-stream by default, row-shift under PD_IMPL_ROWS1): the adjoint drops the "
+                           "eps-weighted (eps <= 8e-6) term of the neighbouring source row on rows whose y round trip is "
+                           "inexact; bounded at 3e-5 of the gradients' range against the general kernels (tests: "
+                           "test_rowshift_kernels_vs_general_kernels_and_oracle, "
                            "test_rowshift_adjoint_cross_row_term_is_bounded_at_large_height); forward exact",
         "config": {"workload": "BASELINE configs[1]: %s, %s, %s loss, batch %d/GPU, %dx%d, %d planes, "
                                "grads to logits/sigma/plane disparities + upstream rgb_rec gradient"
@@ -737,7 +738,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_launch,
                      "avg_launch_ms": round(kt[dom], 4),
-                     "timing": "HIP events on the launch stream around the C-ABI call, inside the training step"}
+                     "timing": "HIP events on the launch stream around the C-ABI call (the sweep kernel plus its 5 us helper "
+                               "launch: ph_mean memset / row reduction), inside the training step, steady state"}
             # headline workload -> "roofline"; the general (homography) kernels report the same block under their own key
             result["roofline" if args.warp_type == "disp_warp" else "roofline_general"] = block
             if args.warp_type != "disp_warp":

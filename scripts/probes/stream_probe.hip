@@ -289,6 +289,14 @@ int main(int argc, char** argv) {
   fill<<<4096, 256>>>(A, n, 1u); fill<<<4096, 256>>>(Bt, n, 7u); fill<<<1024, 256>>>(ctx, (size_t)B * 13 * H * W, 3u);
   fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W);
   CK(hipDeviceSynchronize());
+  if (argc > 1 && argv[1][0] == 'l') {   // loads alone / stores alone, by width, depth and workgroup size
+    run<1, 2, 0, 1>(B, N, H, W); run<2, 2, 0, 1>(B, N, H, W); run<4, 2, 0, 1>(B, N, H, W);
+    run<2, 4, 0, 1>(B, N, H, W); run<4, 4, 0, 1>(B, N, H, W); run<2, 2, 0, 1, 8, 4>(B, N, H, W); run<4, 2, 0, 1, 8, 4>(B, N, H, W);
+    run<2, 4, 0, 1, 8, 4>(B, N, H, W); run<2, 6, 0, 1, 8, 4>(B, N, H, W);
+    run<1, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2>(B, N, H, W); run<4, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2, 8, 4>(B, N, H, W);
+    run<2, 2, 0, 3, 8, 4>(B, N, H, W); run<4, 2, 0, 3, 8, 4>(B, N, H, W); run<2, 4, 0, 3, 8, 4>(B, N, H, W);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'f') {   // forward shape
     runf<2, 0, 10, 5>(B, N, H, W); runf<3, 0, 10, 5>(B, N, H, W); runf<2, 40, 10, 5>(B, N, H, W); runf<3, 40, 10, 5>(B, N, H, W);
     runf<3, 60, 10, 5>(B, N, H, W); runf<2, 60, 10, 5>(B, N, H, W); runf<3, 40, 5, 5>(B, N, H, W); runf<3, 60, 5, 5>(B, N, H, W);
