@@ -406,6 +406,49 @@ def test_size_independent_properties_at_benchmark_size():
     assert rel_err(f(rgbf), rgb) < 2e-3 and rel_err(f(phf), ph) < 2e-3  # fp32 coordinate rounding at x~600: ulp 6e-5 px
 
 
+def test_rowstream_backward_properties_at_benchmark_size():
+    """B=8, 192x640, N=49 WITHOUT a padding mask — the benchmark path itself (row-shift forward, row-stream backward):
+    properties that need no oracle run, and the target-ordered row-shift backward on the same forward as a second
+    implementation of the same adjoint."""
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import survey_fullsize_case
+    c = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in survey_fullsize_case(B=8, sigma_interior=True).items()}
+    B, N, H, W = c["logits"].shape
+
+    def run(perm=None, g_scale=1.0):
+        sel = (lambda t: t[perm]) if perm is not None else (lambda t: t)
+        lg, sg = sel(c["logits"]).clone().requires_grad_(True), sel(c["sigma"]).clone().requires_grad_(True)
+        dp = sel(c["disp_pp"]).clone().requires_grad_(True)
+        rgb, ph, pm = ops.plane_sweep_disp(sel(c["color_l"]), sel(c["color_r"]), lg, sg, dp.expand(B, N, H, W), None,
+                                           return_mean=True)
+        ((pm + (rgb * sel(c["g_rgb_rec"])).sum()) * g_scale).backward()
+        return lg.grad, sg.grad, dp.grad
+
+    gl, gs, gd = run()
+    assert torch.isfinite(gl).all() and torch.isfinite(gs).all() and torch.isfinite(gd).all()
+    # (1) every element of g_logits / g_sigma is stored exactly once (the few range hand-overs add one value onto a stored
+    #     slot): bit-identical between runs
+    gl2, gs2, _ = run()
+    assert torch.equal(gl, gl2) and torch.equal(gs, gs2)
+    # (2) images are independent: permuting the batch permutes the gradients, bit for bit
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device="cuda")
+    glp, gsp, gdp = run(perm=perm)
+    assert torch.equal(glp, gl[perm]) and torch.equal(gsp, gs[perm])
+    assert rel_err(gdp, gd[perm]) < 1e-5     # (sums over the image: the order of the waves' partial sums is not fixed)
+    # (3) linear in the upstream gradient
+    gl3, gs3, gd3 = run(g_scale=3.0)
+    assert rel_err(gl3, 3 * gl) < 1e-6 and rel_err(gs3, 3 * gs) < 1e-6 and rel_err(gd3, 3 * gd) < 1e-5
+    # (4) the target-ordered backward (one pixel per lane, shifted stores, in-wave routing) computes the same adjoint
+    ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
+    try:
+        glo, gso, gdo = run()
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    assert rel_err(gl, glo) < 3e-6 and rel_err(gs, gso) < 3e-6 and rel_err(gd, gdo) < 5e-5, (
+        rel_err(gl, glo), rel_err(gs, gso), rel_err(gd, gdo))
+
+
 def test_modules_vs_reference_golden():
     import planedepth_amd as pa
     from planedepth_amd import ops
