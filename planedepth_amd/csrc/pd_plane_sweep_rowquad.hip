@@ -837,7 +837,8 @@ static size_t quad_bwd_lds(const pd_sweep_desc* d, int Q) {
 }
 
 bool rowquad_applicable(const pd_sweep_desc* d, bool dense_mask) {
-  return rowshift_applicable(d) && !dense_mask && d->W >= 8 && d->impl != PD_IMPL_ROWS1 && !getenv("PD_NO_ROWQUAD") &&
+  // (no compositing code in these kernels: render_probability sweeps keep the row-shift kernels — ADVICE r2)
+  return rowshift_applicable(d) && !dense_mask && !(d->flags & PD_RENDER_PROB) && d->W >= 8 && d->impl != PD_IMPL_ROWS1 && !getenv("PD_NO_ROWQUAD") &&
          quad_bwd_lds(d, PD_QBWD_Q) <= 160 * 1024 && quad_fwd_lds(d) <= 160 * 1024;
 }
 

@@ -58,6 +58,9 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_GENERAL_INLINE
 #define PD_STREAM_GENERAL_INLINE __forceinline__   // the rare general path: inline or a call (__noinline__)
 #endif
+#ifndef PD_STREAM_LDS_PAD
+#define PD_STREAM_LDS_PAD 0   // experiments: extra LDS bytes per workgroup (occupancy studies)
+#endif
 #ifndef PD_STREAM_OCC
 #define PD_STREAM_OCC 4  // waves per SIMD the register allocator must leave room for
 #endif
@@ -467,7 +470,7 @@ __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, fl
 // ---------------------------------------------------------------------------------------------------------------
 static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves) {
   const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
-  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
+  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16 + PD_STREAM_LDS_PAD;
 }
 static int rowstream_waves(const pd_sweep_desc* d) {
   const int items = d->N * ceil_div(d->W, kSeg);

@@ -762,8 +762,9 @@ def cat_flip(own, other, negate_c0=False):
 
 def crop_grid(params, height, width):
     """``inputs["grid"]`` [B,2,H,W] on the device from per-sample crop parameters [B,4] int32 = (full_w, full_h, w0, h0)
-    (datasets/pair_transforms.py:27-37: the RandomResizeCrop grid; Resize is full = (W, H), origin 0) — bit-identical to
-    the reference's ``torch.linspace`` / ``meshgrid`` / crop."""
+    (datasets/pair_transforms.py:27-37: the RandomResizeCrop grid; Resize is full = (W, H), origin 0) — the reference's
+    ``torch.linspace`` / ``meshgrid`` / crop to one ulp (torch's vectorised linspace itself differs in the last bit between
+    host CPUs: tests/test_gpu_parity.py::test_on_device_grid_matches_the_reference_pipeline_to_one_ulp)."""
     lib = C.load()
     C.require_gpu_tensor("params", params, dtype=torch.int32)
     if params.dim() != 2 or params.shape[1] != 4:

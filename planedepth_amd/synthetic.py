@@ -136,7 +136,7 @@ def crop_params(B, H, W, seed=0, crop=True, full=(375, 1242)):
 
 def kitti_like_inputs_on_device(B, H, W, seed=0, *, crop=True, novel_frame_ids=(), device="cuda"):
     """``kitti_like_inputs`` produced ON the device: images from a device generator, ``grid`` by
-    the ``pd_crop_grid`` kernel (bit-identical to the reference's linspace/meshgrid/crop), K / inv_K / Rt constants
+    the ``pd_crop_grid`` kernel (the reference's linspace/meshgrid/crop to one ulp), K / inv_K / Rt constants
     uploaded once.  What a data-loader-free end-to-end step (bench.py --ddp_step) feeds the networks."""
     from . import ops
     g = torch.Generator(device=device).manual_seed(seed)

@@ -168,7 +168,7 @@ __global__ void fill(float* p, size_t n, unsigned seed) {
     p[i] = (float)(h & 0xFFFFFF) * (1.0f / 16777216.0f);
   }
 }
-__global__ void fill_k(int* k, int n, int N, int W) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) k[i] = (int)(300.0f * (W / 640.0f) * powf(2.0f / 300.0f, (float)(i % N) / (N - 1))); }
+__global__ void fill_k(int* k, int n, int N, int W, int even) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { int v = (int)(300.0f * (W / 640.0f) * powf(2.0f / 300.0f, (float)(i % N) / (N - 1))); k[i] = even ? (v & ~1) : v; } }
 
 template <class F> static double time_ms(F f, int iters = 20) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -191,15 +191,16 @@ template <int P, int D, int K, int MODE, int WAVES = 4, int OCC = 4> static void
 
 // ---- forward shape: TARGET-ordered (the softmax state lives with the target pixel), two target pixels per lane, the
 // taps of plane n at xt + k_n: one 12-byte load per tensor at 4-byte alignment, colour taps out of LDS at the same
-// shift, K VALU per pixel-plane; waves = (segment, plane half), the second half parks its state for the first.
-template <int D, int K, int WAVES, int OCC>
+// shift, K VALU per pixel-plane.  A wave owns SEGS consecutive 128-pixel segments and a share of the planes; per plane it
+// walks its segments in order (SEGS = 1: one segment, hopping from plane to plane).
+template <int D, int K, int WAVES, int OCC, int SEGS>
 __global__ __launch_bounds__(WAVES * 64, OCC) void fwdstream(const float* __restrict__ A, const float* __restrict__ Bt,
                                                              const float* __restrict__ ctx_src, const int* __restrict__ kshift,
                                                              float* __restrict__ outp, int N, int H, int W, int Bn) {
   extern __shared__ v4f lds[];
   const int RS = W + 8;
-  v4f* col = lds;                 // [RS] colour row with guard cells
-  float* park = reinterpret_cast<float*>(lds + RS);   // [nseg][8][128]
+  v4f* col = lds;
+  float* park = reinterpret_cast<float*>(lds + RS);
   const int id = blockIdx.x, b = id % Bn, y = id / Bn;
   const long HW = (long)H * W;
   for (int x = threadIdx.x; x < RS; x += blockDim.x) {
@@ -210,75 +211,87 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void fwdstream(const float* __rest
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nseg = (W + 127) / 128, split = WAVES / nseg;       // waves per segment
-  const int seg = wave / split, part = wave - seg * split;
+  const int nseg = (W + 127) / 128, ngrp = nseg / SEGS, split = WAVES / ngrp;   // waves per segment group
+  const int grp = wave / split, part = wave - grp * split;
   const int n0 = N * part / split, n1 = N * (part + 1) / split;
-  const int xt = seg * 128 + lane * 2;
+  const int xt0 = grp * SEGS * 128 + lane * 2;
   const float* Ab = A + (long)b * N * HW + (long)y * W; const float* Bb = Bt + (long)b * N * HW + (long)y * W;
-  const float* tp = ctx_src + ((long)b * 13 + 3) * HW + (long)y * W + min(xt, W - 2);
-  float t[6] = {tp[0], tp[1], tp[HW], tp[HW + 1], tp[2 * HW], tp[2 * HW + 1]};
-  float acc[16];
+  float t[SEGS][6], acc[SEGS][16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int j = 0; j < SEGS; ++j) {
+    const float* tp = ctx_src + ((long)b * 13 + 3) * HW + (long)y * W + min(xt0 + j * 128, W - 2);
+    t[j][0] = tp[0]; t[j][1] = tp[1]; t[j][2] = tp[HW]; t[j][3] = tp[HW + 1]; t[j][4] = tp[2 * HW]; t[j][5] = tp[2 * HW + 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  }
   struct G { float a[3], b[3]; };
-  auto issue = [&](G& g, int n_raw) {
-    const int n = min(n_raw, n1 - 1);
+  const int items = (n1 - n0) * SEGS;      // (plane, segment) pairs, segment innermost
+  auto issue = [&](G& g, int it_raw) {
+    const int it = min(it_raw, items - 1), n = n0 + it / SEGS, j = it % SEGS;
     const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
-    const unsigned off = (unsigned)(xt + k) * 4;
+    const unsigned off = (unsigned)(xt0 + j * 128 + k) * 4;
     const v3f va = ld3(rsrc(Ab + (unsigned)(n * (int)HW), W * 4), off), vb = ld3(rsrc(Bb + (unsigned)(n * (int)HW), W * 4), off);
     g.a[0] = va.x; g.a[1] = va.y; g.a[2] = va.z; g.b[0] = vb.x; g.b[1] = vb.y; g.b[2] = vb.z;
   };
-  auto compute = [&](const G& g, int n) {
+  auto compute = [&](const G& g, int n, int j) {
     const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
-    const v4f* cp = col + min(max(xt + k, -4), W + 1) + 4;
+    const v4f* cp = col + min(max(xt0 + j * 128 + k, -4), W + 1) + 4;
     const v4f c0 = cp[0], c1 = cp[1], c2 = cp[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float l = g.a[i] * 0.25f + g.a[i + 1] * 0.75f, s = g.b[i] * 0.25f + g.b[i + 1] * 0.75f;
       const v4f ca = i ? c1 : c0, cb = i ? c2 : c1;
       const float cr = ca.x * 0.25f + cb.x * 0.75f, cg = ca.y * 0.25f + cb.y * 0.75f, cbl = ca.z * 0.25f + cb.z * 0.75f;
-      const float r = burn<K>(l + t[i], s + t[2 + i], cr + t[4 + i], cg + cbl);
-      acc[i * 8 + 0] += r; acc[i * 8 + 1] += l; acc[i * 8 + 2] += s * r; acc[i * 8 + 3] += cr * r;
-      acc[i * 8 + 4] += cg * r; acc[i * 8 + 5] += cbl * r; acc[i * 8 + 6] += r * l; acc[i * 8 + 7] += r * s;
+      const float r = burn<K>(l + t[j][i], s + t[j][2 + i], cr + t[j][4 + i], cg + cbl);
+      acc[j][i * 8 + 0] += r; acc[j][i * 8 + 1] += l; acc[j][i * 8 + 2] += s * r; acc[j][i * 8 + 3] += cr * r;
+      acc[j][i * 8 + 4] += cg * r; acc[j][i * 8 + 5] += cbl * r; acc[j][i * 8 + 6] += r * l; acc[j][i * 8 + 7] += r * s;
     }
   };
+  // software pipeline over the item list; the unroll factor is a multiple of SEGS so that the segment index is static
+  constexpr int UN = (D + 1) * SEGS;
   G g[D + 1];
 #pragma unroll
-  for (int j = 0; j < D; ++j) issue(g[j], n0 + j);
-  int n = n0;
-  for (; n + (D + 1) <= n1; n += D + 1) {
+  for (int q = 0; q < D; ++q) issue(g[q], q);
+  int it = 0;
+  for (; it + UN <= items; it += UN) {
 #pragma unroll
-    for (int j = 0; j <= D; ++j) { issue(g[(j + D) % (D + 1)], n + j + D); compute(g[j], n + j); }
+    for (int q = 0; q < UN; ++q) { issue(g[(q + D) % (D + 1)], it + q + D); compute(g[q % (D + 1)], n0 + (it + q) / SEGS, q % SEGS); }
   }
 #pragma unroll
-  for (int j = 0; j <= D; ++j) if (n + j < n1) { issue(g[(j + D) % (D + 1)], n + j + D); compute(g[j], n + j); }
+  for (int q = 0; q < UN; ++q) if (it + q < items) { issue(g[(q + D) % (D + 1)], it + q + D); compute(g[q % (D + 1)], n0 + (it + q) / SEGS, q % SEGS); }
   if (part > 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) park[((seg * (split - 1) + part - 1) * 16 + i) * 64 + lane] = acc[i];
+    for (int j = 0; j < SEGS; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) park[(((grp * (split - 1) + part - 1) * SEGS + j) * 16 + i) * 64 + lane] = acc[j][i];
   }
   __syncthreads();
   if (part == 0) {
-    for (int p2 = 1; p2 < split; ++p2)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += park[((seg * (split - 1) + p2 - 1) * 16 + i) * 64 + lane];
-    if (xt < W) {
+    for (int j = 0; j < SEGS; ++j) {
+      for (int p2 = 1; p2 < split; ++p2)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        v2f v = {acc[c], acc[8 + c]};
-        *reinterpret_cast<v2f*>(outp + ((long)b * 8 + c) * HW + (long)y * W + xt) = v;
+        for (int i = 0; i < 16; ++i) acc[j][i] += park[(((grp * (split - 1) + p2 - 1) * SEGS + j) * 16 + i) * 64 + lane];
+      const int xt = xt0 + j * 128;
+      if (xt < W) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          v2f v = {acc[j][c], acc[j][8 + c]};
+          *reinterpret_cast<v2f*>(outp + ((long)b * 8 + c) * HW + (long)y * W + xt) = v;
+        }
       }
     }
   }
 }
 
-template <int D, int K, int WAVES, int OCC> static void runf(int B, int N, int H, int W) {
-  const int nseg = (W + 127) / 128, split = WAVES / nseg;
+template <int D, int K, int WAVES, int OCC, int SEGS = 1> static void runf(int B, int N, int H, int W) {
+  const int nseg = (W + 127) / 128, split = WAVES / (nseg / SEGS);
   const size_t ldsb = (size_t)(W + 8) * 16 + (size_t)nseg * (split - 1) * 16 * 64 * 4 + 64;
-  CK(hipFuncSetAttribute((const void*)fwdstream<D, K, WAVES, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-  const double ms = time_ms([&] { fwdstream<D, K, WAVES, OCC><<<dim3(H * B), WAVES * 64, ldsb>>>(A, Bt, ctx, ks, GA, N, H, W, B); });
+  CK(hipFuncSetAttribute((const void*)fwdstream<D, K, WAVES, OCC, SEGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  const double ms = time_ms([&] { fwdstream<D, K, WAVES, OCC, SEGS><<<dim3(H * B), WAVES * 64, ldsb>>>(A, Bt, ctx, ks, GA, N, H, W, B); });
   CK(hipGetLastError());
   const double bytes = (double)B * H * W * 4 * (2 * N + 9 + 8);
-  printf("FWD W=%4d D=%d K=%3d waves=%d occ=%d lds=%zu  %7.3f ms  %7.1f GB/s\n", W, D, K, WAVES, OCC, ldsb, ms, bytes / 1e9 / (ms * 1e-3));
+  printf("FWD W=%4d D=%d K=%3d waves=%d occ=%d segs=%d lds=%zu  %7.3f ms  %7.1f GB/s\n", W, D, K, WAVES, OCC, SEGS, ldsb, ms, bytes / 1e9 / (ms * 1e-3));
 }
 
 int main(int argc, char** argv) {
@@ -287,7 +300,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&A, n * 4 + 4096)); CK(hipMalloc(&Bt, n * 4 + 4096)); CK(hipMalloc(&GA, n * 4 + 4096)); CK(hipMalloc(&GB, n * 4 + 4096));
   CK(hipMalloc(&ctx, (size_t)B * 13 * H * W * 4)); CK(hipMalloc(&ks, B * N * 4)); CK(hipMalloc(&out, 64));
   fill<<<4096, 256>>>(A, n, 1u); fill<<<4096, 256>>>(Bt, n, 7u); fill<<<1024, 256>>>(ctx, (size_t)B * 13 * H * W, 3u);
-  fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W);
+  fill_k<<<(B * N + 255) / 256, 256>>>(ks, B * N, N, W, (argc > 2) ? 1 : 0);   // any second argument: even shifts only
   CK(hipDeviceSynchronize());
   if (argc > 1 && argv[1][0] == 'l') {   // loads alone / stores alone, by width, depth and workgroup size
     run<1, 2, 0, 1>(B, N, H, W); run<2, 2, 0, 1>(B, N, H, W); run<4, 2, 0, 1>(B, N, H, W);
@@ -298,9 +311,12 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'f') {   // forward shape
-    runf<2, 0, 10, 5>(B, N, H, W); runf<3, 0, 10, 5>(B, N, H, W); runf<2, 40, 10, 5>(B, N, H, W); runf<3, 40, 10, 5>(B, N, H, W);
-    runf<3, 60, 10, 5>(B, N, H, W); runf<2, 60, 10, 5>(B, N, H, W); runf<3, 40, 5, 5>(B, N, H, W); runf<3, 60, 5, 5>(B, N, H, W);
-    runf<3, 40, 10, 4>(B, N, H, W); runf<3, 60, 10, 4>(B, N, H, W); runf<3, 40, 15, 5>(B, N, H, W); runf<1, 40, 10, 5>(B, N, H, W);
+    // W = 640: five segments.  One segment per wave (10 waves) against all five per wave (2 or 4 waves = plane halves / quarters)
+    runf<2, 0, 10, 5>(B, N, H, W); runf<2, 40, 10, 5>(B, N, H, W); runf<1, 40, 10, 5>(B, N, H, W);
+    runf<2, 0, 4, 4, 5>(B, N, H, W); runf<2, 40, 4, 4, 5>(B, N, H, W); runf<1, 40, 4, 4, 5>(B, N, H, W); runf<2, 60, 4, 4, 5>(B, N, H, W);
+    runf<2, 40, 2, 4, 5>(B, N, H, W); runf<2, 40, 4, 3, 5>(B, N, H, W); runf<3, 40, 4, 3, 5>(B, N, H, W);
+    // W = 512: four segments, two per wave (8 waves) against one per wave
+    runf<2, 40, 8, 4>(B, N, H, 512); runf<2, 40, 4, 4, 2>(B, N, H, 512); runf<2, 40, 8, 4, 2>(B, N, H, 512); runf<2, 40, 2, 4, 4>(B, N, H, 512);
     return 0;
   }
   if (argc > 1) {   // calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (scripts/gpu_r3_profile.sh): the row-stream
