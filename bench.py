@@ -278,7 +278,7 @@ def in_step_kernel_times(step, device, iters, skip=0):
     return {k: sum(a.elapsed_time(b) for a, b in v[skip:]) / len(v[skip:]) for k, v in ev.items()}
 
 
-def next_rows_times(args, device, iters=10):
+def next_rows_times(args, device, iters=100):
     """SURVEY.md §8f rows (decoder tail, smoothness loss, post-process) at the headline shape: average ms per call from
     CUDA events around the public operators (the launches are on torch's current stream), with the algorithmic bytes
     each moves.  Reported next to the headline number; not part of `value`."""
@@ -294,15 +294,16 @@ def next_rows_times(args, device, iters=10):
     x0 = int(0.2 * W)
 
     def timed(fn):
-        fn()
-        torch.cuda.synchronize(device)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for a, b in ev:
-            a.record()
+        for _ in range(3):
             fn()
-            b.record()
         torch.cuda.synchronize(device)
-        return sum(a.elapsed_time(b) for a, b in ev) / iters
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):      # back to back, one pair of events around the lot: what a training step sees (the host
+            fn()                    # enqueues ahead of the device where it can; an event pair per call would add its own cost)
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / iters
 
     def tail_fwd():
         with torch.no_grad():
@@ -318,7 +319,7 @@ def next_rows_times(args, device, iters=10):
     disp_leaf = (torch.rand(B, 1, H, W, generator=g) * 50).to(device).requires_grad_(True)
 
     def smooth_fwd_bwd():
-        ops.smooth_loss_disp(disp_leaf[..., x0:], img[..., x0:], 2.0).backward()
+        ops.smooth_loss_disp(disp_leaf, img, 2.0, x0=x0).backward()     # the call compute_losses makes (trainer.py:768)
         disp_leaf.grad = None
 
     Bp = max(1, B // 2)
@@ -350,7 +351,8 @@ def next_rows_times(args, device, iters=10):
         "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
                          "shape": [2 * Bp, N, H, W]},
-        "note": "CUDA-event time around the public operators (includes their Python launch overhead)",
+        "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot (host-paced "
+                "where the Python / autograd overhead exceeds the kernels' time)" % iters,
     }
 
 

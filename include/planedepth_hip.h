@@ -243,6 +243,12 @@ int pd_smooth_loss_fwd(int B, int C, int H, int W, const float* disp, int64_t di
 int pd_smooth_loss_bwd(int B, int C, int H, int W, const float* disp, int64_t disp_stride_b, int64_t disp_stride_h,
                        const float* img, int64_t img_stride_b, int64_t img_stride_c, int64_t img_stride_h, float gamma,
                        const float* g_out, float* g_disp, pd_stream_t stream);
+/* As pd_smooth_loss_bwd, for a crop that drops the first x_pad columns of a wider tensor (trainer.py:768 crops 0.2 W):
+ * g_disp is the gradient of the UNCROPPED disparity, contiguous [B,1,H,W + x_pad], its first x_pad columns written as
+ * the zeros they are — the caller's autograd graph then needs no slice node (a zero-fill and a strided copy per step). */
+int pd_smooth_loss_bwd_padded(int B, int C, int H, int W, int x_pad, const float* disp, int64_t disp_stride_b,
+                              int64_t disp_stride_h, const float* img, int64_t img_stride_b, int64_t img_stride_c,
+                              int64_t img_stride_h, float gamma, const float* g_out, float* g_disp, pd_stream_t stream);
 
 /*
  * Warps of Trainer.generate_post_process_disp (trainer.py:421-466), forward only:

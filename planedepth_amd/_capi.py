@@ -57,6 +57,7 @@ SIGNATURES = {
     "pd_decoder_tail_bwd": (_I, [_I] * 5 + [_P] * 15),
     "pd_smooth_loss_fwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P]),
     "pd_smooth_loss_bwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),
+    "pd_smooth_loss_bwd_padded": (_I, [_I] * 5 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),
     "pd_warp_softmax": (_I, [_I] * 4 + [_F, _I, _P, _P, _P, _P]),
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),

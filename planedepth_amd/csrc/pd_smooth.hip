@@ -76,6 +76,30 @@ __global__ __launch_bounds__(kBlock) void smooth_bwd_kernel(SmoothArgs a, const 
   g_disp[(long)b * a.H * a.W + pix] = g * g_out[0];
 }
 
+// The same with the gradient written into the UNCROPPED tensor: rows of W + x_pad floats whose first x_pad columns (the
+// part trainer.py:768 crops away) get their exact zero here — autograd then has no slice to undo (a zero-fill + a
+// strided copy + three host-side operator calls per step).
+__global__ __launch_bounds__(kBlock) void smooth_bwd_padded_kernel(SmoothArgs a, const float* __restrict__ g_out,
+                                                                   float* __restrict__ g_disp, int x_pad) {
+  const int Wf = a.W + x_pad;
+  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  if (pix >= a.H * Wf) return;
+  const int y = pix / Wf, xf = pix - y * Wf, x = xf - x_pad;
+  float g = 0.0f;
+  if (x >= 0) {
+    const float* db = a.disp + b * a.d_sb;
+    const float* ib = a.img + b * a.i_sb;
+    const float d = db[y * a.d_sh + x];
+    const long ip = y * a.i_sh + x;
+    if (x + 1 < a.W) g += sgn(d - db[y * a.d_sh + x + 1]) * edge_weight(a, ib, ip, ip + 1) * a.inv_nx;
+    if (x > 0)       g -= sgn(db[y * a.d_sh + x - 1] - d) * edge_weight(a, ib, ip - 1, ip) * a.inv_nx;
+    if (y + 1 < a.H) g += sgn(d - db[(y + 1) * a.d_sh + x]) * edge_weight(a, ib, ip, ip + a.i_sh) * a.inv_ny;
+    if (y > 0)       g -= sgn(db[(y - 1) * a.d_sh + x] - d) * edge_weight(a, ib, ip - a.i_sh, ip) * a.inv_ny;
+    g *= g_out[0];
+  }
+  g_disp[(long)b * a.H * Wf + pix] = g;
+}
+
 static int smooth_args(SmoothArgs& a, int B, int C, int H, int W, const float* disp, long d_sb, long d_sh,
                        const float* img, long i_sb, long i_sc, long i_sh, float gamma) {
   PD_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 1 && W > 1, "bad shape (needs H, W >= 2)");
@@ -115,4 +139,16 @@ extern "C" int pd_smooth_loss_bwd(int B, int C, int H, int W, const float* disp,
   PD_REQUIRE(g_out && g_disp, "NULL pointer");
   smooth_bwd_kernel<<<dim3(ceil_div(H * W, kBlock), B), kBlock, 0, (hipStream_t)stream>>>(a, g_out, g_disp);
   return check_launch("smooth_bwd_kernel");
+}
+
+extern "C" int pd_smooth_loss_bwd_padded(int B, int C, int H, int W, int x_pad, const float* disp, int64_t disp_stride_b,
+                                         int64_t disp_stride_h, const float* img, int64_t img_stride_b, int64_t img_stride_c,
+                                         int64_t img_stride_h, float gamma, const float* g_out, float* g_disp,
+                                         pd_stream_t stream) {
+  SmoothArgs a;
+  if (int rc = smooth_args(a, B, C, H, W, disp, disp_stride_b, disp_stride_h, img, img_stride_b, img_stride_c,
+                           img_stride_h, gamma)) return rc;
+  PD_REQUIRE(g_out && g_disp && x_pad >= 0 && (long)H * (W + x_pad) < (1L << 31), "NULL pointer / bad padding");
+  smooth_bwd_padded_kernel<<<dim3(ceil_div(H * (W + x_pad), kBlock), B), kBlock, 0, (hipStream_t)stream>>>(a, g_out, g_disp, x_pad);
+  return check_launch("smooth_bwd_padded_kernel");
 }

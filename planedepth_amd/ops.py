@@ -845,38 +845,48 @@ def _row_strided(name, t):
 
 class _SmoothLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, disp, img, gamma):
+    def forward(ctx, disp, img, gamma, x0):
         lib = C.load()
-        B, Cn, H, W = img.shape
-        if tuple(disp.shape) != (B, 1, H, W):
+        B, Cn, H, Wf = img.shape
+        if tuple(disp.shape) != (B, 1, H, Wf):
             raise ValueError("disp must be [B,1,H,W] matching img, got %s vs %s" % (tuple(disp.shape), tuple(img.shape)))
         disp, img = _row_strided("disp", disp), _row_strided("img", img)
+        W = Wf - x0
         out = torch.empty(1, device=disp.device, dtype=torch.float32)
+        # the crop [..., x0:] is an offset on the two base pointers: same strides, W - x0 columns
+        dptr, iptr = ctypes.c_void_p(disp.data_ptr() + 4 * x0), ctypes.c_void_p(img.data_ptr() + 4 * x0)
         with torch.cuda.device(disp.device):
-            C.check(lib.pd_smooth_loss_fwd(B, Cn, H, W, C.ptr(disp), disp.stride(0), disp.stride(2), C.ptr(img),
+            C.check(lib.pd_smooth_loss_fwd(B, Cn, H, W, dptr, disp.stride(0), disp.stride(2), iptr,
                                            img.stride(0), img.stride(1), img.stride(2), float(gamma), C.ptr(out),
                                            C.stream_handle(disp.device)), "pd_smooth_loss_fwd")
         ctx.save_for_backward(disp, img)
-        ctx.gamma = float(gamma)
+        ctx.gamma, ctx.x0 = float(gamma), int(x0)
         return out.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         lib = C.load()
         disp, img = ctx.saved_tensors
-        B, Cn, H, W = img.shape
-        g_disp = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        B, Cn, H, Wf = img.shape
+        x0 = ctx.x0
+        g_disp = torch.empty(B, 1, H, Wf, device=disp.device, dtype=torch.float32)
         g = g.reshape(1).contiguous().float()
+        dptr, iptr = ctypes.c_void_p(disp.data_ptr() + 4 * x0), ctypes.c_void_p(img.data_ptr() + 4 * x0)
         with torch.cuda.device(disp.device):
-            C.check(lib.pd_smooth_loss_bwd(B, Cn, H, W, C.ptr(disp), disp.stride(0), disp.stride(2), C.ptr(img),
-                                           img.stride(0), img.stride(1), img.stride(2), ctx.gamma, C.ptr(g),
-                                           C.ptr(g_disp), C.stream_handle(disp.device)), "pd_smooth_loss_bwd")
-        return g_disp, None, None
+            # one kernel writes the whole [B,1,H,W] gradient, zeros in the cropped-away columns included
+            C.check(lib.pd_smooth_loss_bwd_padded(B, Cn, H, Wf - x0, x0, dptr, disp.stride(0), disp.stride(2), iptr,
+                                                  img.stride(0), img.stride(1), img.stride(2), ctx.gamma, C.ptr(g),
+                                                  C.ptr(g_disp), C.stream_handle(disp.device)), "pd_smooth_loss_bwd_padded")
+        return g_disp, None, None, None
 
 
-def smooth_loss_disp(disp, img, gamma=1.0):
-    """get_smooth_loss_disp (reference layers.py:243-256) as one kernel each way; crops are read in place."""
-    return _SmoothLoss.apply(disp, img, gamma)
+def smooth_loss_disp(disp, img, gamma=1.0, x0=0):
+    """get_smooth_loss_disp (reference layers.py:243-256) as one kernel each way.  ``x0``: evaluate on the crop
+    ``[..., x0:]`` of both tensors (trainer.py:768 passes ``disp[..., int(0.2 * W):]``) WITHOUT slicing them in the autograd
+    graph: the crop is a pointer offset in the forward, and the backward writes the gradient of the uncropped ``disp``
+    directly (zeros left of the crop) — no slice node, i.e. no zero-fill, strided copy and three operator calls per step.
+    Tensors that already are crops (``x0 = 0``) are read in place through their strides as before."""
+    return _SmoothLoss.apply(disp, img, gamma, int(x0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,6 @@ import os
 import torch
 
 from . import ops
-from .layers import get_smooth_loss_disp
 
 
 class SweepHandle:
@@ -231,8 +230,9 @@ def compute_losses(self, inputs, outputs):
     for k in list(losses.keys()):
         losses[k] = losses[k] / n_sides
 
-    smooth_loss = get_smooth_loss_disp(outputs["disp"][..., int(0.2 * W):], inputs[("color", "l")][..., int(0.2 * W):],
-                                       gamma=opt.gamma_smooth)
+    # trainer.py:768 crops both operands at 0.2 W; the crop goes into the operator (ops.smooth_loss_disp, x0) so that
+    # autograd has no slice to undo
+    smooth_loss = ops.smooth_loss_disp(outputs["disp"], inputs[("color", "l")], opt.gamma_smooth, x0=int(0.2 * W))
     losses["loss/smooth_loss"] = smooth_loss
     losses["loss/total_loss"] = losses["loss/total_loss"] + opt.alpha_smooth * smooth_loss
     return losses
