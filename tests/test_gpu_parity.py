@@ -667,6 +667,14 @@ def test_smooth_loss_against_reference_vector_and_oracle():
     (got * 3.0).backward()
     assert rel_err(got.detach().cpu(), want.detach().float()) < TOL
     assert rel_err(dg.grad.cpu(), d64.grad.float()) < TOL
+    # the form compute_losses uses: the crop as an operator argument (pointer offset forward, the uncropped gradient with
+    # its zeros written by the backward kernel — no slice node in the graph): the same numbers, bit for bit
+    from planedepth_amd import ops
+    dx = disp.cuda().requires_grad_(True)
+    gotx = ops.smooth_loss_disp(dx, img.cuda(), 2.0, x0=x0)
+    (gotx * 3.0).backward()
+    assert torch.equal(gotx.detach(), got.detach()) and torch.equal(dx.grad, dg.grad)
+    assert float(dx.grad[..., :x0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("tag", ["xy", "rows"])
