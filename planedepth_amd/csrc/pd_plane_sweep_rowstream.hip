@@ -43,7 +43,8 @@ namespace pd {
 #define PD_STREAM_D2 1   // two live source rows: twice the registers per group; depth 2 costs the third resident workgroup (90 vs 77 VGPRs)
 #endif
 #ifndef PD_STREAM_WAVES
-#define PD_STREAM_WAVES 8   // waves per row workgroup (512 threads: two workgroups per CU at 192x640, one at 384x1280)
+#define PD_STREAM_WAVES 8   // waves per row workgroup: 42 KB of LDS per 640-pixel row -> three workgroups = 24 waves per CU
+                            // (4 / 12 / 16 waves measured 0.193 / 0.183 / 0.230 ms against 0.176-0.186; rows wider than ~800: 2x)
 #endif
 #ifndef PD_STREAM_ABL
 #define PD_STREAM_ABL 0  // timing experiments only (wrong results): 1 no context reads, 2 no per-plane gradient math,
@@ -55,14 +56,8 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_LOAD_AUX
 #define PD_STREAM_LOAD_AUX 0    // same for the tap loads
 #endif
-#ifndef PD_STREAM_GENERAL_INLINE
-#define PD_STREAM_GENERAL_INLINE __forceinline__   // the rare general path: inline or a call (__noinline__)
-#endif
-#ifndef PD_STREAM_LDS_PAD
-#define PD_STREAM_LDS_PAD 0   // experiments: extra LDS bytes per workgroup (occupancy studies)
-#endif
 #ifndef PD_STREAM_OCC
-#define PD_STREAM_OCC 4  // waves per SIMD the register allocator must leave room for
+#define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 77 = 6 waves per SIMD
 #endif
 
 constexpr int kSlots = 2;               // source slots per lane
@@ -220,7 +215,8 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
 // floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
 // Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
 template <bool MIX, int NROWS>
-__device__ PD_STREAM_GENERAL_INLINE float stream_general_slot(const SweepArgs& a, const BwdOut& o, const StreamRow& r,
+__device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs + scratch — measured)
+    const SweepArgs& a, const BwdOut& o, const StreamRow& r,
                                                      const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
                                                      float Wm1, float rcpWm1) {
   const int W = a.W;
@@ -470,7 +466,7 @@ __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, fl
 // ---------------------------------------------------------------------------------------------------------------
 static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves) {
   const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
-  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16 + PD_STREAM_LDS_PAD;
+  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
 }
 static int rowstream_waves(const pd_sweep_desc* d) {
   const int items = d->N * ceil_div(d->W, kSeg);
