@@ -218,6 +218,8 @@ def _stream_tol(W):
     (130, 7, 9, "l", True, dict(special_disp=[0.25, 1.0, 63.0, 64.0, 64.00001, 65.5, 127.99999, 129.0, 200.0], disp_min=0.5, disp_max=9.0)),
     (300, 8, 8, "r", False, dict(special_disp=[299.99997, 2.0000002, 1.9999998, 0.99999994, 100.0, 33.333332, 255.0, 256.00003], disp_min=0.5, disp_max=9.0)),
     (1280, 6, 4, "r", True, dict(disp_min=2.0, disp_max=300.0)),
+    (2048, 3, 3, "l", True, dict(disp_min=2.0, disp_max=900.0)),      # 131 KB of context per row: one 16-wave workgroup per CU
+    (2600, 2, 2, "r", True, dict(disp_min=2.0, disp_max=900.0)),      # beyond the LDS: the row-shift / general kernels take over
     # more items than waves / fewer items than waves, L1 loss, per-row disparities with a horizon mask
     (640, 3, 1, "r", True, dict(disp_min=5.0, disp_max=5.0)),
     (130, 3, 2, "r", True, dict(special_disp=[5.0, 9.3], disp_min=0.5, disp_max=9.0)),
