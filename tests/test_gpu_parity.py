@@ -670,12 +670,13 @@ def test_smooth_loss_against_reference_vector_and_oracle():
     assert rel_err(got.detach().cpu(), want.detach().float()) < TOL
     assert rel_err(dg.grad.cpu(), d64.grad.float()) < TOL
     # the form compute_losses uses: the crop as an operator argument (pointer offset forward, the uncropped gradient with
-    # its zeros written by the backward kernel — no slice node in the graph): the same numbers, bit for bit
+    # its zeros written by the backward kernel — no slice node in the graph): the same gradient bit for bit, the same
+    # loss up to the order in which the forward's block sums reach its one atomic word
     from planedepth_amd import ops
     dx = disp.cuda().requires_grad_(True)
     gotx = ops.smooth_loss_disp(dx, img.cuda(), 2.0, x0=x0)
     (gotx * 3.0).backward()
-    assert torch.equal(gotx.detach(), got.detach()) and torch.equal(dx.grad, dg.grad)
+    assert abs(float(gotx) - float(got)) <= 4e-7 * abs(float(got)) and torch.equal(dx.grad, dg.grad)
     assert float(dx.grad[..., :x0].abs().max()) == 0.0
 
 
