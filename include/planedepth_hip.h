@@ -73,11 +73,13 @@ enum pd_sweep_flags {
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
 
 /* Kernel selection.  The row kernels apply to PD_WARP_DISP with per-plane or per-row disparities (forward:
- * pd_plane_sweep_rowshift.hip, target-ordered; backward: pd_plane_sweep_rowstream.hip, source-ordered); the general
- * kernels handle everything (and are the cross-check for the specialised ones in the tests). */
+ * pd_plane_sweep_rowshift.hip, target-ordered; backward: pd_plane_sweep_rowstream.hip, source-ordered); homography_warp
+ * with one matrix per image (PD_HOMO_UNIFORM) or per plane runs a two-pass gather backward without atomics
+ * (pd_plane_sweep_uniform.hip, pd_plane_sweep_gather.hip); the general kernels handle everything (and are the
+ * cross-check for the specialised ones in the tests). */
 enum pd_sweep_impl {
-  PD_IMPL_AUTO = 0,      /* row kernels where they apply, exact footprints (default) */
-  PD_IMPL_GENERAL = 1,   /* general kernels only (the cross-check in the tests) */
+  PD_IMPL_AUTO = 0,      /* the specialised kernels where they apply, exact footprints (default) */
+  PD_IMPL_GENERAL = 1,   /* general kernels only: atomic scatter in the backward (the cross-check in the tests) */
   PD_IMPL_FAST_ROWS = 2  /* as AUTO, but a second source row whose bilinear weight is below 2^-16 (fp32 noise of the
                             reference's y round trip, <= 6e-6) is dropped: ~11% faster, results within 1e-4 of the
                             tensors' range on random inputs instead of 1e-6 (opt-in) */
@@ -359,9 +361,14 @@ int pd_grid_sample_bwd(int M, int C, int Hi, int Wi, int Ho, int Wo, int padding
  * Diagnostics (used by tests/ and scripts/, not by the product path).
  *   pd_selftest_division        counts, over `count` samples lo + i*step, where the row kernels' fast division by W-1
  *                               (refined reciprocal) differs from the IEEE quotient; *d_mismatches (device int) += count.
- *   pd_debug_poison_lds, pd_debug_count_lds_nans   see below (PD_DEBUG_POISON_LDS=1 makes the Python layer poison before every launch).
+ *   pd_debug_gather_flags, pd_debug_poison_lds, pd_debug_count_lds_nans   see below (PD_DEBUG_POISON_LDS=1 makes the Python layer poison before every launch).
  */
 int pd_selftest_division(float Wm1, int count, float lo, float step, int* d_mismatches, pd_stream_t stream);
+/* The gather backward's device flags of the LAST pd_plane_sweep_bwd launch that used `workspace` with this descriptor
+ * (per-plane homographies, PD_IMPL_AUTO): host_out[0] = 1 if some plane was irregular (line at infinity near the view,
+ * strong minification, non-finite matrix) and took the atomic fix-up, host_out[1] = 1 if a gather window was cut at its
+ * size limit (a plane the prepare kernel should have sent to the fix-up: always 0 in the tests).  Synchronises `stream`. */
+int pd_debug_gather_flags(const pd_sweep_desc* d, const float* workspace, int* host_out, pd_stream_t stream);
 /* Fills the LDS of the device's CUs with NaNs (a kernel that reads shared memory it never wrote then yields NaNs). */
 int pd_debug_poison_lds(pd_stream_t stream);
 /* *d_count += the NaNs 2048 workgroups find in 32 KB of shared memory they never wrote (checks that the poison sticks). */

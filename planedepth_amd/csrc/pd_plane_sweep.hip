@@ -106,7 +106,9 @@ __global__ __launch_bounds__(kBlock) void sweep_fwd_kernel(SweepArgs a, float* _
 // ---------------------------------------------------------------------------------------------------------------
 // Backward (general: any warp, atomics for the bilinear adjoint)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool MIX>
+// TOSCRATCH (the gather backward's pass 1, pd_plane_sweep_gather.hip): instead of scattering, every pixel writes its
+// per-plane (g_l, g_s) side by side to o.scratch [B][N][H*W] (zeros for masked planes); no ghost lane then.
+template <int MODE, bool MIX, bool TOSCRATCH = false>
 __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float red[];  // [N*K] block accumulators of the plane-parameter gradient
   constexpr int K = (MODE == PD_WARP_DISP) ? 1 : 9;
@@ -117,8 +119,9 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
   // for its first pixel's left taps.  That instruction cost as much as a full one: the L2's atomic unit is busy per
   // (instruction, cache line), not per lane (measured: dropping the left-over atomics halved the scatter time).
   const int lane_id = threadIdx.x & (kWave - 1);
-  const bool ghost = (lane_id == 0);
-  const int pix = (int)((blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * (kWave - 1)) + lane_id - 1;
+  const bool ghost = !TOSCRATCH && (lane_id == 0);
+  const int pix = TOSCRATCH ? (int)(blockIdx.x * kBlock + threadIdx.x)
+                            : (int)((blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * (kWave - 1)) + lane_id - 1;
   const int b = blockIdx.y;
   const bool want_plane = (o.g_plane != nullptr);
   const bool dense = (MODE == PD_WARP_DISP) && (a.flags & PD_DISP_DENSE);
@@ -221,7 +224,13 @@ __global__ __launch_bounds__(kBlock) void sweep_bwd_kernel(SweepArgs a, BwdOut o
 #pragma unroll
       for (int k = 0; k < K; ++k) gk[k] = 0.0f;
     }
-    {  // adjoint of the bilinear gather, all 64 lanes together (pd_common.h: neighbours share their atomics)
+    if (TOSCRATCH) {
+      if (active) {
+        const long e = ((long)b * a.N + n) * HW + pix;
+        if (MIX) reinterpret_cast<float2*>(o.scratch)[e] = make_float2(sg_l, sg_s);
+        else o.scratch[e] = sg_l;
+      }
+    } else {  // adjoint of the bilinear gather, all 64 lanes together (pd_common.h: neighbours share their atomics)
       const long pl = ((long)b * a.N + n) * HW;
 #ifdef PD_GEN_NOSCATTER  // diagnostics: the kernel without its atomics (keeps the values alive through one lane's store)
       if (sg_l + sg_s == 123.456f) o.g_logits[pl] = sg_l;
@@ -468,8 +477,10 @@ extern "C" size_t pd_sweep_bwd_workspace_floats(const pd_sweep_desc* d) {
   const size_t tiles = 0;
 #endif
   const size_t uni = (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) ? uniform_bwd_workspace_floats(d) : 0;
+  const size_t gat = gather_bwd_applicable(d) ? gather_bwd_workspace_floats(d) : 0;
   size_t m = general > rows ? general : rows;
   m = m > tiles ? m : tiles;
+  m = m > gat ? m : gat;
   return m > uni ? m : uni;
 }
 
@@ -533,7 +544,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   SweepArgs ak = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
   BwdOut o;
   o.g_logits = g_logits; o.g_sigma = mix ? g_sigma : nullptr; o.g_plane = g_plane; o.partials = workspace;
-  o.side = nullptr;
+  o.side = nullptr; o.scratch = nullptr;
   o.g_dists = (d->flags & PD_RENDER_PROB) ? g_dists : nullptr;
   o.rgb_rec = rgb_rec; o.stash = stash; o.g_rgb_rec = g_rgb_rec; o.g_ph_map = g_ph_map; o.g_ph_mean = g_ph_mean;
   if (wants_rowshift(d) && rowshift_applicable(d)) {
@@ -561,6 +572,24 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     return PD_ERR_UNSUPPORTED;
   }
 #endif
+  if (gather_bwd_applicable(d) && (g_logits || g_sigma)) {   // one homography per plane: two passes, no atomics (pd_plane_sweep_gather.hip)
+    PD_REQUIRE(workspace, "the gather backward needs workspace (pd_sweep_bwd_workspace_floats)");
+    const GatherPlan gp = gather_bwd_plan(d, workspace);
+    o.partials = gp.partials; o.scratch = gp.scratch;
+    rc = gather_bwd_prepare(d, ak, gp, stream);
+    if (rc) return rc;
+    const dim3 grid1(gp.nblk, d->B);
+    const size_t shmem1 = (size_t)d->N * 9 * sizeof(float);
+    if (mix) sweep_bwd_kernel<PD_WARP_HOMOGRAPHY, true, true><<<grid1, kBlock, shmem1, stream>>>(ak, o);
+    else     sweep_bwd_kernel<PD_WARP_HOMOGRAPHY, false, true><<<grid1, kBlock, shmem1, stream>>>(ak, o);
+    rc = check_launch("sweep_bwd_kernel (scratch)");
+    if (rc) return rc;
+    rc = gather_bwd_finish(d, ak, o, gp, stream);
+    if (rc || !g_plane) return rc;
+    const int M = d->N * 9;
+    reduce_partials_kernel<<<dim3(M, d->B), kWave, 0, stream>>>(gp.partials, g_plane, gp.nblk, M);
+    return check_launch("reduce_partials_kernel");
+  }
   const size_t plane_bytes = (size_t)d->B * d->N * d->H * d->W * sizeof(float);
   const int HW = d->H * d->W;
   dim3 grid(bwd_blocks(HW), d->B);
@@ -578,6 +607,16 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     rc = check_launch("reduce_partials_kernel");
   }
   return rc;
+}
+
+extern "C" int pd_debug_gather_flags(const pd_sweep_desc* d, const float* workspace, int* host_out, pd_stream_t stream) {
+  PD_REQUIRE(d && workspace && host_out, "NULL argument");
+  PD_REQUIRE(gather_bwd_applicable(d), "this descriptor does not run the gather backward");
+  const GatherPlan gp = gather_bwd_plan(d, const_cast<float*>(workspace));
+  if (hipMemcpyAsync(host_out, gp.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return check_launch("pd_debug_gather_flags");
+  return PD_OK;
 }
 
 extern "C" int pd_plane_sweep_layers(const pd_sweep_desc* d, const float* src, const float* logits,

@@ -1,0 +1,259 @@
+// homography_warp with ONE HOMOGRAPHY PER PLANE (6-DoF poses: --use_colmap, reference trainer.py:397-398; any pose with
+// a translation, layers.py:206-219) — the backward without atomics.
+//
+// The general backward (pd_plane_sweep.hip) scatters every sample's gradient into its four taps with atomics and is
+// bound by the L2's atomic unit (1.2 ms at 8x49x192x640, 0.42 ms of it without the scatter).  Here the
+// adjoint of the bilinear gather is turned round, as in the plane-uniform kernels (pd_plane_sweep_uniform.hip), but per
+// plane:
+//   pass 1 = sweep_bwd_kernel<.., TOSCRATCH> (pd_plane_sweep.hip): the target-anchored closed-form gradients, written
+//            side by side as (g_l, g_s) to a scratch [B][N][H*W] with coalesced stores; the homography gradient as before;
+//   pass 2 (this file, one thread per SOURCE pixel, all planes): the target pixels whose bilinear footprint covers the
+//            source pixel are the integer points in the pre-image of the open square s +- 1 under plane n's homography —
+//            located with the inverse matrix (fp64 adjugate, gather_prep_kernel), every candidate CONFIRMED with the
+//            forward's own coordinate chain (plane_coords, bit for bit), which also yields torch's bilinear weight —
+//            g[n][s] = sum_t w(t, s) * scratch[n][t], one plain coalesced store per element: no zero-fill, no atomics,
+//            deterministic.  PD_BWD_ACCUMULATE adds to what is there.
+// Planes whose map is not a moderate, orientation-preserving deformation over the whole image (line at infinity near
+// the view, minification beyond ~3x: nothing a pose produces, but a diverged pose net may) are flagged by the prepare
+// kernel, written as zeros by pass 2 and served by gather_fixup_kernel with atomics out of the same scratch — the same
+// numbers as the general kernel, at its speed, for those planes only.  A plane whose matrix is not finite / not
+// invertible gets no gradient from pass 2 or the fix-up's scatter other than what its finite samples give.
+#include <type_traits>
+
+#include "pd_sweep_geom.h"
+
+namespace pd {
+
+struct GatherPrep {   // per (image, plane)
+  float Hs[9];        // source -> target, from an fp64 adjugate of H_t2s
+  float regular;      // 1: pass 2 gathers this plane; 0: the fix-up kernel scatters it
+  float pad[2];
+};
+constexpr int kGatherPrepFloats = sizeof(GatherPrep) / sizeof(float);
+
+// A sample reaches source pixel s iff it lies in the open square s +- 1.  The square is grown by 1/256 pixel before it is
+// mapped and the mapped box by another 1/256: the fp32 noise of the forward chain and of the inverse matrix are ~1e-4
+// pixel each at 640 columns (3e-4 at 2048), and every candidate is confirmed with the exact forward coordinates anyway.
+// The margins are kept that tight because they decide how many lanes walk 3 instead of 2 candidates per axis (a wave pays
+// for its longest lane): 1/32 + 1/32 made that 12.5 % of the lanes per axis, these make it 0.8 %.
+constexpr float kGatherReach = 1.00390625f, kGatherSlop = 0.00390625f;
+constexpr int kGatherSpan = 16;      // columns / rows of a window pass 2 walks at most (regular planes stay below it)
+constexpr int kGatherSpanOk = 7;     // what the prepare kernel accepts on its 5 x 5 sample of the image
+constexpr float kGatherWRatio = 0.7f;  // min |w| / max |w| of the inverse map's denominator over the (grown) image
+
+// Pre-image box of (sx +- reach) x (sy +- reach): integer candidates [x0, x1] x [y0, y1], NOT clamped to the image
+struct GatherWindow { float x0, x1, y0, y1; };
+__device__ __forceinline__ GatherWindow gather_window(const float* __restrict__ Hs, float sx, float sy) {
+  const float u = Hs[0] * sx + Hs[1] * sy + Hs[2], v = Hs[3] * sx + Hs[4] * sy + Hs[5], w = Hs[6] * sx + Hs[7] * sy + Hs[8];
+  float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ex = (k & 1) ? kGatherReach : -kGatherReach, ey = (k & 2) ? kGatherReach : -kGatherReach;
+    const float r = fast_rcp(w + ex * Hs[6] + ey * Hs[7]);   // (1 ulp: far inside the margins)
+    const float x = (u + ex * Hs[0] + ey * Hs[1]) * r, y = (v + ex * Hs[3] + ey * Hs[4]) * r;
+    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+    ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+  }
+  GatherWindow g;
+  g.x0 = ceilf(xmin - kGatherSlop); g.x1 = floorf(xmax + kGatherSlop);
+  g.y0 = ceilf(ymin - kGatherSlop); g.y1 = floorf(ymax + kGatherSlop);
+  return g;
+}
+
+// flags[0]: some plane of the launch is irregular (the fix-up kernel has work); flags[1]: windows pass 2 cut at kGatherSpan
+// (stays 0 unless the prepare kernel's sample missed a strongly non-uniform map; tests read it)
+__global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* __restrict__ prep, int* __restrict__ flags,
+                                   int BN, int W, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BN) return;
+  const float* h = H_t2s + (long)i * 9;
+  const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], k = h[7], l = h[8];
+  const double A = e * l - f * k, Bc = -(d * l - f * g), C = d * k - e * g;
+  const double det = a * A + b * Bc + c * C, inv = 1.0 / det;
+  GatherPrep p;
+  p.Hs[0] = (float)(A * inv);  p.Hs[1] = (float)(-(b * l - c * k) * inv); p.Hs[2] = (float)((b * f - c * e) * inv);
+  p.Hs[3] = (float)(Bc * inv); p.Hs[4] = (float)((a * l - c * g) * inv);  p.Hs[5] = (float)(-(a * f - c * d) * inv);
+  p.Hs[6] = (float)(C * inv);  p.Hs[7] = (float)(-(a * k - b * g) * inv); p.Hs[8] = (float)((a * e - b * d) * inv);
+  bool ok = (det == det) && fabs(det) > 1e-30 && fabs(inv) < 1e30;
+  for (int j = 0; j < 9; ++j) ok = ok && (fabsf(p.Hs[j]) < 1e30f) && (p.Hs[j] == p.Hs[j]);
+  if (ok) {   // the denominator is affine in the source position: its extremes over the grown image are at the corners
+    float wmin = 3.0e38f, wmax = -3.0e38f;
+    for (int q = 0; q < 4; ++q) {
+      const float x = (q & 1) ? (float)(W - 1) + kGatherReach : -kGatherReach, y = (q & 2) ? (float)(H - 1) + kGatherReach : -kGatherReach;
+      const float w = p.Hs[6] * x + p.Hs[7] * y + p.Hs[8];
+      wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
+    }
+    ok = (wmin * wmax > 0.0f) && (fminf(fabsf(wmin), fabsf(wmax)) >= kGatherWRatio * fmaxf(fabsf(wmin), fabsf(wmax)));
+  }
+  if (ok) {   // window sizes on a 5 x 5 sample of the source image
+    for (int qy = 0; qy < 5 && ok; ++qy)
+      for (int qx = 0; qx < 5 && ok; ++qx) {
+        const GatherWindow w = gather_window(p.Hs, (float)(W - 1) * 0.25f * qx, (float)(H - 1) * 0.25f * qy);
+        ok = (w.x1 - w.x0 + 1.0f <= (float)kGatherSpanOk) && (w.y1 - w.y0 + 1.0f <= (float)kGatherSpanOk);   // (false for NaN)
+      }
+  }
+  p.regular = ok ? 1.0f : 0.0f;
+  p.pad[0] = p.pad[1] = 0.0f;
+  prep[i] = p;
+  if (!ok) atomicOr(&flags[0], 1);
+}
+
+__global__ void gather_clear_flags_kernel(int* __restrict__ flags) { flags[threadIdx.x] = 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 2
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kGatherTileW = 32, kGatherTileH = kBlock / kGatherTileW;
+
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void gather_bwd_pass2_kernel(SweepArgs a, const float* __restrict__ tmp,
+                                                                  const GatherPrep* __restrict__ prep,
+                                                                  float* __restrict__ g_logits, float* __restrict__ g_sigma,
+                                                                  int* __restrict__ flags, int tiles_x, int accumulate) {
+  typedef typename std::conditional<MIX, float2, float>::type Elem;
+  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int blk = xcd_banded(blockIdx.x, gridDim.x);
+  const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
+  const int sx = txi * kGatherTileW + (tid & (kGatherTileW - 1)), sy = tyi * kGatherTileH + tid / kGatherTileW;
+  if (sx >= W || sy >= H) return;
+  const CoordNorm cn = make_coord_norm(W, H);
+  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp) + (long)b * N * HW;
+  const long s_off = (long)b * N * HW + (long)sy * W + sx;
+  float* gl = g_logits ? g_logits + s_off : nullptr;
+  float* gs = (MIX && g_sigma) ? g_sigma + s_off : nullptr;
+  const float fsx = (float)sx, fsy = (float)sy;
+  bool cut = false;
+  for (int n = 0; n < N; ++n) {
+    const GatherPrep* pr = prep + (long)b * N + n;   // workgroup-uniform
+    const long base = (long)n * HW;
+    if (pr->regular == 0.0f) {   // the fix-up kernel adds this plane's gradient with atomics
+      if (!accumulate) {
+        if (gl) gl[base] = 0.0f;
+        if (gs) gs[base] = 0.0f;
+      }
+      continue;
+    }
+    float accl = 0.0f, accs = 0.0f;
+    if (accumulate) {   // requested ahead of the window scan
+      if (gl) accl = gl[base];
+      if (gs) accs = gs[base];
+    }
+    const GatherWindow win = gather_window(pr->Hs, fsx, fsy);
+    const int x0 = (int)fminf(fmaxf(win.x0, 0.0f), (float)W), y0 = (int)fminf(fmaxf(win.y0, 0.0f), (float)H);
+    int x1 = (int)fminf(fmaxf(win.x1, -1.0f), (float)(W - 1)), y1 = (int)fminf(fmaxf(win.y1, -1.0f), (float)(H - 1));
+    if (x1 - x0 >= kGatherSpan) { x1 = x0 + kGatherSpan - 1; cut = true; }
+    if (y1 - y0 >= kGatherSpan) { y1 = y0 + kGatherSpan - 1; cut = true; }
+    // one flat walk over the window: a wave runs as many steps as its largest window has points (4 for most lanes)
+    const int wx = x1 - x0 + 1, cnt = (x1 >= x0 && y1 >= y0) ? wx * (y1 - y0 + 1) : 0;
+    int tx = x0, ty = y0;
+    for (int j = 0; j < cnt; ++j) {
+      bool mk;
+      const PlaneGeom g = plane_coords<PD_WARP_HOMOGRAPHY>(a, cn, b, n, tx, ty, 0.0f, mk);
+      const float w = tap_weight_on(g.ix, g.iy, sx, sy);
+      if (w != 0.0f) {   // (masked planes of a pixel are zeros in the scratch)
+        const Elem v = tmp_b[base + ty * W + tx];
+        if constexpr (MIX) { accl += w * v.x; accs += w * v.y; }
+        else accl += w * v;
+      }
+      if (++tx > x1) { tx = x0; ++ty; }
+    }
+    if (gl) gl[base] = accl;
+    if (gs) gs[base] = accs;
+  }
+  if (cut) atomicOr(&flags[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// irregular planes: scatter out of the scratch with atomics (target-anchored; returns at once when there are none)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void gather_fixup_kernel(SweepArgs a, const float* __restrict__ tmp,
+                                                              const GatherPrep* __restrict__ prep,
+                                                              float* __restrict__ g_logits, float* __restrict__ g_sigma,
+                                                              const int* __restrict__ flags) {
+  if (flags[0] == 0) return;
+  typedef typename std::conditional<MIX, float2, float>::type Elem;
+  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
+  const int pix = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+  if (pix >= HW) return;
+  const int y = pix / W, x = pix - y * W;
+  const CoordNorm cn = make_coord_norm(W, H);
+  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp) + (long)b * N * HW;
+  for (int n = 0; n < N; ++n) {
+    if (prep[(long)b * N + n].regular != 0.0f) continue;
+    const Elem v = tmp_b[(long)n * HW + pix];
+    float vl, vs = 0.0f;
+    if constexpr (MIX) { vl = v.x; vs = v.y; } else vl = v;
+    if (vl == 0.0f && vs == 0.0f) continue;   // masked or without gradient
+    bool mk;
+    const PlaneGeom g = plane_coords<PD_WARP_HOMOGRAPHY>(a, cn, b, n, x, y, 0.0f, mk);
+    const Tap t = make_tap(g.ix, g.iy, W, H);
+    const long pl = ((long)b * N + n) * HW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool right = k & 1, down = k & 2;
+      const bool valid = (right ? t.vx1 : t.vx0) && (down ? t.vy1 : t.vy0);
+      const float w = (right ? t.wx1 : t.wx0) * (down ? t.wy1 : t.wy0);
+      if (valid && w != 0.0f) {
+        const long e = pl + (long)(t.y0 + (down ? 1 : 0)) * W + (t.x0 + (right ? 1 : 0));
+        if (g_logits && vl != 0.0f) unsafeAtomicAdd(g_logits + e, w * vl);
+        if (MIX && g_sigma && vs != 0.0f) unsafeAtomicAdd(g_sigma + e, w * vs);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static size_t galign4(size_t floats) { return (floats + 3) & ~(size_t)3; }
+
+bool gather_bwd_applicable(const pd_sweep_desc* d) {
+  return d->mode == PD_WARP_HOMOGRAPHY && !(d->flags & PD_HOMO_UNIFORM) && d->impl == PD_IMPL_AUTO;
+}
+
+// workspace: partial sums [B][nblk][N*9] | GatherPrep[B*N] | flags (4 ints) | scratch [B][N][H*W] (x2 with PD_MIXTURE)
+size_t gather_bwd_workspace_floats(const pd_sweep_desc* d) {
+  const size_t nblk = (size_t)ceil_div(d->H * d->W, kBlock);
+  const size_t per = (d->flags & PD_MIXTURE) ? 2 : 1;
+  return galign4((size_t)d->B * nblk * d->N * 9) + galign4((size_t)d->B * d->N * kGatherPrepFloats) + 4 +
+         per * (size_t)d->B * d->N * d->H * d->W + 8;
+}
+
+GatherPlan gather_bwd_plan(const pd_sweep_desc* d, float* workspace) {
+  GatherPlan gp;
+  const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+  gp.nblk = ceil_div(d->H * d->W, kBlock);
+  gp.partials = reinterpret_cast<float*>(base);
+  float* prep = gp.partials + galign4((size_t)d->B * gp.nblk * d->N * 9);
+  gp.prep = prep;
+  gp.flags = reinterpret_cast<int*>(prep + galign4((size_t)d->B * d->N * kGatherPrepFloats));
+  gp.scratch = reinterpret_cast<float*>(gp.flags) + 4;
+  return gp;
+}
+
+int gather_bwd_prepare(const pd_sweep_desc* d, const SweepArgs& a, const GatherPlan& gp, hipStream_t stream) {
+  gather_clear_flags_kernel<<<1, 4, 0, stream>>>(gp.flags);
+  const int BN = d->B * d->N;
+  gather_prep_kernel<<<ceil_div(BN, 64), 64, 0, stream>>>(a.plane, reinterpret_cast<GatherPrep*>(gp.prep), gp.flags, BN, d->W, d->H);
+  return check_launch("gather_prep_kernel");
+}
+
+int gather_bwd_finish(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, const GatherPlan& gp, hipStream_t stream) {
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
+  const int tiles_x = ceil_div(d->W, kGatherTileW);
+  const dim3 grid2(tiles_x * ceil_div(d->H, kGatherTileH), d->B), grid1(ceil_div(d->H * d->W, kBlock), d->B);
+  const GatherPrep* prep = reinterpret_cast<const GatherPrep*>(gp.prep);
+  if (mix) {
+    gather_bwd_pass2_kernel<true><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags, tiles_x, accumulate);
+    gather_fixup_kernel<true><<<grid1, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags);
+  } else {
+    gather_bwd_pass2_kernel<false><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags, tiles_x, accumulate);
+    gather_fixup_kernel<false><<<grid1, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags);
+  }
+  return check_launch("gather_bwd_pass2_kernel / gather_fixup_kernel");
+}
+
+}  // namespace pd

@@ -285,17 +285,6 @@ __global__ void uniform_prep_kernel(const float* __restrict__ H_t2s, UniPrep* __
   prep[i] = p;
 }
 
-// bilinear weight with which target sample (ix, iy) reaches source pixel (sx, sy): torch's own expressions
-// (x1 - ix) / (ix - x0) for the tap that IS (sx, sy), zero when neither tap column / row is
-__device__ __forceinline__ float tap_weight_on(float ix, float iy, int sx, int sy) {
-  const float xf = floorf(ix), yf = floorf(iy);
-  const float fsx = (float)sx, fsy = (float)sy;
-  float wx = 0.0f, wy = 0.0f;
-  if (xf == fsx) wx = (xf + 1.0f) - ix; else if (xf + 1.0f == fsx) wx = ix - xf;
-  if (yf == fsy) wy = (yf + 1.0f) - iy; else if (yf + 1.0f == fsy) wy = iy - yf;
-  return wx * wy;
-}
-
 // A sample reaches source pixel s iff it lies in the open square s +- 1; the square is grown by 1/32 pixel before it is
 // mapped and the mapped box by another 1/32: the forward chain's fp32 noise and the fp64-adjugate inverse's error are both
 // below 1e-3 pixel, and every candidate is confirmed with the exact forward coordinates anyway.

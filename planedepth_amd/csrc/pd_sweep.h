@@ -45,6 +45,7 @@ struct BwdOut {
   float* g_dists;   // PD_RENDER_PROB only (may be NULL)
   float* partials;  // per-block partial sums of the plane-parameter gradient
   float* side;      // row-shift backward: global spill of the rare out-of-segment records (see route())
+  float* scratch;   // gather backward, pass 1: per-pixel, per-plane (g_l, g_s) [B][N][H*W] (float2 with PD_MIXTURE)
   const float* rgb_rec;
   const float* stash;
   const float* g_rgb_rec;
@@ -278,6 +279,15 @@ int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float*
 // Plane-uniform homography (pd_plane_sweep_uniform.hip, PD_HOMO_UNIFORM)
 int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
 int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+
+// Per-plane homographies (6-DoF poses) without atomics (pd_plane_sweep_gather.hip): pass 1 is sweep_bwd_kernel<.., true>
+// (pd_plane_sweep.hip, launched by the caller between gather_bwd_prepare and gather_bwd_finish).
+bool gather_bwd_applicable(const pd_sweep_desc* d);
+size_t gather_bwd_workspace_floats(const pd_sweep_desc* d);
+struct GatherPlan { float* partials; float* scratch; void* prep; int* flags; int nblk; };
+GatherPlan gather_bwd_plan(const pd_sweep_desc* d, float* workspace);
+int gather_bwd_prepare(const pd_sweep_desc* d, const SweepArgs& a, const GatherPlan& gp, hipStream_t stream);
+int gather_bwd_finish(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, const GatherPlan& gp, hipStream_t stream);
 size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d);
 // partials [B][nblk][M] -> out [B][M], fixed summation order (pd_plane_sweep.hip)
 int reduce_partials(const float* partials, float* out, int nblk, int M, int B, hipStream_t stream);

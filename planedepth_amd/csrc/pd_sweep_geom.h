@@ -70,6 +70,17 @@ __device__ __forceinline__ PlaneGeom plane_coords(const SweepArgs& a, const Coor
   return g;
 }
 
+// bilinear weight with which target sample (ix, iy) reaches source pixel (sx, sy): torch's own expressions
+// (x1 - ix) / (ix - x0) for the tap that IS (sx, sy), zero when neither tap column / row is
+__device__ __forceinline__ float tap_weight_on(float ix, float iy, int sx, int sy) {
+  const float xf = floorf(ix), yf = floorf(iy);
+  const float fsx = (float)sx, fsy = (float)sy;
+  float wx = 0.0f, wy = 0.0f;
+  if (xf == fsx) wx = (xf + 1.0f) - ix; else if (xf + 1.0f == fsx) wx = ix - xf;
+  if (yf == fsy) wy = (yf + 1.0f) - iy; else if (yf + 1.0f == fsy) wy = iy - yf;
+  return wx * wy;
+}
+
 __device__ __forceinline__ bool read_mask(const SweepArgs& a, int b, int n, int x, int y) {
   return a.padding_mask[(((long)b * a.N + n) * a.H + y) * a.W + x] != 0.0f;
 }

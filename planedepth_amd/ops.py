@@ -16,6 +16,7 @@ from . import _capi as C
 SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
+DEBUG_WORKSPACE = None   # diagnostics (tests): set to a list to collect (descriptor, workspace) of every sweep backward
 if int(os.environ.get("PD_DEBUG_POISON_MEM", "0")):
     # diagnostics: every buffer this module allocates uninitialised (outputs, stash, workspaces) starts as NaNs, so a
     # kernel that reads global memory nobody wrote produces NaNs instead of depending on the allocator's leftovers
@@ -147,6 +148,8 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False):
                                     C.ptr(g_logits), C.ptr(g_sigma if mix else None), C.ptr(g_plane), C.ptr(g_dists),
                                     C.ptr(ws), C.stream_handle(logits.device))
     C.check(rc, "pd_plane_sweep_bwd")
+    if DEBUG_WORKSPACE is not None:
+        DEBUG_WORKSPACE.append((d, ws))
     return g_logits, (g_sigma if mix else None), g_plane, g_dists
 
 

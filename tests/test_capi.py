@@ -42,6 +42,10 @@ def test_desc_layout_and_host_queries():
     assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 192 * 49 * (1 + 4 * 10)
     d.mode = C.PD_WARP_HOMOGRAPHY
     assert lib.pd_sweep_stash_floats(ctypes.byref(d)) == 4 * 192 * 640
+    # gather backward (one homography per plane): [B][480 workgroups][N*9] partial sums, 12 floats per (image, plane),
+    # 4 flag words, the (g_l, g_s) scratch [B][N][H*W][2], 8 floats of alignment slack
+    assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 480 * 49 * 9 + 2 * 49 * 12 + 4 + 2 * 2 * 49 * 192 * 640 + 8
+    d.impl = C.PD_IMPL_GENERAL
     # general backward: workgroups of four 63-pixel waves (ceil(192*640 / 252) = 488), nine sums per plane
     assert lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d)) == 2 * 488 * 49 * 9
 

@@ -1544,7 +1544,7 @@ def test_tile_backward_equals_atomic_backward(B, N, H, W, mix):
     _, inv_K = intrinsics(B, H, W)
     flags = (C.PD_MIXTURE if mix else 0) | C.PD_AUTOMASK
     res = {}
-    for impl in (C.PD_IMPL_TILE, C.PD_IMPL_AUTO):
+    for impl in (C.PD_IMPL_TILE, C.PD_IMPL_GENERAL):
         ops.SWEEP_IMPL = impl
         try:
             lg, sg, Hd = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True), Hm.to(dev).requires_grad_(True)
@@ -1555,12 +1555,119 @@ def test_tile_backward_equals_atomic_backward(B, N, H, W, mix):
             res[impl] = (lg.grad.cpu(), sg.grad.cpu() if mix else None, Hd.grad.cpu())
         finally:
             ops.SWEEP_IMPL = C.PD_IMPL_AUTO
-    new, old = res[C.PD_IMPL_TILE], res[C.PD_IMPL_AUTO]
+    new, old = res[C.PD_IMPL_TILE], res[C.PD_IMPL_GENERAL]
     assert float(old[0].abs().max()) > 0
     assert rel_err(new[0], old[0]) < 2e-6, rel_err(new[0], old[0])
     if mix:
         assert rel_err(new[1], old[1]) < 2e-6, rel_err(new[1], old[1])
     assert rel_err(new[2], old[2]) < 5e-5, rel_err(new[2], old[2])   # sums over the image in a different order
+
+
+def _gather_case(B, N, H, W, seed, irregular=False):
+    """Inputs of a per-plane homography sweep far from the identity; ``irregular``: some planes the gather backward must
+    hand to its atomic fix-up (4x minification, the line at infinity inside the view, a NaN and a singular matrix)."""
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(seed)
+    src, tgt = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    logits = torch.randn(B, N, H, W, generator=g)
+    sigma = 0.011 + 0.978 * torch.rand(B, N, H, W, generator=g)
+    gw = torch.randn(B, 3, H, W, generator=g)
+    Hm, Rn = _wild_homographies(B, N, H, W, seed + 1)
+    if irregular:
+        Hm = Hm.clone()
+        Hm[0] = torch.tensor([[0.25, 0.0, 0.3 * W], [0.0, 0.25, 0.3 * H], [0.0, 0.0, 1.0]])      # 16 target pixels per source pixel
+        Hm[1] = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [2.0 / W, 0.0, 0.2]])          # strong perspective
+        if Hm.shape[0] > 3:
+            Hm[2] = float("nan")
+            Hm[3] = 0.0
+        Rn = Rn.clone()
+        Rn[:2] = torch.tensor([0.0, 0.0, 1.0])
+    _, inv_K = intrinsics(B, H, W)
+    return src, tgt, logits, sigma, gw, Hm, Rn, inv_K[:, :3, :3].contiguous()
+
+
+def _run_gather_case(case, impl, mix=True, render=False, dists=None):
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    src, tgt, logits, sigma, gw, Hm, Rn, iK = [t.cuda() for t in case]
+    flags = (C.PD_MIXTURE if mix else 0) | C.PD_AUTOMASK | (C.PD_RENDER_PROB if render else 0)
+    ops.SWEEP_IMPL = impl
+    ops.DEBUG_WORKSPACE = []
+    try:
+        lg, sg, Hd = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True), Hm.clone().requires_grad_(True)
+        dd = dists.cuda().clone().requires_grad_(True) if render else None
+        rgb, ph, ph_mean = ops._PlaneSweep.apply(src, tgt, lg, sg if mix else None, Hd, Rn, iK, None, dd,
+                                                 C.PD_WARP_HOMOGRAPHY, flags, 0.0)
+        (ph_mean * 3.0 + (rgb * gw).sum()).backward()
+        out = dict(g_logits=lg.grad.cpu(), g_sigma=sg.grad.cpu() if mix else None, g_H=Hd.grad.cpu(),
+                   g_dists=dd.grad.cpu() if render else None)
+        flags_out = None
+        if impl == C.PD_IMPL_AUTO:
+            import ctypes
+            d, ws = ops.DEBUG_WORKSPACE[-1]
+            host = (ctypes.c_int * 2)()
+            C.check(C.load().pd_debug_gather_flags(ctypes.byref(d), C.ptr(ws), host, C.stream_handle(ws.device)),
+                    "pd_debug_gather_flags")
+            flags_out = (host[0], host[1])
+        return out, flags_out
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+        ops.DEBUG_WORKSPACE = None
+
+
+@pytest.mark.parametrize("B,N,H,W,mix,irregular", [
+    (2, 5, 40, 150, True, False), (1, 9, 33, 70, True, False), (1, 3, 50, 200, False, False), (1, 4, 5, 7, True, False),
+    (2, 6, 64, 64, True, False), (1, 5, 96, 320, True, False),
+    (2, 5, 40, 150, True, True), (1, 4, 33, 70, False, True), (1, 6, 96, 320, True, True)])
+def test_gather_backward_equals_atomic_backward(B, N, H, W, mix, irregular):
+    """homography_warp with one matrix per plane (6-DoF poses): the two-pass gather backward (pd_plane_sweep_gather.hip,
+    the default) against the atomic scatter (PD_IMPL_GENERAL) — two independent adjoints of the same gather, equal to
+    summation order — on homographies far from the identity, ragged sizes, and with planes the gather hands to its
+    atomic fix-up (minification, line at infinity, NaN and singular matrices)."""
+    from planedepth_amd import _capi as C
+    case = _gather_case(B, N, H, W, 300 + W + N, irregular)
+    new, fl = _run_gather_case(case, C.PD_IMPL_AUTO, mix)
+    new2, _ = _run_gather_case(case, C.PD_IMPL_AUTO, mix)
+    old, _ = _run_gather_case(case, C.PD_IMPL_GENERAL, mix)
+    assert fl == ((1, 0) if irregular else (0, 0)), fl
+    assert float(old["g_logits"].abs().max()) > 0
+
+    def clean(t):   # the NaN matrix's plane carries NaN homography gradients in both forms
+        return torch.nan_to_num(t, nan=0.0)
+    for k in ("g_logits", "g_sigma"):
+        if new[k] is None:
+            continue
+        assert torch.isfinite(new[k]).all()
+        assert rel_err(new[k], old[k]) < 2e-6, (k, rel_err(new[k], old[k]))
+        if not irregular:
+            assert torch.equal(new[k], new2[k]), k + ": the gather form is deterministic"
+    assert rel_err(clean(new["g_H"]), clean(old["g_H"])) < 5e-5
+
+
+def test_gather_backward_accumulates_and_serves_render_probability():
+    """PD_BWD_ACCUMULATE (a second target view adds into the first one's gradients) and PD_RENDER_PROB on the gather
+    backward, against the atomic kernels."""
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    B, N, H, W = 2, 6, 48, 160
+    case = _gather_case(B, N, H, W, 77, irregular=True)
+    dists = torch.rand(B, N - 1, H, W, generator=torch.Generator().manual_seed(5)) * 2.0
+    new, fl = _run_gather_case(case, C.PD_IMPL_AUTO, True, render=True, dists=dists)
+    old, _ = _run_gather_case(case, C.PD_IMPL_GENERAL, True, render=True, dists=dists)
+    assert fl == (1, 0)
+    for k in ("g_logits", "g_sigma", "g_dists"):
+        assert rel_err(new[k], old[k]) < 2e-6, (k, rel_err(new[k], old[k]))
+    # accumulate: base + gradient
+    src, tgt, logits, sigma, gw, Hm, Rn, iK = [t.cuda() for t in case]
+    flags = C.PD_MIXTURE | C.PD_AUTOMASK
+    (rgb, ph, ph_mean), saved = ops._sweep_forward(src, tgt, logits, sigma, Hm, Rn, iK, None, None, C.PD_WARP_HOMOGRAPHY, flags, 0.0)
+    grads = (gw, None, torch.full((1,), 3.0, device="cuda"))
+    cfg = (C.PD_WARP_HOMOGRAPHY, flags, 0.0)
+    gl, gs, _, _ = ops._sweep_backward(saved, cfg, grads, (True, True, False, False))
+    base_l, base_s = torch.randn_like(logits) * gl.abs().max(), torch.randn_like(sigma) * gs.abs().max()
+    into = (base_l.clone(), base_s.clone())
+    ops._sweep_backward(saved, cfg, grads, (True, True, False, False), into=into, accumulate=True)
+    assert rel_err(into[0] - base_l, gl) < 1e-5 and rel_err(into[1] - base_s, gs) < 1e-5   # (base + g) - base in fp32
 
 
 @pytest.mark.parametrize("W,H,N,side,kw", [
