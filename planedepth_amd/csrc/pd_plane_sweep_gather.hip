@@ -41,14 +41,20 @@ constexpr int kGatherSpan = 16;      // columns / rows of a window pass 2 walks 
 constexpr int kGatherSpanOk = 7;     // what the prepare kernel accepts on its 5 x 5 sample of the image
 constexpr float kGatherWRatio = 0.7f;  // min |w| / max |w| of the inverse map's denominator over the (grown) image
 
-// Pre-image box of (sx +- reach) x (sy +- reach): integer candidates [x0, x1] x [y0, y1], NOT clamped to the image
+// A thread of pass 2 owns a 2 x 2 block of source pixels (sx, sy) .. (sx+1, sy+1): the exact coordinates of a candidate
+// are the expensive part (two IEEE divisions, the normalisation round trip) and serve all four pixels, and a wave pays
+// for its largest window — 9..16 candidates for four pixels instead of 4..9 for one.
+// Pre-image box of the block's footprint (sx - reach, sx + 1 + reach) x (sy - reach, sy + 1 + reach): integer candidates
+// [x0, x1] x [y0, y1], NOT clamped to the image
+constexpr float kGatherHalf = 0.5f + kGatherReach;
 struct GatherWindow { float x0, x1, y0, y1; };
 __device__ __forceinline__ GatherWindow gather_window(const float* __restrict__ Hs, float sx, float sy) {
-  const float u = Hs[0] * sx + Hs[1] * sy + Hs[2], v = Hs[3] * sx + Hs[4] * sy + Hs[5], w = Hs[6] * sx + Hs[7] * sy + Hs[8];
+  const float cx = sx + 0.5f, cy = sy + 0.5f;
+  const float u = Hs[0] * cx + Hs[1] * cy + Hs[2], v = Hs[3] * cx + Hs[4] * cy + Hs[5], w = Hs[6] * cx + Hs[7] * cy + Hs[8];
   float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float ex = (k & 1) ? kGatherReach : -kGatherReach, ey = (k & 2) ? kGatherReach : -kGatherReach;
+    const float ex = (k & 1) ? kGatherHalf : -kGatherHalf, ey = (k & 2) ? kGatherHalf : -kGatherHalf;
     const float r = fast_rcp(w + ex * Hs[6] + ey * Hs[7]);   // (1 ulp: far inside the margins)
     const float x = (u + ex * Hs[0] + ey * Hs[1]) * r, y = (v + ex * Hs[3] + ey * Hs[4]) * r;
     xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
@@ -79,7 +85,7 @@ __global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* 
   if (ok) {   // the denominator is affine in the source position: its extremes over the grown image are at the corners
     float wmin = 3.0e38f, wmax = -3.0e38f;
     for (int q = 0; q < 4; ++q) {
-      const float x = (q & 1) ? (float)(W - 1) + kGatherReach : -kGatherReach, y = (q & 2) ? (float)(H - 1) + kGatherReach : -kGatherReach;
+      const float x = (q & 1) ? (float)W + kGatherReach : -kGatherReach, y = (q & 2) ? (float)H + kGatherReach : -kGatherReach;
       const float w = p.Hs[6] * x + p.Hs[7] * y + p.Hs[8];
       wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
     }
@@ -103,7 +109,22 @@ __global__ void gather_clear_flags_kernel(int* __restrict__ flags) { flags[threa
 // ---------------------------------------------------------------------------------------------------------------
 // pass 2
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kGatherTileW = 32, kGatherTileH = kBlock / kGatherTileW;
+constexpr int kGatherTileW = 64, kGatherTileH = 2 * (kBlock / 32);   // 32 x 8 threads of 2 x 2 source pixels
+
+// bilinear weights of target sample (ix, iy) on the four pixels of the block at (sx, sy): torch's own expressions
+struct BlockWeights { float w00, w01, w10, w11; };
+__device__ __forceinline__ BlockWeights block_weights(float ix, float iy, float fsx, float fsy) {
+  const float xf = floorf(ix), yf = floorf(iy);
+  const float wl = (xf + 1.0f) - ix, wr = ix - xf, wu = (yf + 1.0f) - iy, wd = iy - yf;   // taps xf, xf+1 / yf, yf+1
+  // column sx is tap xf (weight wl) or tap xf + 1 (weight wr); column sx + 1 likewise
+  const float a0 = (xf == fsx) ? wl : ((xf + 1.0f == fsx) ? wr : 0.0f);
+  const float a1 = (xf == fsx + 1.0f) ? wl : ((xf == fsx) ? wr : 0.0f);
+  const float b0 = (yf == fsy) ? wu : ((yf + 1.0f == fsy) ? wd : 0.0f);
+  const float b1 = (yf == fsy + 1.0f) ? wu : ((yf == fsy) ? wd : 0.0f);
+  BlockWeights r;
+  r.w00 = a0 * b0; r.w01 = a1 * b0; r.w10 = a0 * b1; r.w11 = a1 * b1;
+  return r;
+}
 
 template <bool MIX>
 __global__ __launch_bounds__(kBlock) void gather_bwd_pass2_kernel(SweepArgs a, const float* __restrict__ tmp,
@@ -115,51 +136,76 @@ __global__ __launch_bounds__(kBlock) void gather_bwd_pass2_kernel(SweepArgs a, c
   const int b = blockIdx.y, tid = threadIdx.x;
   const int blk = xcd_banded(blockIdx.x, gridDim.x);
   const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
-  const int sx = txi * kGatherTileW + (tid & (kGatherTileW - 1)), sy = tyi * kGatherTileH + tid / kGatherTileW;
+  const int sx = txi * kGatherTileW + 2 * (tid & 31), sy = tyi * kGatherTileH + 2 * (tid >> 5);
   if (sx >= W || sy >= H) return;
+  const bool right = sx + 1 < W, down = sy + 1 < H;
+  const bool pair = right && ((W & 1) == 0);   // both pixels of a row as one aligned 8-byte access
   const CoordNorm cn = make_coord_norm(W, H);
   const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp) + (long)b * N * HW;
   const long s_off = (long)b * N * HW + (long)sy * W + sx;
   float* gl = g_logits ? g_logits + s_off : nullptr;
   float* gs = (MIX && g_sigma) ? g_sigma + s_off : nullptr;
   const float fsx = (float)sx, fsy = (float)sy;
+  auto put = [&](float* p, long base, float v00, float v01, float v10, float v11) {
+    if (!p) return;
+    if (pair) {
+      *reinterpret_cast<float2*>(p + base) = make_float2(v00, v01);
+      if (down) *reinterpret_cast<float2*>(p + base + W) = make_float2(v10, v11);
+    } else {
+      p[base] = v00;
+      if (right) p[base + 1] = v01;
+      if (down) { p[base + W] = v10; if (right) p[base + W + 1] = v11; }
+    }
+  };
+  auto get = [&](const float* p, long base, float& v00, float& v01, float& v10, float& v11) {
+    if (!p) return;
+    v00 = p[base];
+    if (right) v01 = p[base + 1];
+    if (down) { v10 = p[base + W]; if (right) v11 = p[base + W + 1]; }
+  };
   bool cut = false;
   for (int n = 0; n < N; ++n) {
     const GatherPrep* pr = prep + (long)b * N + n;   // workgroup-uniform
     const long base = (long)n * HW;
     if (pr->regular == 0.0f) {   // the fix-up kernel adds this plane's gradient with atomics
-      if (!accumulate) {
-        if (gl) gl[base] = 0.0f;
-        if (gs) gs[base] = 0.0f;
-      }
+      if (!accumulate) { put(gl, base, 0.0f, 0.0f, 0.0f, 0.0f); put(gs, base, 0.0f, 0.0f, 0.0f, 0.0f); }
       continue;
     }
-    float accl = 0.0f, accs = 0.0f;
+    float l00 = 0.0f, l01 = 0.0f, l10 = 0.0f, l11 = 0.0f, s00 = 0.0f, s01 = 0.0f, s10 = 0.0f, s11 = 0.0f;
     if (accumulate) {   // requested ahead of the window scan
-      if (gl) accl = gl[base];
-      if (gs) accs = gs[base];
+      get(gl, base, l00, l01, l10, l11);
+      get(gs, base, s00, s01, s10, s11);
     }
     const GatherWindow win = gather_window(pr->Hs, fsx, fsy);
     const int x0 = (int)fminf(fmaxf(win.x0, 0.0f), (float)W), y0 = (int)fminf(fmaxf(win.y0, 0.0f), (float)H);
     int x1 = (int)fminf(fmaxf(win.x1, -1.0f), (float)(W - 1)), y1 = (int)fminf(fmaxf(win.y1, -1.0f), (float)(H - 1));
     if (x1 - x0 >= kGatherSpan) { x1 = x0 + kGatherSpan - 1; cut = true; }
     if (y1 - y0 >= kGatherSpan) { y1 = y0 + kGatherSpan - 1; cut = true; }
-    // one flat walk over the window: a wave runs as many steps as its largest window has points (4 for most lanes)
-    const int wx = x1 - x0 + 1, cnt = (x1 >= x0 && y1 >= y0) ? wx * (y1 - y0 + 1) : 0;
+    // One flat walk over the window: a wave runs as many steps as its largest window has points.  The scratch element of
+    // a candidate is requested one step ahead and unconditionally (its address needs the window only): read where it is
+    // used, behind the weight test, every step waited for a memory round trip of its own.
+    const int cnt = (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
     int tx = x0, ty = y0;
+    Elem vnext = Elem();
+    if (cnt > 0) vnext = tmp_b[base + y0 * W + x0];
     for (int j = 0; j < cnt; ++j) {
+      const Elem v = vnext;
+      int nx = tx + 1, ny = ty;
+      if (nx > x1) { nx = x0; ++ny; }
+      if (j + 1 < cnt) vnext = tmp_b[base + ny * W + nx];
       bool mk;
       const PlaneGeom g = plane_coords<PD_WARP_HOMOGRAPHY>(a, cn, b, n, tx, ty, 0.0f, mk);
-      const float w = tap_weight_on(g.ix, g.iy, sx, sy);
-      if (w != 0.0f) {   // (masked planes of a pixel are zeros in the scratch)
-        const Elem v = tmp_b[base + ty * W + tx];
-        if constexpr (MIX) { accl += w * v.x; accs += w * v.y; }
-        else accl += w * v;
+      const BlockWeights w = block_weights(g.ix, g.iy, fsx, fsy);
+      if ((w.w00 != 0.0f) | (w.w01 != 0.0f) | (w.w10 != 0.0f) | (w.w11 != 0.0f)) {   // (masked planes of a pixel are zeros in the scratch)
+        float vl, vs = 0.0f;
+        if constexpr (MIX) { vl = v.x; vs = v.y; } else vl = v;
+        l00 += w.w00 * vl; l01 += w.w01 * vl; l10 += w.w10 * vl; l11 += w.w11 * vl;
+        if (MIX) { s00 += w.w00 * vs; s01 += w.w01 * vs; s10 += w.w10 * vs; s11 += w.w11 * vs; }
       }
-      if (++tx > x1) { tx = x0; ++ty; }
+      tx = nx; ty = ny;
     }
-    if (gl) gl[base] = accl;
-    if (gs) gs[base] = accs;
+    put(gl, base, l00, l01, l10, l11);
+    put(gs, base, s00, s01, s10, s11);
   }
   if (cut) atomicOr(&flags[1], 1);
 }
