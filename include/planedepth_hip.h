@@ -95,8 +95,9 @@ enum pd_sweep_impl {
                             one pixel per lane, the headline backward of rounds 1-2) instead of the source-ordered
                             row-stream kernel (pd_plane_sweep_rowstream.hip): cross-check and A/B runs */
   ,
-  PD_IMPL_UNIFORM_DIRECT = 5 /* as AUTO, but pass 2 of the plane-uniform backward gathers directly from the scratch instead
-                            of staging it through LDS (the form large rotations fall back to anyway): cross-check */
+  PD_IMPL_UNIFORM_DIRECT = 5 /* as AUTO, but pass 2 of the two-pass homography backwards (plane-uniform and per-plane) gathers
+                            directly from the scratch instead of staging it through LDS (the form large boxes fall back
+                            to anyway): cross-check */
 };
 
 typedef struct pd_sweep_desc {

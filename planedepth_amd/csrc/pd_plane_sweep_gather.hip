@@ -211,6 +211,177 @@ __global__ __launch_bounds__(kBlock) void gather_bwd_pass2_kernel(SweepArgs a, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pass 2 with the scratch staged through LDS
+// ---------------------------------------------------------------------------------------------------------------
+// In the kernel above every candidate costs a scattered 8-byte gather (0.21 of its 0.565 ms at 8x49x192x640).  The blocks
+// of a workgroup's 64 x 16 tile share their candidates: the pre-image of the tile's footprint is a convex quadrilateral
+// whose bounding box is that of the four CORNER blocks' windows.  Per plane the corner threads publish their windows,
+// the workgroup copies the box of the scratch (~73 x 21 elements) to LDS with coalesced loads — requested one plane
+// ahead, parked after the current plane's walk, one barrier per plane, two alternating buffers — and the candidates
+// become ds_reads.  A box beyond the buffer (24 rows, 128 columns, 2304 elements: magnification > ~1.4) makes the
+// workgroup walk that plane with the direct gathers (workgroup-uniform).
+constexpr int kGStageRows = 24, kGStageCols = 128, kGStageMax = 2304;   // 2 x 18 KB: four workgroups per CU
+constexpr int kGPre = (kGStageRows / (kBlock / kWave)) * (kGStageCols / kWave);   // staged elements per thread and plane
+
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void gather_bwd_pass2_staged_kernel(SweepArgs a, const float* __restrict__ tmp,
+                                                                         const GatherPrep* __restrict__ prep,
+                                                                         float* __restrict__ g_logits, float* __restrict__ g_sigma,
+                                                                         int* __restrict__ flags, int tiles_x, int accumulate) {
+  typedef typename std::conditional<MIX, float2, float>::type Elem;
+  __shared__ Elem buf[2][kGStageMax];
+  __shared__ int corner[2][4][4];   // per buffer: the four corner blocks' windows (x0, y0, x1, y1)
+  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int blk = xcd_banded(blockIdx.x, gridDim.x);
+  const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
+  const int tile_x0 = txi * kGatherTileW, tile_y0 = tyi * kGatherTileH;
+  const int lx = tid & 31, ly = tid >> 5, wv = tid >> 6, ln = tid & (kWave - 1);
+  const int lx_last = min(31, (W - 1 - tile_x0) >> 1), ly_last = min(kBlock / 32 - 1, (H - 1 - tile_y0) >> 1);
+  const bool has_s = lx <= lx_last && ly <= ly_last;
+  const int sx = tile_x0 + 2 * lx, sy = tile_y0 + 2 * ly;
+  const bool right = sx + 1 < W, down = sy + 1 < H;
+  const bool pair = right && ((W & 1) == 0);
+  const CoordNorm cn = make_coord_norm(W, H);
+  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp) + (long)b * N * HW;
+  const long s_off = (long)b * N * HW + (long)sy * W + sx;
+  float* gl = (has_s && g_logits) ? g_logits + s_off : nullptr;
+  float* gs = (has_s && MIX && g_sigma) ? g_sigma + s_off : nullptr;
+  const float fsx = (float)sx, fsy = (float)sy;
+  const GatherPrep* prep_b = prep + (long)b * N;
+  auto put = [&](float* p, long base, float v00, float v01, float v10, float v11) {
+    if (!p) return;
+    if (pair) {
+      *reinterpret_cast<float2*>(p + base) = make_float2(v00, v01);
+      if (down) *reinterpret_cast<float2*>(p + base + W) = make_float2(v10, v11);
+    } else {
+      p[base] = v00;
+      if (right) p[base + 1] = v01;
+      if (down) { p[base + W] = v10; if (right) p[base + W + 1] = v11; }
+    }
+  };
+  auto get = [&](const float* p, long base, float& v00, float& v01, float& v10, float& v11) {
+    if (!p) return;
+    v00 = p[base];
+    if (right) v01 = p[base + 1];
+    if (down) { v10 = p[base + W]; if (right) v11 = p[base + W + 1]; }
+  };
+  struct Win { int x0, y0, x1, y1; };
+  bool cut = false;
+  // window of this thread's block on plane n, clamped to the image (empty: x1 < x0); irregular planes: empty
+  auto window_of = [&](int n) {
+    Win w; w.x0 = 0; w.y0 = 0; w.x1 = -1; w.y1 = -1;
+    if (n < N && prep_b[n].regular != 0.0f) {
+      const GatherWindow g = gather_window(prep_b[n].Hs, fsx, fsy);
+      w.x0 = (int)fminf(fmaxf(g.x0, 0.0f), (float)W); w.y0 = (int)fminf(fmaxf(g.y0, 0.0f), (float)H);
+      w.x1 = (int)fminf(fmaxf(g.x1, -1.0f), (float)(W - 1)); w.y1 = (int)fminf(fmaxf(g.y1, -1.0f), (float)(H - 1));
+      if (w.x1 - w.x0 >= kGatherSpan) { w.x1 = w.x0 + kGatherSpan - 1; cut = true; }
+      if (w.y1 - w.y0 >= kGatherSpan) { w.y1 = w.y0 + kGatherSpan - 1; cut = true; }
+    }
+    return w;
+  };
+  auto publish = [&](int slot, const Win& w) {   // (a thread can be several corners of a tile that is one block wide / high)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (lx == ((q & 1) ? lx_last : 0) && ly == ((q & 2) ? ly_last : 0)) {
+        corner[slot][q][0] = w.x0; corner[slot][q][1] = w.y0; corner[slot][q][2] = w.x1; corner[slot][q][3] = w.y1;
+      }
+  };
+  struct Box { int x0, y0, bw, bh; bool staged; };
+  auto box_of = [&](int slot) {
+    int x0 = corner[slot][0][0], y0 = corner[slot][0][1], x1 = corner[slot][0][2], y1 = corner[slot][0][3];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      x0 = min(x0, corner[slot][q][0]); y0 = min(y0, corner[slot][q][1]);
+      x1 = max(x1, corner[slot][q][2]); y1 = max(y1, corner[slot][q][3]);
+    }
+    Box bx;
+    bx.x0 = __builtin_amdgcn_readfirstlane(x0); bx.y0 = __builtin_amdgcn_readfirstlane(y0);
+    bx.bw = __builtin_amdgcn_readfirstlane(max(x1 - x0 + 1, 0)); bx.bh = __builtin_amdgcn_readfirstlane(max(y1 - y0 + 1, 0));
+    bx.staged = bx.bw <= kGStageCols && bx.bh <= kGStageRows && bx.bw * bx.bh <= kGStageMax;
+    return bx;
+  };
+  Elem pre[kGPre];
+  auto issue = [&](int n, const Box& bx) {   // thread (wave wv, lane ln): rows wv, wv + 4, ...; columns ln, ln + 64
+    if (!bx.staged) return;
+    const Elem* src = tmp_b + (long)n * HW + (long)bx.y0 * W + bx.x0;
+#pragma unroll
+    for (int k = 0; k < kGPre; ++k) {
+      const int r = wv + (kBlock / kWave) * (k >> 1), c = ln + kWave * (k & 1);
+      Elem v = Elem();
+      if (r < bx.bh && c < bx.bw) v = src[(long)r * W + c];
+      pre[k] = v;
+    }
+  };
+  auto park = [&](int which, const Box& bx) {
+    if (!bx.staged) return;
+#pragma unroll
+    for (int k = 0; k < kGPre; ++k) {
+      const int r = wv + (kBlock / kWave) * (k >> 1), c = ln + kWave * (k & 1);
+      if (r < bx.bh && c < bx.bw) buf[which][r * bx.bw + c] = pre[k];
+    }
+  };
+
+  Win w_cur = has_s ? window_of(0) : window_of(N);
+  publish(0, w_cur);
+  __syncthreads();
+  Box box_cur = box_of(0);
+  issue(0, box_cur);
+  park(0, box_cur);
+  Win w_nxt = has_s ? window_of(1) : window_of(N);
+  publish(1, w_nxt);
+  for (int n = 0; n < N; ++n) {
+    __syncthreads();   // buf[n & 1] complete, the corner windows of plane n + 1 visible; nobody reads buf[(n + 1) & 1] any more
+    Box box_nxt; box_nxt.x0 = box_nxt.y0 = box_nxt.bw = box_nxt.bh = 0; box_nxt.staged = false;
+    if (n + 1 < N) { box_nxt = box_of((n + 1) & 1); issue(n + 1, box_nxt); }
+    const long base = (long)n * HW;
+    if (prep_b[n].regular == 0.0f) {   // the fix-up kernel adds this plane's gradient with atomics
+      if (!accumulate) { put(gl, base, 0.0f, 0.0f, 0.0f, 0.0f); put(gs, base, 0.0f, 0.0f, 0.0f, 0.0f); }
+    } else {
+      float l00 = 0.0f, l01 = 0.0f, l10 = 0.0f, l11 = 0.0f, s00 = 0.0f, s01 = 0.0f, s10 = 0.0f, s11 = 0.0f;
+      if (accumulate) { get(gl, base, l00, l01, l10, l11); get(gs, base, s00, s01, s10, s11); }
+      const int x0 = w_cur.x0, y0 = w_cur.y0, x1 = w_cur.x1, y1 = w_cur.y1;
+      const int cnt = (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+      int tx = x0, ty = y0;
+      const Elem* lds = buf[n & 1];
+      const int lbase = -box_cur.y0 * box_cur.bw - box_cur.x0;
+      Elem vnext = Elem();
+      if (!box_cur.staged && cnt > 0) vnext = tmp_b[base + y0 * W + x0];
+      for (int j = 0; j < cnt; ++j) {
+        Elem v;
+        int nx = tx + 1, ny = ty;
+        if (nx > x1) { nx = x0; ++ny; }
+        if (box_cur.staged) {
+          v = lds[lbase + ty * box_cur.bw + tx];
+        } else {
+          v = vnext;
+          if (j + 1 < cnt) vnext = tmp_b[base + ny * W + nx];
+        }
+        bool mk;
+        const PlaneGeom g = plane_coords<PD_WARP_HOMOGRAPHY>(a, cn, b, n, tx, ty, 0.0f, mk);
+        const BlockWeights w = block_weights(g.ix, g.iy, fsx, fsy);
+        if ((w.w00 != 0.0f) | (w.w01 != 0.0f) | (w.w10 != 0.0f) | (w.w11 != 0.0f)) {
+          float vl, vs = 0.0f;
+          if constexpr (MIX) { vl = v.x; vs = v.y; } else vl = v;
+          l00 += w.w00 * vl; l01 += w.w01 * vl; l10 += w.w10 * vl; l11 += w.w11 * vl;
+          if (MIX) { s00 += w.w00 * vs; s01 += w.w01 * vs; s10 += w.w10 * vs; s11 += w.w11 * vs; }
+        }
+        tx = nx; ty = ny;
+      }
+      put(gl, base, l00, l01, l10, l11);
+      put(gs, base, s00, s01, s10, s11);
+    }
+    if (n + 1 < N) park((n + 1) & 1, box_nxt);
+    w_cur = w_nxt; box_cur = box_nxt;
+    if (n + 2 < N) {
+      w_nxt = has_s ? window_of(n + 2) : window_of(N);
+      publish(n & 1, w_nxt);
+    }
+  }
+  if (cut) atomicOr(&flags[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // irregular planes: scatter out of the scratch with atomics (target-anchored; returns at once when there are none)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool MIX>
@@ -256,7 +427,8 @@ __global__ __launch_bounds__(kBlock) void gather_fixup_kernel(SweepArgs a, const
 static size_t galign4(size_t floats) { return (floats + 3) & ~(size_t)3; }
 
 bool gather_bwd_applicable(const pd_sweep_desc* d) {
-  return d->mode == PD_WARP_HOMOGRAPHY && !(d->flags & PD_HOMO_UNIFORM) && d->impl == PD_IMPL_AUTO;
+  return d->mode == PD_WARP_HOMOGRAPHY && !(d->flags & PD_HOMO_UNIFORM) &&
+         (d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_UNIFORM_DIRECT);
 }
 
 // workspace: partial sums [B][nblk][N*9] | GatherPrep[B*N] | flags (4 ints) | scratch [B][N][H*W] (x2 with PD_MIXTURE)
@@ -292,11 +464,14 @@ int gather_bwd_finish(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& 
   const int tiles_x = ceil_div(d->W, kGatherTileW);
   const dim3 grid2(tiles_x * ceil_div(d->H, kGatherTileH), d->B), grid1(ceil_div(d->H * d->W, kBlock), d->B);
   const GatherPrep* prep = reinterpret_cast<const GatherPrep*>(gp.prep);
+  const bool staged = d->impl != PD_IMPL_UNIFORM_DIRECT;   // (the direct-gather form: cross-check, and what large boxes fall back to)
   if (mix) {
-    gather_bwd_pass2_kernel<true><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags, tiles_x, accumulate);
+    if (staged) gather_bwd_pass2_staged_kernel<true><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags, tiles_x, accumulate);
+    else gather_bwd_pass2_kernel<true><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags, tiles_x, accumulate);
     gather_fixup_kernel<true><<<grid1, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, o.g_sigma, gp.flags);
   } else {
-    gather_bwd_pass2_kernel<false><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags, tiles_x, accumulate);
+    if (staged) gather_bwd_pass2_staged_kernel<false><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags, tiles_x, accumulate);
+    else gather_bwd_pass2_kernel<false><<<grid2, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags, tiles_x, accumulate);
     gather_fixup_kernel<false><<<grid1, kBlock, 0, stream>>>(a, gp.scratch, prep, o.g_logits, nullptr, gp.flags);
   }
   return check_launch("gather_bwd_pass2_kernel / gather_fixup_kernel");

@@ -1602,7 +1602,7 @@ def _run_gather_case(case, impl, mix=True, render=False, dists=None):
         out = dict(g_logits=lg.grad.cpu(), g_sigma=sg.grad.cpu() if mix else None, g_H=Hd.grad.cpu(),
                    g_dists=dd.grad.cpu() if render else None)
         flags_out = None
-        if impl == C.PD_IMPL_AUTO:
+        if impl in (C.PD_IMPL_AUTO, C.PD_IMPL_UNIFORM_DIRECT):
             import ctypes
             d, ws = ops.DEBUG_WORKSPACE[-1]
             host = (ctypes.c_int * 2)()
@@ -1628,8 +1628,9 @@ def test_gather_backward_equals_atomic_backward(B, N, H, W, mix, irregular):
     case = _gather_case(B, N, H, W, 300 + W + N, irregular)
     new, fl = _run_gather_case(case, C.PD_IMPL_AUTO, mix)
     new2, _ = _run_gather_case(case, C.PD_IMPL_AUTO, mix)
+    direct, fl_direct = _run_gather_case(case, C.PD_IMPL_UNIFORM_DIRECT, mix)   # pass 2 without the LDS staging
     old, _ = _run_gather_case(case, C.PD_IMPL_GENERAL, mix)
-    assert fl == ((1, 0) if irregular else (0, 0)), fl
+    assert fl == ((1, 0) if irregular else (0, 0)) and fl_direct == fl, (fl, fl_direct)
     assert float(old["g_logits"].abs().max()) > 0
 
     def clean(t):   # the NaN matrix's plane carries NaN homography gradients in both forms
@@ -1641,6 +1642,7 @@ def test_gather_backward_equals_atomic_backward(B, N, H, W, mix, irregular):
         assert rel_err(new[k], old[k]) < 2e-6, (k, rel_err(new[k], old[k]))
         if not irregular:
             assert torch.equal(new[k], new2[k]), k + ": the gather form is deterministic"
+            assert torch.equal(new[k], direct[k]), k + ": staged and direct pass 2 add the same numbers in the same order"
     assert rel_err(clean(new["g_H"]), clean(old["g_H"])) < 5e-5
 
 
