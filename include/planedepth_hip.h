@@ -68,6 +68,12 @@ enum pd_sweep_flags {
                          gradients in place instead of through [B,N,H,W]-sized add kernels.  Honoured where
                          pd_sweep_bwd_accumulates() says so (the plane-uniform kernels: read-modify-write stores; the
                          general kernels: their atomics simply skip the zero-fill); refused elsewhere */
+  ,
+  PD_BWD_DEFER_GATHER = 256 /* pd_plane_sweep_bwd, PD_HOMO_UNIFORM only: run the first pass (per-pixel plane gradients into the
+                         scratch inside `workspace`, g_plane, g_dists) and leave g_logits / g_sigma untouched; the caller
+                         then hands the workspaces of TWO such calls over the same logits / sigma to
+                         pd_uniform_gather_pair, which gathers both views in one kernel (one store per gradient element
+                         instead of a read-modify-write per view) */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
@@ -344,6 +350,17 @@ int pd_project3d_bwd(int B, int H, int W, float eps, const float* cam, const flo
 int pd_homography_grid(int M, int H, int W, const float* H_t2s, const float* Rn, const float* inv_K3, float* grid,
                        uint8_t* mask, pd_stream_t stream);
 int pd_homography_grid_bwd(int M, int H, int W, const float* H_t2s, const float* g_grid, float* g_H, float* workspace,
+                           pd_stream_t stream);
+
+/*
+ * Second pass of TWO plane-uniform backward calls (PD_HOMO_UNIFORM | PD_BWD_DEFER_GATHER, the same descriptor and the
+ * same logits / sigma: the novel frames -1 / +1 of the reference's mono training, trainer.py:532) in one kernel:
+ *   g_logits / g_sigma [B,N,H,W] = (PD_BWD_ACCUMULATE in d->flags: their old contents +) view a's gradient + view b's.
+ * `plane_*` [B,4,3,3] and `inv_K3_*` [B,3,3] are the views' arguments of pd_plane_sweep_bwd, `workspace_*` the workspaces
+ * those calls filled (pd_sweep_bwd_workspace_floats each).  g_sigma may be NULL without PD_MIXTURE.
+ */
+int pd_uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,
+                           const float* plane_b, const float* inv_K3_b, float* workspace_b, float* g_logits, float* g_sigma,
                            pd_stream_t stream);
 
 /*

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("PD_LIB") or os.path.join(_HERE, "lib", "libplanedepth
 PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_ROWS, PD_HOMO_UNIFORM = 1, 2, 4, 8, 16, 32, 64
 PD_BWD_ACCUMULATE = 128
+PD_BWD_DEFER_GATHER = 256
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
@@ -45,6 +46,7 @@ SIGNATURES = {
     "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 14),
     "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 20),
     "pd_plane_sweep_layers": (_I, [_D] + [_P] * 14),
+    "pd_uniform_gather_pair": (_I, [_D] + [_P] * 9),
     "pd_ssim_fwd": (_I, [_I] * 4 + [_P] * 4),
     "pd_ssim_bwd": (_I, [_I] * 4 + [_P] * 6),
     "pd_reproj_loss_fwd": (_I, [_I] * 4 + [_P] * 4),

@@ -399,6 +399,7 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
   } else {
     PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM), "PD_HOMO_UNIFORM is a homography-mode flag");
   }
+  PD_REQUIRE(!(d->flags & PD_BWD_DEFER_GATHER) || (d->flags & PD_HOMO_UNIFORM), "PD_BWD_DEFER_GATHER goes with PD_HOMO_UNIFORM");
   PD_REQUIRE(!((d->flags & PD_DISP_DENSE) && (d->flags & PD_DISP_ROWS)), "PD_DISP_DENSE and PD_DISP_ROWS exclude each other");
   if ((d->flags & PD_DISP_ROWS) && !pd_sweep_uses_rowshift(d)) {
     set_error("PD_DISP_ROWS is served by the row-shift kernels only (pd_sweep_uses_rowshift); pass a dense map instead");
@@ -607,6 +608,19 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     rc = check_launch("reduce_partials_kernel");
   }
   return rc;
+}
+
+extern "C" int pd_uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,
+                                      const float* plane_b, const float* inv_K3_b, float* workspace_b, float* g_logits,
+                                      float* g_sigma, pd_stream_t stream) {
+  PD_REQUIRE(d != nullptr, "desc is NULL");
+  PD_REQUIRE(d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM) && (d->flags & PD_BWD_DEFER_GATHER),
+             "pd_uniform_gather_pair takes the descriptor of two PD_HOMO_UNIFORM | PD_BWD_DEFER_GATHER backward calls");
+  PD_REQUIRE(d->B > 0 && d->B <= 65535 && d->N > 0 && d->H > 1 && d->W > 1, "bad shape");
+  PD_REQUIRE(plane_a && inv_K3_a && workspace_a && plane_b && inv_K3_b && workspace_b && g_logits, "NULL argument");
+  PD_REQUIRE(!(d->flags & PD_MIXTURE) || g_sigma, "PD_MIXTURE needs g_sigma");
+  return uniform_gather_pair(d, plane_a, inv_K3_a, workspace_a, plane_b, inv_K3_b, workspace_b, g_logits, g_sigma,
+                             (hipStream_t)stream);
 }
 
 extern "C" int pd_debug_gather_flags(const pd_sweep_desc* d, const float* workspace, int* host_out, pd_stream_t stream) {

@@ -343,7 +343,8 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
                                                                    const UniPrep* __restrict__ prep,
                                                                    float* __restrict__ g_logits, float* __restrict__ g_sigma,
                                                                    int* __restrict__ overflow_flag, const int* __restrict__ run_flag,
-                                                                   int accumulate) {
+                                                                   int accumulate, int list_limit = kUniK) {
+  // list_limit (OVERFLOW only): the register slots of the kernel this one follows (kUniK, or kPairK after the pair kernel)
   if (run_flag && *run_flag == 0) return;        // the fused kernel served the whole launch
   const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
   const int spix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
   float* gl = g_logits ? g_logits + (long)b * N * HW + spix : nullptr;
   float* gs = (MIX && g_sigma) ? g_sigma + (long)b * N * HW + spix : nullptr;
   if (OVERFLOW) {
-    if (cnt <= kUniK) return;
+    if (cnt <= list_limit) return;
     for (int n = 0; n < N; ++n) {
       float accl = 0.0f, accs = 0.0f;
       for (int ty = win.y0; ty <= win.y1; ++ty)
@@ -611,6 +612,185 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
         if (gs) gs[base] = accs;
       }
     }
+    if (more) park(which ^ 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, pass 2 of TWO target views in one kernel (pd_uniform_gather_pair)
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's mono training sweeps two novel frames (-1, +1) over the same logits / sigma (trainer.py:532), so their
+// gradients land in the same tensors: as two passes the second one reads what the first one wrote (385 MB at
+// 8x49x192x640) and both write the full tensors.  Here one workgroup owns the 32 x 8 source tile for BOTH views: two
+// gather lists per source pixel, the two scratch boxes of a plane staged side by side (one plane per step and view, so
+// the LDS footprint stays that of the single-view kernel), one store per gradient element.  A source pixel whose list
+// overflows in a view takes nothing from that view here; that view's follow-up kernel (uniform_bwd_pass2_kernel<.., true>,
+// accumulate) adds it.  Boxes that do not fit make the workgroup gather both views directly.
+constexpr int kPairViews = 2, kPairK = 10;      // list entries kept per view (12 in the single-view kernel: 142 VGPRs here)
+constexpr int kPairPre = kStageBox / kBlock;    // staged elements per thread, view and plane
+struct PairArgs {
+  int N, H, W;
+  const float* plane[kPairViews];
+  const float* inv_K3[kPairViews];
+  const float* tmp[kPairViews];
+  const UniPrep* prep[kPairViews];
+  int* overflow[kPairViews];
+};
+
+template <bool MIX>
+__global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_pair_kernel(PairArgs pa, float* __restrict__ g_logits,
+                                                                        float* __restrict__ g_sigma, int tiles_x, int accumulate) {
+  typedef typename std::conditional<MIX, float2, float>::type Elem;
+  __shared__ Elem buf[2][kPairViews][kStageBox];
+  const int H = pa.H, W = pa.W, N = pa.N, HW = H * W;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int blk = xcd_banded(blockIdx.x, gridDim.x);
+  const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
+  const int xs0 = txi * kStageW, ys0 = tyi * kStageH;
+  const int tw_ = min(kStageW, W - xs0), th = min(kStageH, H - ys0);
+  const CoordNorm cn = make_coord_norm(W, H);
+  const int lx = tid & (kStageW - 1), ly = tid >> 5;
+  const bool has_s = lx < tw_ && ly < th;
+  const int sx = xs0 + lx, sy = ys0 + ly;
+  int bx0[kPairViews], by0[kPairViews], bw[kPairViews], npx[kPairViews];
+  int idx[kPairViews][kPairK];
+  float wgt[kPairViews][kPairK];
+  int kuse[kPairViews];
+  const Elem* tmp_b[kPairViews];
+  bool staged = true;
+#pragma unroll
+  for (int v = 0; v < kPairViews; ++v) {
+    const UniPrep pr = pa.prep[v][b];
+    const UniWindow w0 = uni_window(pr, xs0, ys0, W, H), w1 = uni_window(pr, xs0 + tw_ - 1, ys0 + th - 1, W, H);
+    const UniWindow w2 = uni_window(pr, xs0 + tw_ - 1, ys0, W, H), w3 = uni_window(pr, xs0, ys0 + th - 1, W, H);
+    bx0[v] = min(min(w0.x0, w1.x0), min(w2.x0, w3.x0));
+    by0[v] = min(min(w0.y0, w1.y0), min(w2.y0, w3.y0));
+    const int bx1 = max(max(w0.x1, w1.x1), max(w2.x1, w3.x1)), by1 = max(max(w0.y1, w1.y1), max(w2.y1, w3.y1));
+    bw[v] = max(bx1 - bx0[v] + 1, 0);
+    npx[v] = bw[v] * max(by1 - by0[v] + 1, 0);
+    staged = staged && npx[v] <= kStageBox;
+    tmp_b[v] = reinterpret_cast<const Elem*>(pa.tmp[v] + (long)blockIdx.y * 2 * N * HW);
+  }
+#pragma unroll
+  for (int v = 0; v < kPairViews; ++v) {
+#pragma unroll
+    for (int k = 0; k < kPairK; ++k) { idx[v][k] = 0; wgt[v][k] = 0.0f; }
+    int cnt = 0;
+    if (has_s) {
+      const float* Hm = pa.plane[v] + (long)b * kUniH;
+      const float* Ki = pa.inv_K3[v] + (long)b * 9;
+      const UniWindow win = uni_window(pa.prep[v][b], sx, sy, W, H);
+      for (int ty = win.y0; ty <= win.y1; ++ty)
+        for (int tx = win.x0; tx <= win.x1; ++tx) {
+          const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
+          const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
+          if (w != 0.0f) {
+            const int slot = staged ? min(max((ty - by0[v]) * bw[v] + (tx - bx0[v]), 0), kStageBox - 1) : ty * W + tx;
+#pragma unroll
+            for (int k = 0; k < kPairK; ++k)
+              if (k == cnt) { idx[v][k] = slot; wgt[v][k] = w; }
+            ++cnt;
+          }
+        }
+    }
+    if (cnt > kPairK) { atomicOr(pa.overflow[v], 1); cnt = 0;   // this view's follow-up kernel adds the pixel's share
+#pragma unroll
+      for (int k = 0; k < kPairK; ++k) { idx[v][k] = 0; wgt[v][k] = 0.0f; } }
+    int kmax = cnt;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, kWave));
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    kuse[v] = kmax == 0 ? 0 : max(kmax, 4);   // (a wave without contributors must not read the possibly empty box)
+  }
+  const long s_off = (long)b * N * HW + (long)sy * W + sx;
+  float* gl = (has_s && g_logits) ? g_logits + s_off : nullptr;
+  float* gs = (has_s && MIX && g_sigma) ? g_sigma + s_off : nullptr;
+
+  if (!staged) {   // direct gathers (idx = absolute pixel index)
+    for (int n = 0; n < N; ++n) {
+      const long base = (long)n * HW;
+      float accl = 0.0f, accs = 0.0f;
+      if (accumulate) {
+        if (gl) accl = gl[base];
+        if (gs) accs = gs[base];
+      }
+#pragma unroll
+      for (int v = 0; v < kPairViews; ++v)
+#pragma unroll
+        for (int k = 0; k < kPairK; ++k)
+          if (k < kuse[v]) {
+            const PairLS e = load_ls<MIX>(reinterpret_cast<const float*>(tmp_b[v]), base + idx[v][k]);
+            accl += wgt[v][k] * e.l;
+            accs += wgt[v][k] * e.s;
+          }
+      if (gl) gl[base] = accl;
+      if (gs) gs[base] = accs;
+    }
+    return;
+  }
+
+  // staging map (the same for every plane): element e = tid, tid + 256, ... of each view's box
+  int e_rc[kPairViews][kPairPre];
+#pragma unroll
+  for (int v = 0; v < kPairViews; ++v)
+#pragma unroll
+    for (int j = 0; j < kPairPre; ++j) {
+      const int q = tid + j * kBlock;
+      const int ry = q / max(bw[v], 1), rx = q - ry * bw[v];
+      e_rc[v][j] = q < npx[v] ? (by0[v] + ry) * W + (bx0[v] + rx) : -1;
+    }
+  // (Requesting the loads two steps ahead instead of one — two register sets, 145 VGPRs — made the kernel slower, 0.43 ->
+  // 0.49 ms: it is not waiting for latency but moving 1.64x the scratch through the L1s, the boxes' overlap.)
+  Elem pre[kPairViews][kPairPre];
+  auto issue = [&](int n) {
+#pragma unroll
+    for (int v = 0; v < kPairViews; ++v)
+#pragma unroll
+      for (int j = 0; j < kPairPre; ++j) {
+        Elem e = Elem();
+        if (e_rc[v][j] >= 0) e = tmp_b[v][(long)n * HW + e_rc[v][j]];
+        pre[v][j] = e;
+      }
+  };
+  auto park = [&](int which) {
+#pragma unroll
+    for (int v = 0; v < kPairViews; ++v)
+#pragma unroll
+      for (int j = 0; j < kPairPre; ++j)
+        if (e_rc[v][j] >= 0) buf[which][v][tid + j * kBlock] = pre[v][j];
+  };
+  float nextl = 0.0f, nexts = 0.0f;
+  auto fetch_old = [&](int n) {
+    nextl = 0.0f; nexts = 0.0f;
+    if (accumulate) {
+      if (gl) nextl = gl[(long)n * HW];
+      if (gs) nexts = gs[(long)n * HW];
+    }
+  };
+  issue(0);
+  fetch_old(0);
+  park(0);
+  for (int n = 0; n < N; ++n) {
+    const int which = n & 1;
+    __syncthreads();                               // buf[which] complete; buf[which ^ 1] no longer read by anybody
+    float accl = nextl, accs = nexts;
+    const bool more = n + 1 < N;
+    if (more) {                                    // in flight while this plane is reduced
+      issue(n + 1);
+      fetch_old(n + 1);
+    }
+#pragma unroll
+    for (int v = 0; v < kPairViews; ++v)
+#pragma unroll
+      for (int k = 0; k < kPairK; ++k)
+        if (k < kuse[v]) {
+          const Elem e = buf[which][v][idx[v][k]];
+          if constexpr (MIX) { accl += wgt[v][k] * e.x; accs += wgt[v][k] * e.y; }
+          else accl += wgt[v][k] * e;
+        }
+    const long base = (long)n * HW;
+    if (gl) gl[base] = accl;
+    if (gs) gs[base] = accs;
     if (more) park(which ^ 1);
   }
 }
@@ -877,8 +1057,9 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
   const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
   const bool render = (d->flags & PD_RENDER_PROB) != 0;
+  const bool defer = (d->flags & PD_BWD_DEFER_GATHER) != 0;   // pass 2 is pd_uniform_gather_pair's
 #ifdef PD_EXPERIMENTS
-  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !render;   // experiments build only
+  const bool fused = getenv("PD_UNI_FUSED") != nullptr && !accumulate && !render && !defer;   // experiments build only
 #else
   const bool fused = false;
 #endif
@@ -897,6 +1078,10 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
 #endif
   const int* run_flag = fused ? irregular : nullptr;   // the two-pass kernels return at once unless the fused one gave up
   const int chunk = uniform_chunk(d);
+  if (defer && chunk < d->B) {
+    set_error("PD_BWD_DEFER_GATHER needs the whole batch's scratch (PD_UNI_CHUNK is set)");
+    return PD_ERR_UNSUPPORTED;
+  }
   for (int b0 = 0; b0 < d->B && !rc; b0 += chunk) {
     const int nb = (d->B - b0) < chunk ? (d->B - b0) : chunk;
     dim3 grid(nblk, nb);
@@ -908,15 +1093,21 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
     if (mix) {
       if (render) uniform_bwd_pass1_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       else        uniform_bwd_pass1_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      if (defer) { /* the caller gathers: pd_uniform_gather_pair */ }
+      else {
       if (staged) uniform_bwd_pass2_staged_kernel<true><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
+      }
     } else {
       if (render) uniform_bwd_pass1_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       else        uniform_bwd_pass1_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
+      if (defer) { /* the caller gathers: pd_uniform_gather_pair */ }
+      else {
       if (staged) uniform_bwd_pass2_staged_kernel<false><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
+      }
     }
     rc = check_launch("uniform_bwd_pass kernels");
   }
@@ -924,6 +1115,49 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   uniform_reduce_kernel<<<dim3(kUniG * 9, d->B), kWave, 0, stream>>>(fused ? part_fused : nullptr, ntiles, part_two, nblk,
                                                                      irregular, o.g_plane, kUniG * 9);
   return check_launch("uniform_reduce_kernel");
+}
+
+// where uniform_bwd keeps its pieces inside a workspace (the same arithmetic as there)
+struct UniformWs { UniPrep* prep; float* tmp; int* overflow; };
+static UniformWs uniform_ws(const pd_sweep_desc* d, float* workspace) {
+  const int nblk = ceil_div(d->H * d->W, kBlock);
+  const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+  float* part_two = reinterpret_cast<float*>(base);
+  float* part_fused = part_two + ualign4((size_t)d->B * nblk * kUniG * 9);
+  UniformWs w;
+  w.prep = reinterpret_cast<UniPrep*>(part_fused + ualign4((size_t)d->B * nblk * kUniG * 9));
+  w.tmp = reinterpret_cast<float*>(w.prep) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float)));
+  w.overflow = reinterpret_cast<int*>(&w.prep[0].pad[0]);
+  return w;
+}
+
+int uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,
+                        const float* plane_b, const float* inv_K3_b, float* workspace_b, float* g_logits, float* g_sigma,
+                        hipStream_t stream) {
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
+  const UniformWs wa = uniform_ws(d, workspace_a), wb = uniform_ws(d, workspace_b);
+  PairArgs pa;
+  pa.N = d->N; pa.H = d->H; pa.W = d->W;
+  pa.plane[0] = plane_a; pa.plane[1] = plane_b;
+  pa.inv_K3[0] = inv_K3_a; pa.inv_K3[1] = inv_K3_b;
+  pa.tmp[0] = wa.tmp; pa.tmp[1] = wb.tmp;
+  pa.prep[0] = wa.prep; pa.prep[1] = wb.prep;
+  pa.overflow[0] = wa.overflow; pa.overflow[1] = wb.overflow;
+  const int stiles_x = ceil_div(d->W, kStageW);
+  const dim3 sgrid(stiles_x * ceil_div(d->H, kStageH), d->B), grid(ceil_div(d->H * d->W, kBlock), d->B);
+  if (mix) uniform_bwd_pass2_pair_kernel<true><<<sgrid, kBlock, 0, stream>>>(pa, g_logits, g_sigma, stiles_x, accumulate);
+  else     uniform_bwd_pass2_pair_kernel<false><<<sgrid, kBlock, 0, stream>>>(pa, g_logits, nullptr, stiles_x, accumulate);
+  // source pixels with more than kPairK contributors in a view: that view's follow-up adds them (returns at once otherwise)
+  for (int v = 0; v < 2; ++v) {
+    SweepArgs a{};
+    a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W; a.flags = d->flags;
+    a.plane = v ? plane_b : plane_a; a.inv_K3 = v ? inv_K3_b : inv_K3_a;
+    const UniformWs& w = v ? wb : wa;
+    if (mix) uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(a, 0, w.tmp, w.prep, g_logits, g_sigma, w.overflow, nullptr, 1, kPairK);
+    else     uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(a, 0, w.tmp, w.prep, g_logits, nullptr, w.overflow, nullptr, 1, kPairK);
+  }
+  return check_launch("uniform_bwd_pass2_pair_kernel");
 }
 
 }  // namespace pd

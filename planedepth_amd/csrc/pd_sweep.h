@@ -289,6 +289,9 @@ GatherPlan gather_bwd_plan(const pd_sweep_desc* d, float* workspace);
 int gather_bwd_prepare(const pd_sweep_desc* d, const SweepArgs& a, const GatherPlan& gp, hipStream_t stream);
 int gather_bwd_finish(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, const GatherPlan& gp, hipStream_t stream);
 size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d);
+int uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,
+                        const float* plane_b, const float* inv_K3_b, float* workspace_b, float* g_logits, float* g_sigma,
+                        hipStream_t stream);
 // partials [B][nblk][M] -> out [B][M], fixed summation order (pd_plane_sweep.hip)
 int reduce_partials(const float* partials, float* out, int nblk, int M, int B, hipStream_t stream);
 

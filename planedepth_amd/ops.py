@@ -16,6 +16,7 @@ from . import _capi as C
 SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
+PAIR_GATHER = os.environ.get("PD_PAIR_GATHER", "1") != "0"   # two plane-uniform views of a step: their second passes in one kernel
 DEBUG_WORKSPACE = None   # diagnostics (tests): set to a list to collect (descriptor, workspace) of every sweep backward
 if int(os.environ.get("PD_DEBUG_POISON_MEM", "0")):
     # diagnostics: every buffer this module allocates uninitialised (outputs, stash, workspaces) starts as NaNs, so a
@@ -116,19 +117,23 @@ def _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_ma
     return (rgb_rec, ph_map, ph_mean), (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
 
 
-def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False):
+def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=False):
     """pd_plane_sweep_bwd of one target view.  ``need`` = (logits, sigma, plane, dists) gradients wanted; ``into`` =
     (g_logits, g_sigma) buffers to write (or, ``accumulate``: add) into instead of fresh ones.
-    Returns (g_logits, g_sigma, g_plane, g_dists)."""
+    Returns (g_logits, g_sigma, g_plane, g_dists).  ``defer`` (plane-uniform views only): the first pass only
+    (PD_BWD_DEFER_GATHER) -> (g_plane, g_dists, workspace); ``_gather_pair`` finishes two such views in one kernel."""
     lib = C.load()
     src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = saved
     mode, flags, sign = cfg
     g_rgb_rec, g_ph_map, g_ph_mean = grads
     B, N, H, W = logits.shape
-    d = _desc(B, N, H, W, mode, flags | (C.PD_BWD_ACCUMULATE if accumulate else 0), sign)
+    d = _desc(B, N, H, W, mode, flags | (C.PD_BWD_ACCUMULATE if accumulate else 0) | (C.PD_BWD_DEFER_GATHER if defer else 0),
+              sign)
     need_logits, need_sigma, need_plane, need_dists = need
     mix = bool(flags & C.PD_MIXTURE)
-    if into is not None:
+    if defer:
+        g_logits = g_sigma = None
+    elif into is not None:
         g_logits, g_sigma = into
     else:
         g_logits = torch.empty_like(logits) if need_logits else None
@@ -150,7 +155,26 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False):
     C.check(rc, "pd_plane_sweep_bwd")
     if DEBUG_WORKSPACE is not None:
         DEBUG_WORKSPACE.append((d, ws))
+    if defer:
+        return g_plane, g_dists, ws
     return g_logits, (g_sigma if mix else None), g_plane, g_dists
+
+
+def _gather_pair(view_a, view_b, cfg, g_logits, g_sigma, accumulate):
+    """pd_uniform_gather_pair: the second pass of two deferred plane-uniform backward calls (``view_*`` = (saved tensors,
+    workspace)) into (or, ``accumulate``: added to) g_logits / g_sigma."""
+    lib = C.load()
+    (saved_a, ws_a), (saved_b, ws_b) = view_a, view_b
+    logits = saved_a[2]
+    B, N, H, W = logits.shape
+    mode, flags, sign = cfg
+    mix = bool(flags & C.PD_MIXTURE)
+    d = _desc(B, N, H, W, mode, flags | C.PD_BWD_DEFER_GATHER | (C.PD_BWD_ACCUMULATE if accumulate else 0), sign)
+    with torch.cuda.device(logits.device), _timed("bwd"):
+        rc = lib.pd_uniform_gather_pair(ctypes.byref(d), C.ptr(saved_a[4]), C.ptr(saved_a[6]), C.ptr(ws_a),
+                                        C.ptr(saved_b[4]), C.ptr(saved_b[6]), C.ptr(ws_b), C.ptr(g_logits),
+                                        C.ptr(g_sigma if mix else None), C.stream_handle(logits.device))
+    C.check(rc, "pd_uniform_gather_pair")
 
 
 class _PlaneSweep(torch.autograd.Function):
@@ -235,10 +259,34 @@ class _MultiPlaneSweep(torch.autograd.Function):
         views.sort(key=lambda v: v[3])   # kernels that cannot add in place (the row-shift ones) first: one of them starts the sum
         g_logits = g_sigma = None
         per_view = {}
-        for k, (i, saved, g, can) in enumerate(views):
+
+        def pairable(v):   # plane-uniform views with the same kernel configuration gather together (pd_uniform_gather_pair)
+            mode, flags, sign = ctx.cfgs[v[0]]
+            return PAIR_GATHER and mode == C.PD_WARP_HOMOGRAPHY and bool(flags & C.PD_HOMO_UNIFORM) and (need_logits or need_sigma)
+        k = 0
+        while k < len(views):
+            i, saved, g, can = views[k]
             base = 3 + i * _PER_SIDE
             need = (need_logits, need_sigma, ctx.needs_input_grad[base + 1], ctx.needs_input_grad[base + 5])
-            if k == 0:
+            nxt = views[k + 1] if k + 1 < len(views) else None
+            if nxt is not None and pairable(views[k]) and pairable(nxt) and ctx.cfgs[i] == ctx.cfgs[nxt[0]]:
+                j, saved_j, g_j, _ = nxt
+                base_j = 3 + j * _PER_SIDE
+                need_j = (need_logits, need_sigma, ctx.needs_input_grad[base_j + 1], ctx.needs_input_grad[base_j + 5])
+                gp, gd, ws = _sweep_backward(saved, ctx.cfgs[i], g, need, defer=True)
+                gp_j, gd_j, ws_j = _sweep_backward(saved_j, ctx.cfgs[j], g_j, need_j, defer=True)
+                started = g_logits is not None or g_sigma is not None
+                logits = saved[2]
+                mix = bool(ctx.cfgs[i][1] & C.PD_MIXTURE)
+                if g_logits is None:
+                    g_logits = torch.zeros_like(logits) if started else torch.empty_like(logits)
+                if mix and g_sigma is None:
+                    g_sigma = torch.zeros_like(logits) if started else torch.empty_like(logits)
+                _gather_pair((saved, ws), (saved_j, ws_j), ctx.cfgs[i], g_logits, g_sigma, accumulate=started)
+                per_view[i], per_view[j] = (gp, gd), (gp_j, gd_j)
+                k += 2
+                continue
+            if g_logits is None and g_sigma is None:
                 g_logits, g_sigma, gp, gd = _sweep_backward(saved, ctx.cfgs[i], g, need)
             elif can:
                 gl, gs, gp, gd = _sweep_backward(saved, ctx.cfgs[i], g, need, into=(g_logits, g_sigma), accumulate=True)
@@ -250,6 +298,7 @@ class _MultiPlaneSweep(torch.autograd.Function):
                 if gs is not None:
                     g_sigma = gs if g_sigma is None else g_sigma.add_(gs)
             per_view[i] = (gp, gd)
+            k += 1
         out = [None, g_logits, g_sigma]
         for i in range(n):
             gp, gd = per_view.get(i, (None, None))

@@ -2060,6 +2060,64 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     return Rt.to(device)
 
 
+@pytest.mark.parametrize("B,N,H,W,mix,rots,zooms,with_stereo", [
+    (2, 7, 24, 80, True, (0.02, 0.03), (1.0, 1.0), True),       # two pose-net frames behind a disp_warp view (accumulate)
+    (2, 7, 24, 80, True, (0.02, 0.03), (1.0, 1.0), False),      # the pair starts the sum (plain stores)
+    (1, 5, 40, 150, False, (0.05, 0.01), (1.0, 1.0), True),     # L1 loss: float scratch
+    (1, 9, 64, 200, True, (0.5, 0.02), (1.0, 1.0), True),       # one view rotated by ~29 degrees: its box does not fit -> direct gathers
+    (1, 4, 30, 90, True, (0.05, 0.02), (2.6, 1.0), False),      # one view 2.6x denser than the source: lists overflow -> follow-up
+    (1, 4, 30, 90, True, (0.05, 0.02), (1.6, 1.55), True),      # 9-12 contributors: around the pair kernel's 10 slots
+    (1, 49, 96, 320, True, (0.01, 0.012), (1.0, 1.0), True)])
+def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zooms, with_stereo, monkeypatch):
+    """pd_uniform_gather_pair (the second passes of the two novel frames of a step in one kernel: one store per gradient
+    element) against the same node with the views' second passes one after the other (PD_PAIR_GATHER=0: read-modify-write
+    per view).  Same contributions added in the same order -> the same bits in g_logits / g_sigma, unless a list overflows
+    the 12 register slots (then the follow-up kernels add those shares last)."""
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(4200 + W + N)
+    dev = "cuda"
+    src = torch.rand(B, 3, H, W, generator=g).to(dev)
+    tgts = [torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3)]
+    logits = torch.randn(B, N, H, W, generator=g).to(dev)
+    sigma = (0.011 + 0.978 * torch.rand(B, N, H, W, generator=g)).to(dev)
+    gws = [(torch.randn(B, 3, H, W, generator=g) * 0.1).to(dev) for _ in range(3)]
+    distance = (0.5 + 5 * torch.rand(B, N, generator=g)).to(dev)
+    norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
+    disp = (torch.rand(B, N, 1, 1, generator=g) * 20 + 0.5).to(dev)
+    K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    res = {}
+    for pair in (True, False):
+        monkeypatch.setattr(ops, "PAIR_GATHER", pair)
+        lg, sg = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
+        Rts = []
+        calls = []
+        if with_stereo:
+            calls.append(ops.plane_sweep_disp(src, tgts[2], lg, sg if mix else None, disp.expand(-1, -1, H, W), None,
+                                              target_side="r", use_mixture_loss=mix, return_mean=True, defer=True))
+        for v in range(2):
+            Rt = _f8_pose(B, 31 + H + v, rots[v], dev)
+            Rt[:, :2, :3] *= zooms[v]
+            Rt.requires_grad_(True)
+            Rts.append(Rt)
+            calls.append(ops.plane_sweep_homography(src, tgts[v], lg, sg if mix else None, distance, norm, Rt, K, inv_K,
+                                                    use_mixture_loss=mix, automask=True, return_mean=True,
+                                                    plane_uniform=True, defer=True))
+        outs = ops.plane_sweep_multi(calls)
+        loss = sum(o[2] * (i + 1.0) + (o[0] * gws[i]).sum() for i, o in enumerate(outs))
+        loss.backward()
+        res[pair] = dict(g_logits=lg.grad.cpu(), g_sigma=sg.grad.cpu() if mix else torch.zeros(1),
+                         g_Rt0=Rts[0].grad.cpu(), g_Rt1=Rts[1].grad.cpu())
+    a, b = res[True], res[False]
+    assert float(b["g_logits"].abs().max()) > 0
+    exact = max(zooms) == 1.0
+    for k in a:
+        if exact and not k.startswith("g_Rt"):    # (the pose gradients pass through torch's own reductions)
+            assert torch.equal(a[k], b[k]), (k, rel_err(a[k], b[k]))
+        else:
+            assert rel_err(a[k], b[k]) < 2e-6, (k, rel_err(a[k], b[k]))
+
+
 @pytest.mark.parametrize("B,N,H,W,mix,automask,rot,zoom", [
     (2, 7, 24, 80, True, True, 0.02, 1.0), (1, 9, 33, 70, True, False, 0.15, 1.0), (2, 5, 40, 150, False, True, 0.05, 1.0),
     (1, 3, 5, 7, True, False, 0.3, 1.0), (1, 63, 192, 640, True, True, 0.01, 1.0),
