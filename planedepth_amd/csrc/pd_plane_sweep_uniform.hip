@@ -23,7 +23,7 @@
 //           weight — keeps up to 12 (slot, weight) pairs in registers, and then gathers
 //           g[n][s] = sum_k w_k * scratch[n][t_k] for all planes with plain coalesced stores (PD_BWD_ACCUMULATE: added to
 //           what another target view left there).  The scratch reaches the gather through LDS: a workgroup owns a
-//           32 x 8 source tile and stages the tile's pre-image box two planes at a time
+//           32 x 16 source tile and stages the tile's pre-image box two planes at a time
 //           (uniform_bwd_pass2_staged_kernel; uniform_bwd_pass2_kernel is the direct-gather form and the follow-up for
 //           source pixels with more than 12 contributors, i.e. strong minification).  Every element of g_logits /
 //           g_sigma is written exactly once: no zero-fill, no atomics, deterministic.
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
 // Backward, pass 2 with the scratch staged through LDS
 // ---------------------------------------------------------------------------------------------------------------
 // The gather above issues one 8-byte load per list entry, plane and lane (4-6 of them) and is paced by that instruction
-// count.  Neighbouring source pixels share most of their contributors, so here a workgroup owns a 32 x 8 tile of source
-// pixels, copies the tile's pre-image box of the scratch (~35 x 12 target pixels for pose_net rotations) to LDS with
+// count.  Neighbouring source pixels share most of their contributors, so here a workgroup owns a 32 x 16 tile of source
+// pixels, copies the tile's pre-image box of the scratch (~35 x 20 target pixels for pose_net rotations) to LDS with
 // coalesced loads — kStageP planes at a time, the next group's loads in flight while the current one is reduced — and
 // the list entries become ds_read_b64s.  A box that does not fit kStageBox pixels (strong rotation / minification)
 // makes the workgroup take the direct gather of the kernel above (workgroup-uniform branch, same lists).
@@ -449,11 +449,15 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_kernel(SweepArgs a, 
 #ifndef PD_STAGE_P
 #define PD_STAGE_P 2
 #endif
-constexpr int kStageW = 32, kStageH = 8, kStageP = PD_STAGE_P, kStageBox = 1024;
-constexpr int kStagePre = (kStageBox * kStageP + kBlock - 1) / kBlock;   // staged elements per thread and group
+#ifndef PD_STAGE_H
+#define PD_STAGE_H 16   // 32 x 16 source tiles, 512 threads: the tile's pre-image box holds 1.37x the tile's scratch elements, a 32 x 8
+#endif                 // tile's 1.64x — and that overlap is re-read through the L1s (pass 2 0.215 -> 0.185 ms, pair 0.420 -> 0.407)
+constexpr int kStageW = 32, kStageH = PD_STAGE_H, kStageP = PD_STAGE_P, kStageBox = 1024;
+constexpr int kStageThreads = kStageW * kStageH;   // one thread per source pixel of the tile
+constexpr int kStagePre = (kStageBox * kStageP + kStageThreads - 1) / kStageThreads;   // staged elements per thread and group
 
 template <bool MIX>
-__global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
+__global__ __launch_bounds__(kStageThreads) void uniform_bwd_pass2_staged_kernel(SweepArgs a, int b0, const float* __restrict__ tmp,
                                                                           const UniPrep* __restrict__ prep,
                                                                           float* __restrict__ g_logits, float* __restrict__ g_sigma,
                                                                           int* __restrict__ overflow_flag, int tiles_x, int accumulate) {
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
   int e_pl[kStagePre], e_rc[kStagePre], e_q[kStagePre];   // plane within the group (-1: none), pixel offset, box slot
 #pragma unroll
   for (int j = 0; j < kStagePre; ++j) {
-    const int e = tid + j * kBlock;
+    const int e = tid + j * kStageThreads;
     const int pp = e / max(npx, 1), q = e - pp * npx;
     const int ry = q / max(bw, 1), rx = q - ry * bw;
     e_pl[j] = e < per_group ? pp : -1;
@@ -621,13 +625,13 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_staged_kernel(SweepA
 // ---------------------------------------------------------------------------------------------------------------
 // The reference's mono training sweeps two novel frames (-1, +1) over the same logits / sigma (trainer.py:532), so their
 // gradients land in the same tensors: as two passes the second one reads what the first one wrote (385 MB at
-// 8x49x192x640) and both write the full tensors.  Here one workgroup owns the 32 x 8 source tile for BOTH views: two
+// 8x49x192x640) and both write the full tensors.  Here one workgroup owns the 32 x 16 source tile for BOTH views: two
 // gather lists per source pixel, the two scratch boxes of a plane staged side by side (one plane per step and view, so
 // the LDS footprint stays that of the single-view kernel), one store per gradient element.  A source pixel whose list
 // overflows in a view takes nothing from that view here; that view's follow-up kernel (uniform_bwd_pass2_kernel<.., true>,
 // accumulate) adds it.  Boxes that do not fit make the workgroup gather both views directly.
 constexpr int kPairViews = 2, kPairK = 10;      // list entries kept per view (12 in the single-view kernel: 142 VGPRs here)
-constexpr int kPairPre = kStageBox / kBlock;    // staged elements per thread, view and plane
+constexpr int kPairPre = kStageBox / kStageThreads;    // staged elements per thread, view and plane
 struct PairArgs {
   int N, H, W;
   const float* plane[kPairViews];
@@ -638,7 +642,7 @@ struct PairArgs {
 };
 
 template <bool MIX>
-__global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_pair_kernel(PairArgs pa, float* __restrict__ g_logits,
+__global__ __launch_bounds__(kStageThreads) void uniform_bwd_pass2_pair_kernel(PairArgs pa, float* __restrict__ g_logits,
                                                                         float* __restrict__ g_sigma, int tiles_x, int accumulate) {
   typedef typename std::conditional<MIX, float2, float>::type Elem;
   __shared__ Elem buf[2][kPairViews][kStageBox];
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_pair_kernel(PairArgs
   for (int v = 0; v < kPairViews; ++v)
 #pragma unroll
     for (int j = 0; j < kPairPre; ++j) {
-      const int q = tid + j * kBlock;
+      const int q = tid + j * kStageThreads;
       const int ry = q / max(bw[v], 1), rx = q - ry * bw[v];
       e_rc[v][j] = q < npx[v] ? (by0[v] + ry) * W + (bx0[v] + rx) : -1;
     }
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass2_pair_kernel(PairArgs
     for (int v = 0; v < kPairViews; ++v)
 #pragma unroll
       for (int j = 0; j < kPairPre; ++j)
-        if (e_rc[v][j] >= 0) buf[which][v][tid + j * kBlock] = pre[v][j];
+        if (e_rc[v][j] >= 0) buf[which][v][tid + j * kStageThreads] = pre[v][j];
   };
   float nextl = 0.0f, nexts = 0.0f;
   auto fetch_old = [&](int n) {
@@ -1095,7 +1099,7 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
       else        uniform_bwd_pass1_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       if (defer) { /* the caller gathers: pd_uniform_gather_pair */ }
       else {
-      if (staged) uniform_bwd_pass2_staged_kernel<true><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, stiles_x, accumulate);
+      if (staged) uniform_bwd_pass2_staged_kernel<true><<<sgrid, kStageThreads, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, o.g_sigma, overflow, run_flag, accumulate);
       }
@@ -1104,7 +1108,7 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
       else        uniform_bwd_pass1_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, o, b0, tmp, part_two, tw, run_flag);
       if (defer) { /* the caller gathers: pd_uniform_gather_pair */ }
       else {
-      if (staged) uniform_bwd_pass2_staged_kernel<false><<<sgrid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, stiles_x, accumulate);
+      if (staged) uniform_bwd_pass2_staged_kernel<false><<<sgrid, kStageThreads, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, stiles_x, accumulate);
       else uniform_bwd_pass2_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
       uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, b0, tmp, prep, o.g_logits, nullptr, overflow, run_flag, accumulate);
       }
@@ -1146,8 +1150,8 @@ int uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const floa
   pa.overflow[0] = wa.overflow; pa.overflow[1] = wb.overflow;
   const int stiles_x = ceil_div(d->W, kStageW);
   const dim3 sgrid(stiles_x * ceil_div(d->H, kStageH), d->B), grid(ceil_div(d->H * d->W, kBlock), d->B);
-  if (mix) uniform_bwd_pass2_pair_kernel<true><<<sgrid, kBlock, 0, stream>>>(pa, g_logits, g_sigma, stiles_x, accumulate);
-  else     uniform_bwd_pass2_pair_kernel<false><<<sgrid, kBlock, 0, stream>>>(pa, g_logits, nullptr, stiles_x, accumulate);
+  if (mix) uniform_bwd_pass2_pair_kernel<true><<<sgrid, kStageThreads, 0, stream>>>(pa, g_logits, g_sigma, stiles_x, accumulate);
+  else     uniform_bwd_pass2_pair_kernel<false><<<sgrid, kStageThreads, 0, stream>>>(pa, g_logits, nullptr, stiles_x, accumulate);
   // source pixels with more than kPairK contributors in a view: that view's follow-up adds them (returns at once otherwise)
   for (int v = 0; v < 2; ++v) {
     SweepArgs a{};
