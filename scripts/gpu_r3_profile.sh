@@ -4,7 +4,8 @@
 export TMPDIR=/tmp
 REPO=$PWD
 OUT=gpurun_out/r3/profile
-rm -rf $OUT; mkdir -p $OUT/pmc
+if [ -z "$ONLY_CONFIGS" ]; then rm -rf $OUT; fi; mkdir -p $OUT/pmc
+if [ -z "$ONLY_CONFIGS" ]; then
 stats() {  # name flags...
   name=$1; shift
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/$name -o k -- python $REPO/bench.py --steps 30 --warmup 5 --no_cpu_baseline --no_next_rows --no_ddp_step "$@" > $REPO/$OUT/$name.log 2>&1); echo "stats $name rc=$?"
@@ -75,8 +76,9 @@ for k, d in out.items():
 print("calibration", json.dumps(calib["kernels"], indent=1))
 PY
 rm -rf $OUT/pmc
-# configuration table
-b() { name=$1; shift; timeout 400 python bench.py --steps 30 --warmup 5 --no_cpu_baseline --no_next_rows --no_ddp_step "$@" > $OUT/cfg_$name.log 2>&1; echo "| $name | \`$*\` | $(python - $OUT/cfg_$name.log <<'PY'
+fi   # ONLY_CONFIGS
+# configuration table (100 timed steps after 20: a fresh process runs its first ~50 steps slower)
+b() { name=$1; shift; timeout 400 python bench.py --steps 100 --warmup 20 --no_cpu_baseline --no_next_rows --no_ddp_step "$@" > $OUT/cfg_$name.log 2>&1; echo "| $name | \`$*\` | $(python - $OUT/cfg_$name.log <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
 k = d.get('kernels', {})
