@@ -74,6 +74,14 @@ for label, kw, run, extra in (("192x640x49 mixture", {}, {}, None),
     got = run_product(case, run, opt_extra=extra)
     add("full size %s" % label, "oracle fp32", got, run_oracle(case, run), run_oracle(case, run, dtype=torch.float64))
 
+# one homography per PLANE (a pose with rotation and translation, --use_colmap): general forward + the two-pass gather backward
+from planedepth_amd.synthetic import small_pose  # noqa: E402
+case = survey_fullsize_case(sigma_interior=True)
+case["Rt"] = small_pose(torch.Generator().manual_seed(99), 1)
+run = dict(warp_type="homography_warp")
+add("full size 192x640x49 homography_warp 6-DoF pose (gather backward)", "oracle fp32", run_product(case, run),
+    run_oracle(case, run), run_oracle(case, run, dtype=torch.float64))
+
 fmt = lambda v: "—" if v is None else "%.1e" % v  # noqa: E731
 out = ["| configuration | compared with | tensor | vs reference fp32 | vs fp64 | reference fp32 vs fp64 | elements beyond 1e-4·\\|b\\| + 1e-4·max\\|b\\| |",
        "|---|---|---|---|---|---|---|"]
