@@ -86,6 +86,7 @@ struct StreamLds {
   float4* ctx1;   // [CW] (gr0, gr1, gr2, gdotr)
   float4* ctx2;   // [CW] (invS, mx, A, -)
   float4* col;    // [CW] vertically blended source colour (r, g, b, -), zero beyond the row
+  float2* colgb;  // PK layout (rows too wide for two workgroups per CU otherwise): (g, b) here, r in ctx2[].w, `col` unused
   int2* shift;    // [N]  (bits of s*d clamped, k << 1 | irregular) — integers: a float-typed slot may flush the denormal pattern
   float* red;     // [N]  disparity-gradient sums of the row
   float* hand;    // [nwaves][2] carries that leave a wave's range in the middle of a row
@@ -100,6 +101,17 @@ __device__ __forceinline__ PixelCtx ctx_at(const StreamLds& L, int cell) {
   c.gr0 = g.x; c.gr1 = g.y; c.gr2 = g.z; c.gdotr = g.w;
   c.invS = h.x; c.mx = h.y; c.A = h.z;
   return c;
+}
+
+// blended source colour of cell i; PK: 56 instead of 64 bytes of LDS per cell (the two spare floats of the plain layout gone)
+template <bool PK>
+__device__ __forceinline__ float4 col_at(const StreamLds& L, int i) {
+  if (PK) {
+    const float r = L.ctx2[i].w;
+    const float2 gb = L.colgb[i];
+    return make_float4(r, gb.x, gb.y, 0.0f);
+  }
+  return L.col[i];
 }
 
 // ix of the reference for target column xtf (an integer-valued float) under the shift sd: make_col_tap's chain
@@ -146,7 +158,7 @@ __device__ __forceinline__ void stream_issue(StreamGroup<NROWS>& g, const SweepA
 
 // One regular (plane, segment) iteration.  carry_*: right-tap contribution of the previous segment's last slot (wave
 // uniform); returns this segment's in the same variables.
-template <bool MIX, int NROWS>
+template <bool MIX, int NROWS, bool PK>
 __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, const SweepArgs& a, const BwdOut& o,
                                                const StreamRow& r, const StreamLds& L, int n, int seg, int k, float sd,
                                                int lane, unsigned lane8, float lane2f, int HW, float Wm1, float rcpWm1,
@@ -157,8 +169,7 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
   const float xt0f = xs0f - (float)k;   // integers below 2^24: exact
   // context of the two paired targets xt, xt+1: adjacent cells (guard cells two deep on both sides keep them adjacent)
   const int cell = min(max(xs0 - k, -2), a.W) + 2;
-  const float4* colp = L.col + xs0 + 2;
-  const float4 cv0 = colp[0], cv1 = colp[1], cv2 = colp[2];
+  const float4 cv0 = col_at<PK>(L, xs0 + 2), cv1 = col_at<PK>(L, xs0 + 3), cv2 = col_at<PK>(L, xs0 + 4);
   float cl0[kSlots], cl1[kSlots], cs0[kSlots], cs1[kSlots];
 #pragma unroll
   for (int i = 0; i < kSlots; ++i) {
@@ -214,7 +225,7 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
 // General form for one paired slot xs of plane n (n may differ per lane): the target xt = xs - k with its EXACT
 // floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
 // Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
-template <bool MIX, int NROWS>
+template <bool MIX, int NROWS, bool PK>
 __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs + scratch — measured)
     const SweepArgs& a, const BwdOut& o, const StreamRow& r,
                                                      const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
@@ -238,7 +249,7 @@ __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs
   const float l = la0 * a0 + la1 * a1 + lb0 * b0 + lb1 * b1;
   const float s = sa0 * a0 + sa1 * a1 + sb0 * b0 + sb1 * b1;
   const float dlx = (la1 - la0) * wA + (lb1 - lb0) * wB, dsx = (sa1 - sa0) * wA + (sb1 - sb0) * wB;
-  const float4 ca = L.col[min(max(t.x0, -2), L.CW - 4) + 2], cb = L.col[min(max(t.x0 + 1, -2), L.CW - 4) + 2];
+  const float4 ca = col_at<PK>(L, min(max(t.x0, -2), L.CW - 4) + 2), cb = col_at<PK>(L, min(max(t.x0 + 1, -2), L.CW - 4) + 2);
   const float c0 = ca.x * t.w0 + cb.x * t.w1, c1 = ca.y * t.w0 + cb.y * t.w1, c2 = ca.z * t.w0 + cb.z * t.w1;
   const PixelCtx c = ctx_at(L, xt + 2);
   const PlaneGrad pg = plane_grad<MIX>(c, l, s, c0, c1, c2);
@@ -256,7 +267,7 @@ __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs
   return pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * (cb.x - ca.x) + pg.gc1 * (cb.y - ca.y) + pg.gc2 * (cb.z - ca.z);
 }
 
-template <bool MIX, int NROWS>
+template <bool MIX, int NROWS, bool PK>
 __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, const StreamLds& L) {
   constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
   const int W = a.W, N = a.N, HW = a.H * a.W;
@@ -294,8 +305,9 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     }
     L.ctx0[cidx] = make_float4(c.t0, c.t1, c.t2, c.lse2);
     L.ctx1[cidx] = make_float4(c.gr0, c.gr1, c.gr2, c.gdotr);
-    L.ctx2[cidx] = make_float4(c.invS, c.mx, c.A, 0.0f);
-    L.col[cidx] = cc;
+    L.ctx2[cidx] = make_float4(c.invS, c.mx, c.A, PK ? cc.x : 0.0f);
+    if (PK) L.colgb[cidx] = make_float2(cc.y, cc.z);
+    else L.col[cidx] = cc;
   }
   if (threadIdx.x == 0) *L.special = 0;
   __syncthreads();
@@ -356,12 +368,12 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     if (kk & 1) {   // irregular plane (wave-uniform branch): exact per-lane floor, atomics into the zero-filled row
 #pragma unroll
       for (int i = 0; i < kSlots; ++i) {
-        const float gd = stream_general_slot<MIX, NROWS>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
+        const float gd = stream_general_slot<MIX, NROWS, PK>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
         if (want_plane) gacc += gd;
       }
       carry_l = carry_s = 0.0f;
     } else {
-      stream_compute<MIX, NROWS>(grp, a, o, r, L, n, seg, k, sd, lane, lane8, lane2f, HW, Wm1, rcpWm1, want_plane, gl_bytes,
+      stream_compute<MIX, NROWS, PK>(grp, a, o, r, L, n, seg, k, sd, lane, lane8, lane2f, HW, Wm1, rcpWm1, want_plane, gl_bytes,
                                  gs_bytes, carry_l, carry_s, gacc);
     }
     advance(n, seg);
@@ -420,7 +432,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
       const bool irr = kk & 1;
       const int xs = (which == 0) ? -1 : ((which == 1) ? -2 : s_end);
       const bool on = (which == 0) || irr;
-      const float gd = stream_general_slot<MIX, NROWS>(a, o, r, L, pn2, xs, k, __int_as_float(sh.x), on, HW, Wm1, rcpWm1);
+      const float gd = stream_general_slot<MIX, NROWS, PK>(a, o, r, L, pn2, xs, k, __int_as_float(sh.x), on, HW, Wm1, rcpWm1);
       if (want_plane && gd != 0.0f) atomicAdd(&L.red[pn2], gd);
     }
     __syncthreads();
@@ -436,20 +448,21 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   }
 }
 
-template <bool MIX>
+template <bool MIX, bool PK>
 __global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   StreamLds L;
   const int nseg = (a.W + kSeg - 1) / kSeg;
   L.CW = nseg * kSeg + 4;
   L.ctx0 = lds4; L.ctx1 = lds4 + L.CW; L.ctx2 = lds4 + 2 * L.CW; L.col = lds4 + 3 * L.CW;
-  L.shift = reinterpret_cast<int2*>(lds4 + 4 * L.CW);
+  L.colgb = reinterpret_cast<float2*>(lds4 + 3 * L.CW);
+  L.shift = PK ? reinterpret_cast<int2*>(L.colgb + L.CW) : reinterpret_cast<int2*>(lds4 + 4 * L.CW);
   L.red = reinterpret_cast<float*>(L.shift + a.N);
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
   const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
-  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2>(a, o, row, L);
-  else                                     stream_body<MIX, 1>(a, o, row, L);
+  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK>(a, o, row, L);
+  else                                     stream_body<MIX, 1, PK>(a, o, row, L);
 }
 
 __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
@@ -464,37 +477,54 @@ __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, fl
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves) {
+// LDS of a row workgroup.  Plain layout: four float4 per cell (64 B; the colour's and ctx2's fourth floats unused); packed:
+// the colour's r in ctx2's spare float and (g, b) as a float2 (56 B) — two more LDS reads per item, so it is used only where
+// it buys a workgroup per CU (192 x 640: 42 KB, three workgroups either way; 384 x 1280: 83 KB = ONE workgroup plain,
+// 72 KB = two packed).
+static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves, bool packed) {
   const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
-  return CW * 4 * sizeof(float4) + (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
+  return CW * (packed ? 3 * sizeof(float4) + sizeof(float2) : 4 * sizeof(float4)) +
+         (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
 }
-static int rowstream_waves(const pd_sweep_desc* d) {
+struct StreamShape { int nwaves; bool packed; size_t lds; };
+static StreamShape rowstream_shape(const pd_sweep_desc* d) {
+  constexpr size_t kCuLds = 160 * 1024;
+  // workgroups per CU by LDS (at most three: 24 waves per CU at the kernel's 77 VGPRs); waves per workgroup to fill them:
+  // three workgroups of 8, two of 12, one of 16
+  const int wg_plain = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, false));
+  const int wg_packed = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, true));
+  StreamShape s;
+  s.packed = wg_plain < 3 && wg_packed > wg_plain;
+  const int wg = s.packed ? wg_packed : wg_plain;
+  const int w = wg >= 3 ? PD_STREAM_WAVES : wg == 2 ? (3 * PD_STREAM_WAVES) / 2 : 2 * PD_STREAM_WAVES;
   const int items = d->N * ceil_div(d->W, kSeg);
-  // 8 waves per row workgroup while three of them fit a CU's LDS (W <= ~800: 24 waves per CU at the kernel's 77 VGPRs);
-  // wider rows stage more context per workgroup, so they get 16 waves to keep the CU's wave slots filled
-  const int w = rowstream_lds_bytes(d, PD_STREAM_WAVES) * 3 <= 160 * 1024 ? PD_STREAM_WAVES : 2 * PD_STREAM_WAVES;
-  return items < w ? items : w;
+  s.nwaves = items < w ? items : w;
+  s.lds = rowstream_lds_bytes(d, s.nwaves, s.packed);
+  return s;
 }
 
 bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
   return rowshift_applicable(d) && !(d->flags & PD_RENDER_PROB) && !a.has_mask && (d->W % 2 == 0) &&
-         rowstream_lds_bytes(d, rowstream_waves(d)) <= 160 * 1024;
+         rowstream_shape(d).lds <= 160 * 1024;
 }
 
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
 
+template <bool MIX, bool PK>
+static void rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+  if (shmem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<MIX, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  rowstream_bwd_kernel<MIX, PK><<<grid, block, shmem, stream>>>(a, o);
+}
+
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
-  const int nwaves = rowstream_waves(d);
-  dim3 grid(d->H, d->B), block(nwaves * kWave);
-  const size_t shmem = rowstream_lds_bytes(d, nwaves);
+  const StreamShape sh = rowstream_shape(d);
+  dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
-  if (mix) {
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    rowstream_bwd_kernel<true><<<grid, block, shmem, stream>>>(a, o);
-  } else {
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    rowstream_bwd_kernel<false><<<grid, block, shmem, stream>>>(a, o);
-  }
+  if (mix) { if (sh.packed) rowstream_launch<true, true>(a, o, grid, block, sh.lds, stream);
+             else           rowstream_launch<true, false>(a, o, grid, block, sh.lds, stream); }
+  else     { if (sh.packed) rowstream_launch<false, true>(a, o, grid, block, sh.lds, stream);
+             else           rowstream_launch<false, false>(a, o, grid, block, sh.lds, stream); }
   int rc = check_launch("rowstream_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
   reduce_rows_stream_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);
