@@ -284,6 +284,93 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void fwdstream(const float* __rest
   }
 }
 
+// ---- forward shape, R rows per wave: a wave owns one 128-pixel segment of R CONSECUTIVE rows and all planes; per plane it
+// loads its segment of the R rows back to back (R loads per tensor within 2.5 KB x R of one plane) before it hops to the
+// next plane — does staying on a plane for R loads (DRAM page / TLB locality) buy what walking a row buys the backward?
+template <int D, int K, int OCC, int R>
+__global__ __launch_bounds__(5 * 64, OCC) void fwdrows(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                      const float* __restrict__ ctx_src, const int* __restrict__ kshift,
+                                                      float* __restrict__ outp, int N, int H, int W, int Bn) {
+  extern __shared__ v4f lds[];
+  const int RS = W + 8;
+  const int id = blockIdx.x, b = id % Bn, y0 = (id / Bn) * R;
+  const long HW = (long)H * W;
+  for (int x = threadIdx.x; x < RS * R; x += blockDim.x) {
+    const int r = x / RS, xi = x - r * RS - 4;
+    v4f cc = {0, 0, 0, 0};
+    if (xi >= 0 && xi < W) { const float* p = ctx_src + ((long)b * 13) * HW + (long)(y0 + r) * W + xi; cc = v4f{p[0], p[HW], p[2 * HW], 0}; }
+    lds[x] = cc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xt0 = wave * 128 + lane * 2;
+  const float* Ab = A + (long)b * N * HW + (long)y0 * W; const float* Bb = Bt + (long)b * N * HW + (long)y0 * W;
+  float t[R][6], acc[R][16];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float* tp = ctx_src + ((long)b * 13 + 3) * HW + (long)(y0 + r) * W + min(xt0, W - 2);
+    t[r][0] = tp[0]; t[r][1] = tp[1]; t[r][2] = tp[HW]; t[r][3] = tp[HW + 1]; t[r][4] = tp[2 * HW]; t[r][5] = tp[2 * HW + 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+  }
+  struct G { float a[R][3], b[R][3]; };
+  auto issue = [&](G& g, int n_raw) {
+    const int n = min(n_raw, N - 1);
+    const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned off = (unsigned)(r * W + xt0 + k) * 4;
+      const v3f va = ld3(rsrc(Ab + (unsigned)(n * (int)HW), (R * W) * 4), off), vb = ld3(rsrc(Bb + (unsigned)(n * (int)HW), (R * W) * 4), off);
+      g.a[r][0] = va.x; g.a[r][1] = va.y; g.a[r][2] = va.z; g.b[r][0] = vb.x; g.b[r][1] = vb.y; g.b[r][2] = vb.z;
+    }
+  };
+  auto compute = [&](const G& g, int n) {
+    const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const v4f* cp = lds + r * RS + min(max(xt0 + k, -4), W + 1) + 4;
+      const v4f c0 = cp[0], c1 = cp[1], c2 = cp[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float l = g.a[r][i] * 0.25f + g.a[r][i + 1] * 0.75f, s = g.b[r][i] * 0.25f + g.b[r][i + 1] * 0.75f;
+        const v4f ca = i ? c1 : c0, cb = i ? c2 : c1;
+        const float cr = ca.x * 0.25f + cb.x * 0.75f, cg = ca.y * 0.25f + cb.y * 0.75f, cbl = ca.z * 0.25f + cb.z * 0.75f;
+        const float q = burn<K>(l + t[r][i], s + t[r][2 + i], cr + t[r][4 + i], cg + cbl);
+        acc[r][i * 8 + 0] += q; acc[r][i * 8 + 1] += l; acc[r][i * 8 + 2] += s * q; acc[r][i * 8 + 3] += cr * q;
+        acc[r][i * 8 + 4] += cg * q; acc[r][i * 8 + 5] += cbl * q; acc[r][i * 8 + 6] += q * l; acc[r][i * 8 + 7] += q * s;
+      }
+    }
+  };
+  G g[D + 1];
+#pragma unroll
+  for (int q = 0; q < D; ++q) issue(g[q], q);
+  int n = 0;
+  for (; n + (D + 1) <= N; n += D + 1) {
+#pragma unroll
+    for (int q = 0; q < D + 1; ++q) { issue(g[(q + D) % (D + 1)], n + q + D); compute(g[q], n + q); }
+  }
+#pragma unroll
+  for (int q = 0; q < D + 1; ++q) if (n + q < N) { issue(g[(q + D) % (D + 1)], n + q + D); compute(g[q], n + q); }
+  if (xt0 < W) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v2f v = {acc[r][c], acc[r][8 + c]};
+        *reinterpret_cast<v2f*>(outp + ((long)b * 8 + c) * HW + (long)(y0 + r) * W + xt0) = v;
+      }
+  }
+}
+
+template <int D, int K, int OCC, int R> static void runr(int B, int N, int H, int W) {
+  const size_t ldsb = (size_t)(W + 8) * 16 * R + 64;
+  CK(hipFuncSetAttribute((const void*)fwdrows<D, K, OCC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  const double ms = time_ms([&] { fwdrows<D, K, OCC, R><<<dim3(H / R * B), 5 * 64, ldsb>>>(A, Bt, ctx, ks, GA, N, H, W, B); });
+  CK(hipGetLastError());
+  const double bytes = (double)B * H * W * 4 * (2 * N + 9 + 8);
+  printf("FWDROWS W=%4d D=%d K=%3d occ=%d rows=%d lds=%zu  %7.3f ms  %7.1f GB/s\n", W, D, K, OCC, R, ldsb, ms, bytes / 1e9 / (ms * 1e-3));
+}
+
 template <int D, int K, int WAVES, int OCC, int SEGS = 1> static void runf(int B, int N, int H, int W) {
   const int nseg = (W + 127) / 128, split = WAVES / (nseg / SEGS);
   const size_t ldsb = (size_t)(W + 8) * 16 + (size_t)nseg * (split - 1) * 16 * 64 * 4 + 64;
@@ -308,6 +395,13 @@ int main(int argc, char** argv) {
     run<2, 4, 0, 1, 8, 4>(B, N, H, W); run<2, 6, 0, 1, 8, 4>(B, N, H, W);
     run<1, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2>(B, N, H, W); run<4, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2, 8, 4>(B, N, H, W);
     run<2, 2, 0, 3, 8, 4>(B, N, H, W); run<4, 2, 0, 3, 8, 4>(B, N, H, W); run<2, 4, 0, 3, 8, 4>(B, N, H, W);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'r') {   // forward shape, R rows per wave (five waves = one segment each; W = 640)
+    runr<1, 0, 4, 1>(B, N, H, W); runr<2, 0, 4, 1>(B, N, H, W); runr<1, 0, 4, 2>(B, N, H, W); runr<2, 0, 4, 2>(B, N, H, W);
+    runr<1, 0, 4, 4>(B, N, H, W); runr<1, 0, 3, 4>(B, N, H, W); runr<1, 0, 2, 8>(B, N, H, W);
+    runr<1, 40, 4, 1>(B, N, H, W); runr<1, 40, 4, 2>(B, N, H, W); runr<2, 40, 4, 2>(B, N, H, W); runr<1, 40, 3, 4>(B, N, H, W);
+    runr<1, 60, 4, 1>(B, N, H, W); runr<1, 60, 4, 2>(B, N, H, W); runr<1, 60, 3, 4>(B, N, H, W);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'f') {   // forward shape
