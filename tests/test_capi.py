@@ -71,6 +71,16 @@ def test_argument_validation_needs_no_gpu():
     assert lib.pd_cat_flip(0, 3, 8, 8, None, None, 0, None, None) == 1
     assert lib.pd_mixture_nll_fwd(1, 4, 8, 8, 1, None, None, None, None, None) == 1
     assert lib.pd_decoder_tail_bwd_workspace_floats(2, 49, 192, 640) == 2 * 480 * 49
+    # round 3: the pair gather takes the descriptor of two deferred plane-uniform backward calls, nothing else
+    d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_HOMOGRAPHY, C.PD_MIXTURE | C.PD_HOMO_UNIFORM, 0.0, 0)
+    assert lib.pd_uniform_gather_pair(ctypes.byref(d), *([None] * 9)) == 1
+    assert b"PD_BWD_DEFER_GATHER" in lib.pd_last_error()
+    d.flags |= C.PD_BWD_DEFER_GATHER
+    assert lib.pd_uniform_gather_pair(ctypes.byref(d), *([None] * 9)) == 1
+    assert b"NULL" in lib.pd_last_error()
+    d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_HOMOGRAPHY, C.PD_MIXTURE | C.PD_BWD_DEFER_GATHER, 0.0, 0)   # without PD_HOMO_UNIFORM
+    assert lib.pd_plane_sweep_bwd(ctypes.byref(d), *([None] * 20)) == 1
+    assert lib.pd_debug_gather_flags(ctypes.byref(d), None, None, None) == 1
 
 
 def test_ops_refuse_cpu_tensors():
