@@ -44,7 +44,7 @@ extern "C" int pd_experiments(void) {
   return 0;
 #endif
 }
-extern "C" int pd_version(void) { (void)pd::switches(); return 210; /* 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
+extern "C" int pd_version(void) { (void)pd::switches(); return 220; /* 0.2.2: gather backward for per-plane homographies (pd_debug_gather_flags), pd_uniform_gather_pair + PD_BWD_DEFER_GATHER, packed wide-row context; 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
 
 // Diagnostics: fill the LDS of (as good as) every CU with NaNs, so that a kernel that reads shared memory it never wrote
