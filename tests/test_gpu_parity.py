@@ -2060,6 +2060,7 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     return Rt.to(device)
 
 
+@pytest.mark.parametrize("render", [False, True])
 @pytest.mark.parametrize("B,N,H,W,mix,rots,zooms,with_stereo", [
     (2, 7, 24, 80, True, (0.02, 0.03), (1.0, 1.0), True),       # two pose-net frames behind a disp_warp view (accumulate)
     (2, 7, 24, 80, True, (0.02, 0.03), (1.0, 1.0), False),      # the pair starts the sum (plain stores)
@@ -2068,7 +2069,7 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     (1, 4, 30, 90, True, (0.05, 0.02), (2.6, 1.0), False),      # one view 2.6x denser than the source: lists overflow -> follow-up
     (1, 4, 30, 90, True, (0.05, 0.02), (1.6, 1.55), True),      # 9-12 contributors: around the pair kernel's 10 slots
     (1, 49, 96, 320, True, (0.01, 0.012), (1.0, 1.0), True)])
-def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zooms, with_stereo, monkeypatch):
+def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zooms, with_stereo, render, monkeypatch):
     """pd_uniform_gather_pair (the second passes of the two novel frames of a step in one kernel: one store per gradient
     element) against the same node with the views' second passes one after the other (PD_PAIR_GATHER=0: read-modify-write
     per view).  Same contributions added in the same order -> the same bits in g_logits / g_sigma, unless a list overflows
@@ -2086,6 +2087,9 @@ def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zoo
     norm = torch.tensor([0.0, 0.0, 1.0])[None, None].repeat(B, N, 1).to(dev)
     disp = (torch.rand(B, N, 1, 1, generator=g) * 20 + 0.5).to(dev)
     K, inv_K = (t.to(dev) for t in intrinsics(B, H, W))
+    if render and (W > 100 or N > 9):
+        pytest.skip("render_probability: the small cases cover the pair kernel's independence of the compositing mode")
+    dists = (torch.rand(B, N - 1, H, W, generator=g) * 2.0).to(dev) if render else None
     res = {}
     for pair in (True, False):
         monkeypatch.setattr(ops, "PAIR_GATHER", pair)
@@ -2094,7 +2098,8 @@ def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zoo
         calls = []
         if with_stereo:
             calls.append(ops.plane_sweep_disp(src, tgts[2], lg, sg if mix else None, disp.expand(-1, -1, H, W), None,
-                                              target_side="r", use_mixture_loss=mix, return_mean=True, defer=True))
+                                              target_side="r", use_mixture_loss=mix, return_mean=True, defer=True,
+                                              render_probability=render, dists=dists))
         for v in range(2):
             Rt = _f8_pose(B, 31 + H + v, rots[v], dev)
             Rt[:, :2, :3] *= zooms[v]
@@ -2102,7 +2107,7 @@ def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zoo
             Rts.append(Rt)
             calls.append(ops.plane_sweep_homography(src, tgts[v], lg, sg if mix else None, distance, norm, Rt, K, inv_K,
                                                     use_mixture_loss=mix, automask=True, return_mean=True,
-                                                    plane_uniform=True, defer=True))
+                                                    plane_uniform=True, defer=True, render_probability=render, dists=dists))
         outs = ops.plane_sweep_multi(calls)
         loss = sum(o[2] * (i + 1.0) + (o[0] * gws[i]).sum() for i, o in enumerate(outs))
         loss.backward()
