@@ -2068,7 +2068,9 @@ def _f8_pose(B, seed, rot=0.02, device="cpu"):
     (1, 9, 64, 200, True, (0.5, 0.02), (1.0, 1.0), True),       # one view rotated by ~29 degrees: its box does not fit -> direct gathers
     (1, 4, 30, 90, True, (0.05, 0.02), (2.6, 1.0), False),      # one view 2.6x denser than the source: lists overflow -> follow-up
     (1, 4, 30, 90, True, (0.05, 0.02), (1.6, 1.55), True),      # 9-12 contributors: around the pair kernel's 10 slots
-    (1, 49, 96, 320, True, (0.01, 0.012), (1.0, 1.0), True)])
+    (1, 49, 96, 320, True, (0.01, 0.012), (1.0, 1.0), True),
+    (1, 3, 5, 7, True, (0.3, 0.1), (1.0, 1.0), False),          # smaller than one tile, odd sizes
+    (1, 4, 33, 71, True, (0.04, 0.02), (1.0, 1.0), False)])     # ragged tiles on both axes
 def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zooms, with_stereo, render, monkeypatch):
     """pd_uniform_gather_pair (the second passes of the two novel frames of a step in one kernel: one store per gradient
     element) against the same node with the views' second passes one after the other (PD_PAIR_GATHER=0: read-modify-write
