@@ -337,8 +337,38 @@ def next_rows_times(args, device, iters=100):
         ops.reprojection_loss(pred_leaf, img, True).backward(g_rl)
         pred_leaf.grad = None
 
+    def timed_graph(fn):
+        """The same call captured once in a HIP graph and replayed: what the DEVICE spends on it.  The eager figure of an
+        operator whose kernels take 30-50 us is the host's enqueue rate on whatever CPU the box has (0.05-0.16 ms measured
+        across boxes); inside a training step those launches are enqueued far ahead of the device."""
+        try:
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize(device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                graph.replay()
+            b.record()
+            torch.cuda.synchronize(device)
+            return round(a.elapsed_time(b) / iters, 4)
+        except Exception as e:   # a capture that fails must not take the bench line with it
+            torch.cuda.synchronize(device)
+            return "graph capture failed: %s" % type(e).__name__
+
     t_f, t_fb, t_s, t_p = timed(tail_fwd), timed(tail_fwd_bwd), timed(smooth_fwd_bwd), timed(post)
     t_r = timed(reproj_fwd_bwd)
+    g_s, g_r = timed_graph(smooth_fwd_bwd), timed_graph(reproj_fwd_bwd)
     hw4 = H * W * 4
     tail_f_bytes, tail_b_bytes = (3 * N + 4) * hw4 * B, (6 * N + 4) * hw4 * B
     post_bytes = (2 * (2 * N) + 2 * N + N + 3) * hw4 * Bp   # 2 warp-softmax (read N, write N) + 3 warp-sums (read N)
@@ -347,12 +377,14 @@ def next_rows_times(args, device, iters=100):
                          "fwd_GBs": round(tail_f_bytes / (t_f * 1e-3) / 1e9, 1),
                          "fwd_bwd_GBs": round((tail_f_bytes + tail_b_bytes) / (t_fb * 1e-3) / 1e9, 1),
                          "shape": [B, N, H, W]},
-        "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "shape": [B, 1, H, W - x0]},
-        "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "shape": [B, 3, H, W]},
+        "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "fwd_bwd_device_ms": g_s, "shape": [B, 1, H, W - x0]},
+        "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "fwd_bwd_device_ms": g_r, "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
                          "shape": [2 * Bp, N, H, W]},
         "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot (host-paced "
-                "where the Python / autograd overhead exceeds the kernels' time)" % iters,
+                "where the Python / autograd overhead exceeds the kernels' time: fwd_bwd_ms of the two small operators is the "
+                "box's CPU speed, 0.05-0.16 ms across boxes; fwd_bwd_device_ms is the same call replayed from a HIP graph, "
+                "i.e. the device's share)" % iters,
     }
 
 

@@ -122,6 +122,30 @@ def ptr(t):
 POISON_LDS = bool(int(os.environ.get("PD_DEBUG_POISON_LDS", "0")))   # diagnostics: NaNs into the CUs' LDS before every launch
 
 
+class _NoSwitch:
+    """`with` target that does nothing (the tensor's device already is the current one)."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(device):
+    """`with on_device(t.device):` — torch.cuda.device(device) only when a switch is needed.  The context manager costs
+    several microseconds per entry (two set_device calls and their bookkeeping), which is most of what the HOST spends on
+    an operator whose kernels take 30 us; on a one-GPU-per-process layout the tensor's device always is the current one."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def stream_handle(device=None):
     """The raw hipStream_t torch is currently enqueueing on (so our launches order with torch's ops)."""
     h = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -106,7 +106,7 @@ def _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_ma
     ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
     ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
     stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
-    with torch.cuda.device(logits.device), _timed("fwd"):
+    with C.on_device(logits.device), _timed("fwd"):
         rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                     C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                     C.ptr(rgb_rec), C.ptr(ph_map), C.ptr(ph_mean), C.ptr(stash),
@@ -146,7 +146,7 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=
     g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
     if g_ph_mean is not None:
         g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
-    with torch.cuda.device(logits.device), _timed("bwd"):
+    with C.on_device(logits.device), _timed("bwd"):
         rc = lib.pd_plane_sweep_bwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
                                     C.ptr(plane), C.ptr(plane_aux), C.ptr(inv_K3), C.ptr(padding_mask), C.ptr(dists),
                                     C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
@@ -170,7 +170,7 @@ def _gather_pair(view_a, view_b, cfg, g_logits, g_sigma, accumulate):
     mode, flags, sign = cfg
     mix = bool(flags & C.PD_MIXTURE)
     d = _desc(B, N, H, W, mode, flags | C.PD_BWD_DEFER_GATHER | (C.PD_BWD_ACCUMULATE if accumulate else 0), sign)
-    with torch.cuda.device(logits.device), _timed("bwd"):
+    with C.on_device(logits.device), _timed("bwd"):
         rc = lib.pd_uniform_gather_pair(ctypes.byref(d), C.ptr(saved_a[4]), C.ptr(saved_a[6]), C.ptr(ws_a),
                                         C.ptr(saved_b[4]), C.ptr(saved_b[6]), C.ptr(ws_b), C.ptr(g_logits),
                                         C.ptr(g_sigma if mix else None), C.stream_handle(logits.device))
@@ -441,7 +441,7 @@ class _HomographyMatrices(torch.autograd.Function):
             shift, mask = torch.empty(B, N, rows, device=dev), torch.empty(B, N, rows, device=dev)
         else:
             Hm = torch.empty(B, 4 if mode == C.PD_HMAT_UNIFORM else N, 3, 3, device=dev)
-        with torch.cuda.device(dev):
+        with C.on_device(dev):
             C.check(lib.pd_homography_matrices_fwd(B, N, mode, rows, C.ptr(distance), C.ptr(norm), C.ptr(T), C.ptr(K),
                                                    C.ptr(inv_K), C.ptr(Hm), C.ptr(Rn), C.ptr(shift), C.ptr(mask),
                                                    C.stream_handle(dev)), "pd_homography_matrices_fwd")
@@ -468,7 +468,7 @@ class _HomographyMatrices(torch.autograd.Function):
         gd = torch.empty(B, N, device=dev) if need_d else None
         gn = torch.empty(B, N, 3, device=dev) if need_n else None
         gT = torch.empty(B, 4, 4, device=dev) if need_T else None
-        with torch.cuda.device(dev):
+        with C.on_device(dev):
             C.check(lib.pd_homography_matrices_bwd(B, N, ctx.mode, ctx.rows, C.ptr(distance), C.ptr(norm), C.ptr(T),
                                                    C.ptr(K), C.ptr(inv_K), C.ptr(None if stereo else g_first),
                                                    C.ptr(g_first if stereo else None), C.ptr(gd), C.ptr(gn), C.ptr(gT),
@@ -608,7 +608,7 @@ def plane_sweep_layers(src, logits, sigma, *, disp_layered=None, padding_mask=No
                 continue
             out[k] = torch.empty(shapes[k], device=dev, dtype=torch.float32)
         d = _desc(B, N, H, W, mode, flags, sign)
-        with torch.cuda.device(dev):
+        with C.on_device(dev):
             rc = lib.pd_plane_sweep_layers(ctypes.byref(d), C.ptr(src.contiguous()), C.ptr(logits.contiguous()),
                                            C.ptr(_contig(sigma) if use_mixture_loss else None), C.ptr(plane),
                                            C.ptr(aux), C.ptr(k3), C.ptr(padding_mask),
@@ -632,7 +632,7 @@ class _SSIM(torch.autograd.Function):
         x, y = x.contiguous(), y.contiguous()
         B, Cc, H, W = x.shape
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with C.on_device(x.device):
             C.check(lib.pd_ssim_fwd(B, Cc, H, W, C.ptr(x), C.ptr(y), C.ptr(out), C.stream_handle(x.device)), "pd_ssim_fwd")
         ctx.save_for_backward(x, y)
         return out
@@ -646,7 +646,7 @@ class _SSIM(torch.autograd.Function):
         gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
         if gx is None and gy is None:
             return None, None
-        with torch.cuda.device(x.device):
+        with C.on_device(x.device):
             C.check(lib.pd_ssim_bwd(B, Cc, H, W, C.ptr(x), C.ptr(y), C.ptr(g.contiguous()), C.ptr(gx), C.ptr(gy),
                                     C.stream_handle(x.device)), "pd_ssim_bwd")
         return gx, gy
@@ -668,7 +668,7 @@ class _ReprojLoss(torch.autograd.Function):
         C.require_gpu_tensor("target", target, pred.shape)
         pred, target = pred.contiguous(), target.contiguous()
         loss = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
-        with torch.cuda.device(pred.device):
+        with C.on_device(pred.device):
             C.check(lib.pd_reproj_loss_fwd(B, H, W, int(use_ssim), C.ptr(pred), C.ptr(target), C.ptr(loss),
                                            C.stream_handle(pred.device)), "pd_reproj_loss_fwd")
         ctx.save_for_backward(pred, target)
@@ -682,7 +682,7 @@ class _ReprojLoss(torch.autograd.Function):
         B, _, H, W = pred.shape
         gp = torch.empty_like(pred)
         gt = torch.empty_like(target) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(pred.device):
+        with C.on_device(pred.device):
             C.check(lib.pd_reproj_loss_bwd(B, H, W, ctx.use_ssim, C.ptr(pred), C.ptr(target), C.ptr(g.contiguous()),
                                            C.ptr(gp), C.ptr(gt), C.stream_handle(pred.device)), "pd_reproj_loss_bwd")
         return gp, gt, None
@@ -703,7 +703,7 @@ class _MixtureNLL(torch.autograd.Function):
         C.require_gpu_tensor("sigma", sigma)
         C.require_gpu_tensor("pi", pi)
         out = torch.empty(B, 1, H, W, device=error.device, dtype=torch.float32)
-        with torch.cuda.device(error.device):
+        with C.on_device(error.device):
             C.check(lib.pd_mixture_nll_fwd(B, N, H, W, int(laplacian), C.ptr(error), C.ptr(sigma), C.ptr(pi), C.ptr(out),
                                            C.stream_handle(error.device)), "pd_mixture_nll_fwd")
         ctx.save_for_backward(error, sigma, pi)
@@ -720,7 +720,7 @@ class _MixtureNLL(torch.autograd.Function):
         gp = torch.empty_like(pi) if ctx.needs_input_grad[2] else None
         if ge is None and gs is None and gp is None:
             return None, None, None, None
-        with torch.cuda.device(error.device):
+        with C.on_device(error.device):
             C.check(lib.pd_mixture_nll_bwd(B, N, H, W, ctx.lap, C.ptr(error), C.ptr(sigma), C.ptr(pi),
                                            C.ptr(g.contiguous()), C.ptr(ge), C.ptr(gs), C.ptr(gp),
                                            C.stream_handle(error.device)), "pd_mixture_nll_bwd")
@@ -753,7 +753,7 @@ def warp_softmax(planes, disp_layered, sign, flip_src=False):
         planes = planes.detach().contiguous()
         disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
         out = torch.empty_like(planes)
-        with torch.cuda.device(planes.device):
+        with C.on_device(planes.device):
             C.check(lib.pd_warp_softmax(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
                                         C.ptr(planes), C.ptr(disp), C.ptr(out), C.stream_handle(planes.device)),
                     "pd_warp_softmax")
@@ -769,7 +769,7 @@ def warp_sum(planes, disp_layered, sign, cap=1.0, flip_src=False):
         planes = planes.detach().contiguous()
         disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
         out = torch.empty(B, 1, H, W, device=planes.device, dtype=torch.float32)
-        with torch.cuda.device(planes.device):
+        with C.on_device(planes.device):
             C.check(lib.pd_warp_sum(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
                                     C.ptr(planes), C.ptr(disp), float(cap), C.ptr(out),
                                     C.stream_handle(planes.device)), "pd_warp_sum")
@@ -806,7 +806,7 @@ def cat_flip(own, other, negate_c0=False):
     with torch.no_grad():
         own, other = own.contiguous(), other.contiguous()
         out = torch.empty(2 * B, Cn, H, W, device=own.device, dtype=torch.float32)
-        with torch.cuda.device(own.device):
+        with C.on_device(own.device):
             C.check(lib.pd_cat_flip(B, Cn, H, W, C.ptr(own), C.ptr(other), int(bool(negate_c0)), C.ptr(out),
                                     C.stream_handle(own.device)), "pd_cat_flip")
     return out
@@ -824,7 +824,7 @@ def crop_grid(params, height, width):
     B = params.shape[0]
     params = params.contiguous()
     grid = torch.empty(B, 2, int(height), int(width), device=params.device, dtype=torch.float32)
-    with torch.cuda.device(params.device):
+    with C.on_device(params.device):
         C.check(lib.pd_crop_grid(B, int(height), int(width), C.ptr(params), C.ptr(grid), C.stream_handle(params.device)),
                 "pd_crop_grid")
     return grid
@@ -851,7 +851,7 @@ class _MaskedPhotometric(torch.autograd.Function):
         pred = torch.empty_like(rgb_rec)
         partials = torch.empty(B * ((H * W + 255) // 256), device=dev)
         mean = torch.empty(1, device=dev)
-        with torch.cuda.device(dev):
+        with C.on_device(dev):
             C.check(lib.pd_masked_photometric_fwd(B, H, W, int(mix), C.ptr(rgb_rec), C.ptr(target), C.ptr(source),
                                                   C.ptr(mask), C.ptr(pm), C.ptr(pred), C.ptr(partials), C.ptr(mean),
                                                   C.stream_handle(dev)), "pd_masked_photometric_fwd")
@@ -870,7 +870,7 @@ class _MaskedPhotometric(torch.autograd.Function):
         g_rgb = torch.empty_like(rgb_rec) if ctx.needs_input_grad[0] else None
         g_ph = torch.empty(B, 1, H, W, device=dev) if (ctx.mix and ctx.needs_input_grad[1]) else None
         if g_rgb is not None or g_ph is not None:
-            with torch.cuda.device(dev):
+            with C.on_device(dev):
                 C.check(lib.pd_masked_photometric_bwd(B, H, W, int(ctx.mix), C.ptr(rgb_rec), C.ptr(target), C.ptr(source),
                                                       C.ptr(mask), C.ptr(g_mean), C.ptr(g_pred), C.ptr(g_rgb),
                                                       C.ptr(g_ph), C.stream_handle(dev)), "pd_masked_photometric_bwd")
@@ -907,7 +907,7 @@ class _SmoothLoss(torch.autograd.Function):
         out = torch.empty(1, device=disp.device, dtype=torch.float32)
         # the crop [..., x0:] is an offset on the two base pointers: same strides, W - x0 columns
         dptr, iptr = ctypes.c_void_p(disp.data_ptr() + 4 * x0), ctypes.c_void_p(img.data_ptr() + 4 * x0)
-        with torch.cuda.device(disp.device):
+        with C.on_device(disp.device):
             C.check(lib.pd_smooth_loss_fwd(B, Cn, H, W, dptr, disp.stride(0), disp.stride(2), iptr,
                                            img.stride(0), img.stride(1), img.stride(2), float(gamma), C.ptr(out),
                                            C.stream_handle(disp.device)), "pd_smooth_loss_fwd")
@@ -924,7 +924,7 @@ class _SmoothLoss(torch.autograd.Function):
         g_disp = torch.empty(B, 1, H, Wf, device=disp.device, dtype=torch.float32)
         g = g.reshape(1).contiguous().float()
         dptr, iptr = ctypes.c_void_p(disp.data_ptr() + 4 * x0), ctypes.c_void_p(img.data_ptr() + 4 * x0)
-        with torch.cuda.device(disp.device):
+        with C.on_device(disp.device):
             # one kernel writes the whole [B,1,H,W] gradient, zeros in the cropped-away columns included
             C.check(lib.pd_smooth_loss_bwd_padded(B, Cn, H, Wf - x0, x0, dptr, disp.stride(0), disp.stride(2), iptr,
                                                   img.stride(0), img.stride(1), img.stride(2), ctx.gamma, C.ptr(g),
@@ -964,7 +964,7 @@ class _DecoderTail(torch.autograd.Function):
         logits = new(B, N, H, W) if padding_mask is not None else None
         sigma = new(B, N, H, W) if mix else None
         disp, depth, stash = new(B, 1, H, W), new(B, 1, H, W), new(B, 2, H, W)
-        with torch.cuda.device(dev):
+        with C.on_device(dev):
             C.check(lib.pd_decoder_tail_fwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
                                             C.ptr(disp_layered), C.ptr(logits), C.ptr(sigma), C.ptr(disp), C.ptr(depth),
                                             C.ptr(stash), C.stream_handle(dev)), "pd_decoder_tail_fwd")
@@ -996,7 +996,7 @@ class _DecoderTail(torch.autograd.Function):
             ws = torch.empty(lib.pd_decoder_tail_bwd_workspace_floats(B, N, H, W), device=raw_logits.device,
                              dtype=torch.float32)
         g_logits, g_sigma, g_disp, g_depth = map(_contig, (g_logits, g_sigma if mix else None, g_disp, g_depth))
-        with torch.cuda.device(raw_logits.device):
+        with C.on_device(raw_logits.device):
             C.check(lib.pd_decoder_tail_bwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
                                             C.ptr(disp_layered), C.ptr(stash), C.ptr(disp), C.ptr(g_logits),
                                             C.ptr(g_sigma), C.ptr(g_disp), C.ptr(g_depth), C.ptr(g_raw_logits),
@@ -1032,7 +1032,7 @@ def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_
             pi = torch.empty_like(raw_logits) if want_pi else None
             prob = torch.empty_like(raw_logits) if want_probability else None
             rl, rs, pm = map(_contig, (raw_logits.detach(), raw_sigma.detach() if use_mixture_loss else None, padding_mask))
-            with torch.cuda.device(raw_logits.device):
+            with C.on_device(raw_logits.device):
                 C.check(lib.pd_decoder_tail_layers(B, N, H, W, flags, C.ptr(rl), C.ptr(rs), C.ptr(pm), C.ptr(stash),
                                                    C.ptr(pi), C.ptr(prob), C.stream_handle(raw_logits.device)),
                         "pd_decoder_tail_layers")
@@ -1053,7 +1053,7 @@ class _Backproject(torch.autograd.Function):
         C.require_gpu_tensor("inv_K", inv_K, (B, 4, 4))
         depth, inv_K = depth.contiguous(), inv_K.contiguous()
         cam = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
-        with torch.cuda.device(depth.device):
+        with C.on_device(depth.device):
             C.check(lib.pd_backproject(B, H, W, C.ptr(depth), C.ptr(inv_K), C.ptr(cam), C.stream_handle(depth.device)),
                     "pd_backproject")
         ctx.save_for_backward(inv_K)
@@ -1067,7 +1067,7 @@ class _Backproject(torch.autograd.Function):
         H, W = ctx.hw
         B = inv_K.shape[0]
         g_depth = torch.empty(B, 1, H, W, device=g_cam.device, dtype=torch.float32)
-        with torch.cuda.device(g_cam.device):
+        with C.on_device(g_cam.device):
             C.check(lib.pd_backproject_bwd(B, H, W, C.ptr(inv_K), C.ptr(g_cam.contiguous()), C.ptr(g_depth),
                                            C.stream_handle(g_cam.device)), "pd_backproject_bwd")
         return g_depth, None
@@ -1087,7 +1087,7 @@ class _Project3D(torch.autograd.Function):
         C.require_gpu_tensor("P", P, (B, 3, 4))
         cam, P = cam.contiguous(), P.contiguous()
         grid = torch.empty(B, H, W, 2, device=cam.device, dtype=torch.float32)
-        with torch.cuda.device(cam.device):
+        with C.on_device(cam.device):
             C.check(lib.pd_project3d(B, H, W, eps, C.ptr(cam), C.ptr(P), C.ptr(grid), C.stream_handle(cam.device)),
                     "pd_project3d")
         ctx.save_for_backward(cam, P)
@@ -1103,7 +1103,7 @@ class _Project3D(torch.autograd.Function):
         g_cam = torch.empty_like(cam) if ctx.needs_input_grad[0] else None
         g_P = torch.empty_like(P) if ctx.needs_input_grad[1] else None
         ws = torch.empty(12 * B * ((H * W + 255) // 256), device=cam.device, dtype=torch.float32) if g_P is not None else None
-        with torch.cuda.device(cam.device):
+        with C.on_device(cam.device):
             C.check(lib.pd_project3d_bwd(B, H, W, eps, C.ptr(cam), C.ptr(P), C.ptr(g_grid.contiguous()), C.ptr(g_cam),
                                          C.ptr(g_P), C.ptr(ws), C.stream_handle(cam.device)), "pd_project3d_bwd")
         return g_cam, g_P, None, None, None
@@ -1126,7 +1126,7 @@ class _HomographyGrid(torch.autograd.Function):
         H_t2s, Rn, inv_K3 = H_t2s.contiguous(), Rn.contiguous(), inv_K3.contiguous()
         grid = torch.empty(M, H, W, 2, device=H_t2s.device, dtype=torch.float32)
         mask = torch.empty(M, H, W, device=H_t2s.device, dtype=torch.uint8)
-        with torch.cuda.device(H_t2s.device):
+        with C.on_device(H_t2s.device):
             C.check(lib.pd_homography_grid(M, H, W, C.ptr(H_t2s), C.ptr(Rn), C.ptr(inv_K3), C.ptr(grid), C.ptr(mask),
                                            C.stream_handle(H_t2s.device)), "pd_homography_grid")
         ctx.save_for_backward(H_t2s)
@@ -1142,7 +1142,7 @@ class _HomographyGrid(torch.autograd.Function):
         M = H_t2s.shape[0]
         g_H = torch.empty_like(H_t2s)
         ws = torch.empty(9 * M * ((H * W + 255) // 256), device=H_t2s.device, dtype=torch.float32)
-        with torch.cuda.device(H_t2s.device):
+        with C.on_device(H_t2s.device):
             C.check(lib.pd_homography_grid_bwd(M, H, W, C.ptr(H_t2s), C.ptr(g_grid.contiguous()), C.ptr(g_H), C.ptr(ws),
                                                C.stream_handle(H_t2s.device)), "pd_homography_grid_bwd")
         return g_H, None, None, None, None
@@ -1169,7 +1169,7 @@ class _GridSample(torch.autograd.Function):
         C.require_gpu_tensor("grid", grid, (M, Ho, Wo, 2))
         inp, grid = inp.contiguous(), grid.contiguous()
         out = torch.empty(M, Cc, Ho, Wo, device=inp.device, dtype=torch.float32)
-        with torch.cuda.device(inp.device):
+        with C.on_device(inp.device):
             C.check(lib.pd_grid_sample_fwd(M, Cc, Hi, Wi, Ho, Wo, padding_mode, C.ptr(inp), C.ptr(grid), C.ptr(out),
                                            C.stream_handle(inp.device)), "pd_grid_sample_fwd")
         ctx.save_for_backward(inp, grid)
@@ -1186,7 +1186,7 @@ class _GridSample(torch.autograd.Function):
         g_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
         if g_in is None and g_grid is None:
             return None, None, None
-        with torch.cuda.device(inp.device):
+        with C.on_device(inp.device):
             C.check(lib.pd_grid_sample_bwd(M, Cc, Hi, Wi, Ho, Wo, ctx.padding_mode, C.ptr(inp), C.ptr(grid),
                                            C.ptr(g_out.contiguous()), C.ptr(g_in), C.ptr(g_grid),
                                            C.stream_handle(inp.device)), "pd_grid_sample_bwd")
