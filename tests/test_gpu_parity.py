@@ -217,9 +217,11 @@ def _stream_tol(W):
     (70, 11, 10, "r", True, dict(special_disp=[0.0, 1.0, 2.0, 1.9999999, 3.0000002, 7.5, 68.9999, 69.0, 75.0, 1e6], disp_min=0.5, disp_max=9.0)),
     (130, 7, 9, "l", True, dict(special_disp=[0.25, 1.0, 63.0, 64.0, 64.00001, 65.5, 127.99999, 129.0, 200.0], disp_min=0.5, disp_max=9.0)),
     (300, 8, 8, "r", False, dict(special_disp=[299.99997, 2.0000002, 1.9999998, 0.99999994, 100.0, 33.333332, 255.0, 256.00003], disp_min=0.5, disp_max=9.0)),
-    (1280, 6, 4, "r", True, dict(disp_min=2.0, disp_max=300.0)),
-    (2048, 3, 3, "l", True, dict(disp_min=2.0, disp_max=900.0)),      # 131 KB of context per row: one 16-wave workgroup per CU
-    (2600, 2, 2, "r", True, dict(disp_min=2.0, disp_max=900.0)),      # beyond the LDS: the row-shift / general kernels take over
+    (1280, 6, 4, "r", True, dict(disp_min=2.0, disp_max=300.0)),      # 83 KB plain = one workgroup per CU; packed 72 KB = two
+    (1024, 4, 9, "l", True, dict(disp_min=2.0, disp_max=400.0)),      # 66 KB of context per row: two 12-wave workgroups per CU
+    (2048, 3, 3, "l", True, dict(disp_min=2.0, disp_max=900.0)),      # 131 KB: one 16-wave workgroup per CU
+    (2600, 2, 2, "r", True, dict(disp_min=2.0, disp_max=900.0)),      # 167 KB plain: only the packed context (146 KB) fits
+    (3000, 2, 2, "r", True, dict(disp_min=2.0, disp_max=900.0)),      # beyond the LDS either way: the row-shift backward takes over
     # more items than waves / fewer items than waves, L1 loss, per-row disparities with a horizon mask
     (640, 3, 1, "r", True, dict(disp_min=5.0, disp_max=5.0)),
     (130, 3, 2, "r", True, dict(special_disp=[5.0, 9.3], disp_min=0.5, disp_max=9.0)),
