@@ -267,6 +267,26 @@ def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, m
     _compare(new, {"g_disp_pp": want["g_disp_pp"]}, tag="rowstream/W%d" % W, tol=2e-4)
 
 
+def test_rowstream_backward_at_the_high_resolution_configuration():
+    """BASELINE configs[4] (384x1280, 49 planes; one image here): the packed LDS context and 12-wave workgroups of the wide
+    rows against the target-ordered row-shift backward on the same forward."""
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import survey_fullsize_case
+    case = survey_fullsize_case(B=1, H=384, W=1280, sigma_interior=True)
+    run = dict(automask=True)
+    new = run_product(case, run)
+    ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
+    try:
+        old = run_product(case, run)
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    assert float(old["g_logits"].abs().max()) > 0
+    _compare(new, {k: old[k] for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma")}, tag="hr stream-vs-shift", tol=3e-6)
+    _compare(new, {"g_disp_pp": old["g_disp_pp"]}, tag="hr stream-vs-shift", tol=5e-5)
+
+
 @pytest.mark.parametrize("name", ["disp_mix_xz", "disp_mix_r", "disp_mix_automask", "disp_mix_integer_d"])
 def test_per_row_disparities_use_the_rowshift_kernels(name):
     """opt.yz_levels == 0 promises row-uniform disparity maps: dense maps (xz planes, horizon mask) then go through the
