@@ -135,7 +135,11 @@ def build_step(args, c, device):
         margs = argparse.Namespace(**dict(vars(args), mono_pose=True))
         poses[-1] = bench_pose(margs, c, device)
         poses[1] = bench_pose(margs, c, device).transpose(1, 2).contiguous()   # the opposite rotation
-    norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1)
+    norm = torch.tensor([0.0, 0.0, 1.0], device=device)[None, None].expand(B, N, -1).contiguous()
+    # outputs["distance"] is a DECODER output (networks/depth_decoder.py:254), like logits and sigma: a leaf that wants a
+    # gradient, handed to the path as the decoder hands it over — not re-derived from the disparities inside the timed step
+    # (that was ten 2-5 us launches of decoder arithmetic and its autograd per step: 10-15 % of a homography step)
+    distance = (0.1 * 0.58 * W / disp_pp.detach()[:, :, 0, 0]).contiguous().requires_grad_(not args.no_plane_grad)
     shape_probe = torch.empty(B, N, H, W, device="meta")
     g_rgb = c["g_rgb_rec"]
     one = torch.ones((), device=device)  # d loss / d ph_loss
@@ -170,7 +174,8 @@ def build_step(args, c, device):
         if dists is not None:
             outputs["dists"] = dists
         if args.warp_type == "homography_warp":  # only the homography reads the plane distances (trainer.py:557)
-            outputs["distance"] = 0.1 * 0.58 * W / disp_pp[:, :, 0, 0]
+            distance.grad = None
+            outputs["distance"] = distance
         planedepth_amd.pred_novel_images(ns, inputs, outputs)
         # photometric part of compute_losses (trainer.py:717-742) + a stand-in for the perceptual net's gradient
         # ph_mean = ph_map.mean() (trainer.py:742), accumulated by the sweep kernel
@@ -178,7 +183,7 @@ def build_step(args, c, device):
         torch.autograd.backward(heads, [one, g_rgb] * len(sides))
         return heads[0]
 
-    return step, (logits, sigma, disp_pp)
+    return step, (logits, sigma, disp_pp, distance)
 
 
 def algorithmic_bytes(args):

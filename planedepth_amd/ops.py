@@ -447,6 +447,7 @@ class _HomographyMatrices(torch.autograd.Function):
                                                    C.stream_handle(dev)), "pd_homography_matrices_fwd")
         ctx.save_for_backward(distance, norm, T, K, inv_K)
         ctx.mode, ctx.rows = mode, rows
+        ctx.set_materialize_grads(False)   # (else autograd zero-fills gradients for the non-differentiable Rn / mask: two launches)
         ctx.mark_non_differentiable(Rn)
         if mode == C.PD_HMAT_STEREO_ROWS:
             ctx.mark_non_differentiable(mask)
@@ -464,6 +465,8 @@ class _HomographyMatrices(torch.autograd.Function):
         if stereo and (need_n or need_T):
             raise RuntimeError("PD_HMAT_STEREO_ROWS carries the gradient of `distance` only (h00 is not part of the "
                                "per-row shift); use PD_HMAT_PLANES when the pose or the normals need gradients")
+        if g_first is None:   # the matrices took no part in the loss
+            return None, None, None, None, None, None, None
         g_first = _contig(g_first.float())
         gd = torch.empty(B, N, device=dev) if need_d else None
         gn = torch.empty(B, N, 3, device=dev) if need_n else None
