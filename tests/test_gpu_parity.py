@@ -1640,6 +1640,7 @@ def _run_gather_case(case, impl, mix=True, render=False, dists=None):
 @pytest.mark.parametrize("B,N,H,W,mix,irregular", [
     (2, 5, 40, 150, True, False), (1, 9, 33, 70, True, False), (1, 3, 50, 200, False, False), (1, 4, 5, 7, True, False),
     (2, 6, 64, 64, True, False), (1, 5, 96, 320, True, False), (1, 49, 192, 640, True, False),
+    (1, 1, 16, 40, True, False), (2, 2, 16, 40, True, False),   # one / two planes: the staging pipeline's prologue alone
     (2, 5, 40, 150, True, True), (1, 4, 33, 70, False, True), (1, 6, 96, 320, True, True)])
 def test_gather_backward_equals_atomic_backward(B, N, H, W, mix, irregular):
     """homography_warp with one matrix per plane (6-DoF poses): the two-pass gather backward (pd_plane_sweep_gather.hip,
