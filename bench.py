@@ -779,6 +779,13 @@ def main():
                      "avg_launch_ms": round(kt[dom], 4),
                      "timing": "HIP events on the launch stream around the C-ABI call (the sweep kernel plus its 5 us helper "
                                "launch: ph_mean memset / row reduction), inside the training step, steady state"}
+            if dom == "bwd" and args.warp_type == "disp_warp" and not args.render_probability:
+                # context for `frac` (not a measurement of this run): what the part gives the kernel's memory shape
+                block["shape_ceiling"] = {
+                    "frac": 0.66, "ms_at_default_workload": 0.152,
+                    "source": "scripts/probes/stream_probe.hip (DESIGN.md 3.6.1 / 3.6.4): 12-byte aligned loads + 8-byte aligned "
+                              "stores of this kernel's byte counts and no arithmetic; loads alone run at 5.8 TB/s, stores alone at "
+                              "4.4 TB/s, and reads and writes do not overlap in the memory system"}
             # headline workload -> "roofline"; the general (homography) kernels report the same block under their own key
             result["roofline" if args.warp_type == "disp_warp" else "roofline_general"] = block
             if args.warp_type != "disp_warp":
