@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--no_plane_grad", action="store_true", help="diagnostics: disparities do not require grad")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_next_rows", action="store_true", help="skip the timings of the SURVEY 8f operators")
+    ap.add_argument("--skip_context", default="", help="comma list of context measurements to skip: copy")
     ap.add_argument("--no_ddp_step", action="store_true", help="skip the end-to-end DDP training-step block")
     ap.add_argument("--ddp_model", default="r18", choices=["r18", "r50"],
                     help="stand-in depth network of the ddp_step block: ResNet-18-shaped (59.6 MB of gradients, BASELINE configs[1]) "
@@ -554,10 +555,10 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     t_nosync = timed(lambda: step(False), steps)      # the same step without DDP's hooks: what the all-reduce adds
     ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
     try:
-        for _ in range(3):
+        for _ in range(10):
             step()
         torch.cuda.synchronize(device)
-        hot = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ops.KERNEL_EVENTS.items()}
+        hot = {k: sum(a.elapsed_time(b) for a, b in v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in ops.KERNEL_EVENTS.items() if v}
     finally:
         ops.KERNEL_EVENTS = None
     flat = torch.empty(n_params, device=device)
@@ -567,6 +568,9 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     block = {"images_per_sec": round(B * world / t_step, 1), "ms_per_step": round(t_step * 1e3, 3),
              "ms_per_step_without_gradient_sync": round(t_nosync * 1e3, 3),
              "sweep_fwd_ms": round(hot["fwd"], 4), "sweep_bwd_ms": round(hot["bwd"], 4),
+             # the sweep's producer and consumer in a real step: the fused decoder tail writes logits / sigma right before the
+             # sweep's forward and reads g_logits / g_sigma right after its backward
+             "tail_fwd_ms": round(hot.get("tail_fwd", float("nan")), 4), "tail_bwd_ms": round(hot.get("tail_bwd", float("nan")), 4),
              "hot_path_share_of_step": round((hot["fwd"] + hot["bwd"]) * 1e-3 / t_step, 4),
              "network": "%s-shaped stand-in (stock Conv2d/BatchNorm2d blocks + skip decoder + the decoder's three heads), %d "
                         "parameters = %.1f MB of fp32 gradients (SURVEY C1: 59.6 / 156.6 MB), %s, "
@@ -601,6 +605,26 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     return block
 
 
+def measured_copy_rate(device, mbytes=384, iters=20):
+    """What this box's HBM gives a plain device-to-device copy right now (torch's own copy kernel; bytes read + bytes
+    written per second): context for the roofline fractions, measured in this run — the spec's 8 TB/s is the denominator
+    everywhere, this is what a kernel with no arithmetic and perfect access order reaches on the day."""
+    n = mbytes * (1 << 20) // 4
+    a, b = torch.empty(n, device=device), torch.empty(n, device=device)
+    a.fill_(1.0)
+    b.copy_(a)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / iters
+    return {"GBs": round(2 * n * 4 / (ms * 1e-3) / 1e9, 1), "frac_of_peak": round(2 * n * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "what": "torch copy_ of %d MiB (read + write bytes), %d launches, measured in this run" % (mbytes, iters)}
+
+
 def parallel_max(v, device):
     from planedepth_amd import parallel
     return parallel.max_over_ranks(v, device)
@@ -626,21 +650,26 @@ def measured_traffic(args, kernel):
 
 
 def cpu_baseline(args, budget_s):
-    """The oracle (port of the reference's op-by-op PyTorch path) on the host cores: B=1 sample of the same workload."""
+    """The oracle (port of the reference's op-by-op PyTorch path) on the host cores: B=1 sample of the same workload.
+    Sampling goes through F.grid_sample — the operator the reference itself calls (trainer.py:573-577) and the one that
+    ships with torch on this box; the oracle's own gather-based restatement of it (oracle.bilinear_sample, 3-4x slower:
+    it exists to pin the formula, not to be fast) is timed once and reported beside it."""
+    import torch.nn.functional as F
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cases import run_oracle
     from planedepth_amd.synthetic import survey_fullsize_case
     ncpu = os.cpu_count() or 1
     case = survey_fullsize_case(B=1, N=args.planes, H=args.height, W=args.width)
     run = dict(warp_type=args.warp_type, use_mixture_loss=not args.no_mixture, automask=args.automask)
+    torch_sampler = lambda f, g, pm: F.grid_sample(f, g, mode="bilinear", padding_mode=pm, align_corners=True)  # noqa: E731
     # torch's intra-op pool degrades badly when oversubscribed (256 threads: 36 s / image); pick the better of two
     # sane thread counts with one probe iteration each, then time the sample at that setting.
     best = None
     for th in sorted({min(8, ncpu), min(32, ncpu)}):
         torch.set_num_threads(th)
-        run_oracle(case, run)  # warm-up at this setting
+        run_oracle(case, run, sampler=torch_sampler)  # warm-up at this setting
         t0 = time.perf_counter()
-        run_oracle(case, run)
+        run_oracle(case, run, sampler=torch_sampler)
         dt = time.perf_counter() - t0
         if best is None or dt < best[1]:
             best = (th, dt)
@@ -650,14 +679,19 @@ def cpu_baseline(args, budget_s):
     t_end = time.perf_counter() + budget_s
     while len(times) < 9 and (time.perf_counter() < t_end or len(times) < 2):
         t0 = time.perf_counter()
-        run_oracle(case, run)
+        run_oracle(case, run, sampler=torch_sampler)
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    t0 = time.perf_counter()
+    run_oracle(case, run)   # the restated sampler, once (warm pool): the second figure
+    restated = time.perf_counter() - t0
     return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle (torch CPU restatement of trainer.py:523-603,717-742) fwd+bwd, B=1, N=%d, %dx%d, median of %d"
-                      % (args.planes, args.height, args.width, len(times)),
-            "ms_per_image": round(med * 1e3, 2)}
+            "sample": "oracle (torch CPU restatement of trainer.py:523-603,717-742, sampling through F.grid_sample as the "
+                      "reference does) fwd+bwd, B=1, N=%d, %dx%d, median of %d" % (args.planes, args.height, args.width, len(times)),
+            "ms_per_image": round(med * 1e3, 2),
+            "restated_sampler": {"value": round(1.0 / restated, 4), "ms_per_image": round(restated * 1e3, 2),
+                                 "what": "same pass with the oracle's gather-based bilinear_sample instead of F.grid_sample, one run"}}
 
 
 def spawn_ranks(args):
@@ -729,6 +763,14 @@ def main():
     leg_iters = max(50, min(args.steps, 100))
     kt = in_step_kernel_times(eager_step, device, iters=2 * leg_iters, skip=leg_iters)   # the figure the roofline uses
     iso = kernel_times(args, c, device, iters=leg_iters)
+    pre_timed = {"in_step_kernel_timing_steps": 2 * leg_iters, "isolated_fwd_launches": (leg_iters + 1) if iso else 0,
+                 "isolated_bwd_launches": (leg_iters + 1) if iso else 0, "warmup_steps": args.warmup,
+                 "hip_graph_capture_steps": 4 if args.hip_graph else 0,
+                 "why": "steady state: a fresh process runs its first ~50 steps ~10 % slower (device power state; DESIGN.md "
+                        "section 6), and the roofline legs need the kernel times anyway"}
+    pre_timed["steps_total"] = pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"]
+    if "copy" not in args.skip_context:
+        hbm_copy = measured_copy_rate(device)
     for _ in range(args.warmup):
         step()
     parallel.barrier(device)
@@ -744,6 +786,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
+        "pre_timed_steps": pre_timed,
         "library": dict(entry.BUILD_INFO),   # "built" here from source, or "reused" (the travelling .so matches this source hash)
         "known_deviation": "row kernels' backward (row-stream by default, row-shift under PD_IMPL_ROWS1): the adjoint drops the "
                            "eps-weighted (eps <= 8e-6) term of the neighbouring source row on rows whose y round trip is "
@@ -767,6 +810,8 @@ def main():
                           "devices": "shared cuda:0 (PD_BENCH_SHARE_GPU)" if os.environ.get("PD_BENCH_SHARE_GPU")
                           else "one per rank"}
     if rank == 0:
+        if "copy" not in args.skip_context:
+            result["hbm_copy_measured"] = hbm_copy
         if kt:
             fwd_b, bwd_b = algorithmic_bytes(args)
             dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
@@ -779,23 +824,26 @@ def main():
                      "avg_launch_ms": round(kt[dom], 4),
                      "timing": "HIP events on the launch stream around the C-ABI call (the sweep kernel plus its 5 us helper "
                                "launch: ph_mean memset / row reduction), inside the training step, steady state"}
-            if dom == "bwd" and args.warp_type == "disp_warp" and not args.render_probability:
-                # context for `frac` (not a measurement of this run): what the part gives the kernel's memory shape
-                block["shape_ceiling"] = {
-                    "frac": 0.66, "ms_at_default_workload": 0.152,
-                    "source": "scripts/probes/stream_probe.hip (DESIGN.md 3.6.1 / 3.6.4): 12-byte aligned loads + 8-byte aligned "
-                              "stores of this kernel's byte counts and no arithmetic; loads alone run at 5.8 TB/s, stores alone at "
-                              "4.4 TB/s, and reads and writes do not overlap in the memory system"}
             # headline workload -> "roofline"; the general (homography) kernels report the same block under their own key
             result["roofline" if args.warp_type == "disp_warp" else "roofline_general"] = block
             if args.warp_type != "disp_warp":
                 result["roofline"] = dict(block, note="general kernels (homography_warp); the headline disp_warp "
                                                       "kernels are measured by the default invocation")
+            # SURVEY.md 8(d)'s own figure: the WHOLE path (images/s x algorithmic bytes per image and view over the spec
+            # peak), from the timed window's `value`; `roofline` above is the dominant kernel alone
+            n_views = 3 if args.mono_sides else 1
+            path_GBs = (fwd_b + bwd_b) * n_views * value / world / 1e9
+            result["roofline_path"] = {
+                "bound": "hbm", "achieved": round(path_GBs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(path_GBs / HBM_PEAK_GBS, 4), "bytes_per_image": (fwd_b + bwd_b) * n_views,
+                "definition": "SURVEY 8d: images/s per GPU x (6N+18) HW 4 bytes per image and view / 8 TB/s (the target "
+                              "there: 0.60 = 31.3 k images/s at N = 49, 192x640)"}
             result["kernels"] = {
                 "fwd_ms": round(kt["fwd"], 4), "bwd_ms": round(kt["bwd"], 4),
                 "fwd_GBs": round(fwd_b * args.batch / (kt["fwd"] * 1e-3) / 1e9, 1),
                 "bwd_GBs": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9, 1),
-                "whole_path_frac_of_peak": round((fwd_b + bwd_b) * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+                "fwd_frac_of_peak": round(fwd_b * args.batch / (kt["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bwd_frac_of_peak": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if iso:
                 result["kernels"].update(isolated_fwd_ms=round(iso["fwd"], 4), isolated_bwd_ms=round(iso["bwd"], 4))
         if world == 1 and not args.no_next_rows:

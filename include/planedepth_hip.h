@@ -79,7 +79,8 @@ enum pd_sweep_flags {
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
 
 /* Kernel selection.  The row kernels apply to PD_WARP_DISP with per-plane or per-row disparities (forward:
- * pd_plane_sweep_rowshift.hip, target-ordered; backward: pd_plane_sweep_rowstream.hip, source-ordered); homography_warp
+ * pd_plane_sweep_fwdstream.hip, a wave per 128-pixel segment streaming over the planes — pd_plane_sweep_rowshift.hip,
+ * plane groups, with a per-pixel mask or PD_RENDER_PROB; backward: pd_plane_sweep_rowstream.hip, source-ordered); homography_warp
  * with one matrix per image (PD_HOMO_UNIFORM) or per plane runs a two-pass gather backward without atomics
  * (pd_plane_sweep_uniform.hip, pd_plane_sweep_gather.hip); the general kernels handle everything (and are the
  * cross-check for the specialised ones in the tests). */
@@ -97,9 +98,10 @@ enum pd_sweep_impl {
                             wave instruction: DESIGN.md 3.4.6) - kept as an in-suite cross-check and as the record of
                             that measurement */
   ,
-  PD_IMPL_ROWS1 = 4      /* as AUTO, but the backward is the target-ordered row-shift kernel (pd_plane_sweep_rowshift.hip,
-                            one pixel per lane, the headline backward of rounds 1-2) instead of the source-ordered
-                            row-stream kernel (pd_plane_sweep_rowstream.hip): cross-check and A/B runs */
+  PD_IMPL_ROWS1 = 4      /* as AUTO, but forward and backward are the target-ordered, one-pixel-per-lane row-shift kernels
+                            (pd_plane_sweep_rowshift.hip, the headline kernels of rounds 1-2) instead of the segment-stream
+                            forward (pd_plane_sweep_fwdstream.hip) and the source-ordered row-stream backward
+                            (pd_plane_sweep_rowstream.hip): cross-check and A/B runs */
   ,
   PD_IMPL_UNIFORM_DIRECT = 5 /* as AUTO, but pass 2 of the two-pass homography backwards (plane-uniform and per-plane) gathers
                             directly from the scratch instead of staging it through LDS (the form large boxes fall back
@@ -116,6 +118,9 @@ typedef struct pd_sweep_desc {
 
 int pd_version(void);
 const char* pd_last_error(void);
+/* sha256[:16] over the kernel sources and headers this library was compiled from (the .hip and .h files under csrc/ and
+ * include/: __graft_entry__.source_hash), baked in at build time (-DPD_SRC_HASH); "unknown" for a build without it. */
+const char* pd_source_hash(void);
 /* 1 if the library was built with -DPD_EXPERIMENTS: the kernels measured SLOWER than the defaults (four-pixels-per-lane
  * row kernels, owned-tile backward, one-kernel plane-uniform backward) are then compiled in and selectable
  * (PD_IMPL_TILE; PD_QUAD_FWD / PD_QUAD_BWD / PD_UNI_FUSED in the environment).  The product library returns 0. */

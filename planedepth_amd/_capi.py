@@ -39,6 +39,7 @@ _D = ctypes.POINTER(SweepDesc)
 SIGNATURES = {
     "pd_version": (_I, []),
     "pd_last_error": (ctypes.c_char_p, []),
+    "pd_source_hash": (ctypes.c_char_p, []),
     "pd_sweep_uses_rowshift": (_I, [_D]),
     "pd_sweep_bwd_accumulates": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),

@@ -23,8 +23,17 @@ struct Switches {
   bool pp_rows_off;   // PD_PP_ROWS=0: post-process kernels in per-pixel gather form
   int row_waves;      // PD_ROW_WAVES=n: waves per row workgroup of the row-shift kernels (0 = default)
   int uni_chunk;      // PD_UNI_CHUNK=n: images per launch of the plane-uniform backward passes (0 = whole batch)
+  bool fwd_stream;    // PD_FWD_STREAM=0: the headline forward on the plane-group row-shift kernel instead of the segment-stream one
 };
 const Switches& switches();
+
+// LDS a workgroup of this device can be given (bytes; queried once per process: hipDeviceAttributeMaxSharedMemoryPerMultiprocessor,
+// 160 KB on gfx950, which is also the answer when there is no device to ask).  The kernels' applicability tests use it instead of a constant, so a device or partition with less falls
+// back to a kernel that fits instead of failing at launch.
+size_t device_lds_bytes();
+// Raise a kernel's dynamic-LDS limit to `bytes` if it is above what was granted before (*granted: one static per kernel
+// instantiation, starts at 64 KB); PD_OK, or PD_ERR_UNSUPPORTED with the error text set.  Not on the hot path after the first call.
+int grant_dynamic_lds(const void* kernel, size_t bytes, size_t* granted, const char* what);
 
 #define PD_REQUIRE(cond, ...)        \
   do {                               \

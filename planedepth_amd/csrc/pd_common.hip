@@ -23,9 +23,33 @@ const Switches& switches() {
     v.pp_rows_off = num("PD_PP_ROWS") == 0;
     v.row_waves = num("PD_ROW_WAVES") > 0 ? num("PD_ROW_WAVES") : 0;
     v.uni_chunk = num("PD_UNI_CHUNK") > 0 ? num("PD_UNI_CHUNK") : 0;
+    v.fwd_stream = num("PD_FWD_STREAM") != 0;
     return v;
   }();
   return sw;
+}
+
+size_t device_lds_bytes() {
+  static const size_t bytes = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || n <= 0)
+      n = 160 * 1024;  // no device to ask (host-side size queries on a box without a GPU): the target's value, gfx950
+    (void)hipGetLastError();
+    return (size_t)n;
+  }();
+  return bytes;
+}
+
+int grant_dynamic_lds(const void* kernel, size_t bytes, size_t* granted, const char* what) {
+  if (bytes <= *granted) return PD_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: %zu bytes of LDS per workgroup are not available on this device", what, bytes);
+    return PD_ERR_UNSUPPORTED;
+  }
+  *granted = bytes;
+  return PD_OK;
 }
 
 int check_launch(const char* what) {
@@ -44,8 +68,16 @@ extern "C" int pd_experiments(void) {
   return 0;
 #endif
 }
-extern "C" int pd_version(void) { (void)pd::switches(); return 220; /* 0.2.2: gather backward for per-plane homographies (pd_debug_gather_flags), pd_uniform_gather_pair + PD_BWD_DEFER_GATHER, packed wide-row context; 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
+extern "C" int pd_version(void) { (void)pd::switches(); return 230; /* 0.2.3: segment-stream forward (pd_plane_sweep_fwdstream.hip; PD_IMPL_ROWS1 selects the plane-group forward too), pd_source_hash; 0.2.2: gather backward for per-plane homographies (pd_debug_gather_flags), pd_uniform_gather_pair + PD_BWD_DEFER_GATHER, packed wide-row context; 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
+
+// What this binary was compiled from.  The marker string is also what __graft_entry__.build() looks for in the file's bytes
+// to decide whether the library on disk matches the source tree (no side file, no dlopen of a stale library).
+#ifndef PD_SRC_HASH
+#define PD_SRC_HASH "unknown"
+#endif
+static const char kSourceHashMarker[] = "PD_SRC_HASH=" PD_SRC_HASH;
+extern "C" const char* pd_source_hash(void) { return kSourceHashMarker + 12; }
 
 // Diagnostics: fill the LDS of (as good as) every CU with NaNs, so that a kernel that reads shared memory it never wrote
 // shows up as NaN results instead of depending on what the previous tenant left there (tests/test_gpu_parity.py).

@@ -1,0 +1,343 @@
+// Segment-stream forward of the fused plane sweep: PD_WARP_DISP with one disparity per (image, plane) or per (image,
+// plane, row), no per-pixel mask, softmax probabilities (reference trainer.py:540-603 + 728-742) — the headline forward.
+//
+// The plane-group forward (pd_plane_sweep_rowshift.hip) keeps two groups of four planes in registers per wave (taps,
+// colour taps, coordinates: 148 VGPRs = 3 waves per SIMD, 12 per CU) and splits a row's segments and planes over four
+// waves that meet in LDS.  Measured: its load phase and its arithmetic are both latency-bound at that occupancy (all
+// arithmetic compiled out: 0.136 ms; all tap loads compiled out: 0.092 ms; 30 VALU per pixel and plane are 0.02 ms of
+// issue time), and neither persistent workgroups nor overlapped row staging move it (scripts/experiments/
+// pd_plane_sweep_rowpersist.hip.txt).  This kernel is the forward counterpart of the row-stream backward's loop:
+//   * one wave owns one 128-pixel segment of a target row and ALL planes: no split of the online softmax, no partial
+//     sums through LDS, no barrier after the row's constants are staged; the waves of a row (5 at W = 640) start together
+//     and do the same work, so between them they read a plane's whole source row at about the same time;
+//   * a lane owns two adjacent target pixels; the taps of both on plane n are the three source values at xt + k ..
+//     xt + k + 2, k = floor(s d_n): ONE 12-byte load per tensor and live source row (4-byte aligned; the buffer
+//     descriptor's range check is padding_mode = "zeros"), half the memory instructions per pixel of the 8-byte form;
+//   * one plane per iteration behind a register ring of PD_FS_D1 iterations of loads (6 VGPRs per slot): the state per
+//     wave is two accumulator sets + the ring, ~90 VGPRs instead of 148 — five waves per SIMD, 20 per CU, each with
+//     three planes of loads in flight;
+//   * the colour taps come out of LDS (packed float4 row, vertically pre-blended for rows with two live source rows, as
+//     the row-stream backward stages it) when the plane is reduced.
+//
+// Exactness.  The pairing "left tap of target xt on plane n = source column xt + k" is the row-stream backward's premise
+// (pd_rowshift_common.h: stream_ix, irregular_tol): planes whose frac(s d) is closer than irregular_tol
+// to an integer take a general per-pixel path (exact floor(ix) per pixel, dword loads), and so does the one segment per
+// plane that straddles column 0 under a negative shift (a 12-byte load that STARTS left of the row reads as zeros as a
+// whole).  Weights and samples are the reference's expressions in the row-shift forward's order.
+#include <stdlib.h>
+
+#include "pd_rowshift_common.h"
+
+namespace pd {
+
+#ifndef PD_FS_D1
+#define PD_FS_D1 3   // prefetch depth in planes, one live source row (6 VGPRs per slot)
+#endif
+#ifndef PD_FS_D2
+#define PD_FS_D2 1   // two live source rows (12 VGPRs per slot): this body sets the kernel's register count (depth 2: 108 VGPRs)
+#endif
+#ifndef PD_FS_OCC
+#define PD_FS_OCC 5  // waves per SIMD the register allocator must leave room for: 96 VGPRs, which the mixture kernel just fits
+#endif               // (the automask variant needs 8 more for its extra exponential's operands: it runs at 4 waves per SIMD)
+
+#ifndef PD_FS_LDS_PAD
+#define PD_FS_LDS_PAD 0   // timing experiments: extra LDS bytes per workgroup (caps the workgroups per CU)
+#endif
+#ifndef PD_FS_ROWS
+#define PD_FS_ROWS 3   // consecutive target rows per workgroup where its 16 waves allow (each row: one wave per segment).  Measured
+#endif                 // at 8x49x192x640, isolated / in the step: 1 row 0.114 / 0.128 ms, 2 rows 0.119 / 0.131, 3 rows 0.104 / 0.122
+                       // — 15 waves that read three adjacent rows (7.5 KB) of every plane at about the same time
+constexpr int kFsSeg = 2 * kWave;      // target pixels per wave
+constexpr int kFsGuard = 4;            // zero cells on each side of the colour row
+constexpr int kFsThreadsMax = 1024;    // 16 waves: rows up to 2048 pixels
+
+typedef float v3f __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ v3f fs_load3(Rsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)byte_off, 0, 0));
+}
+
+template <int NROWS>
+struct FsTaps {   // the taps of one plane for the lane's two pixels: L[c .. c+2] per live source row
+  float l[NROWS][3], s[NROWS][3];
+};
+
+struct FsRow {    // workgroup-uniform
+  int b, y, yA, yB;
+  float wA, wB;
+};
+
+template <bool MIX, int NROWS>
+__device__ __forceinline__ void fs_issue(FsTaps<NROWS>& g, const SweepArgs& a, const FsRow& r, int n, unsigned off, int HW) {
+  const float* pl = plane_ptr(a.logits + (long)r.b * a.N * HW, n, HW);
+  const v3f la = fs_load3(row_rsrc(pl + (long)r.yA * a.W, a.W), off);
+  g.l[0][0] = la.x; g.l[0][1] = la.y; g.l[0][2] = la.z;
+  if (NROWS == 2) {
+    const v3f lb = fs_load3(row_rsrc(pl + (long)r.yB * a.W, a.W), off);
+    g.l[NROWS - 1][0] = lb.x; g.l[NROWS - 1][1] = lb.y; g.l[NROWS - 1][2] = lb.z;
+  }
+  if (MIX) {
+    const float* ps = plane_ptr(a.sigma + (long)r.b * a.N * HW, n, HW);
+    const v3f sa = fs_load3(row_rsrc(ps + (long)r.yA * a.W, a.W), off);
+    g.s[0][0] = sa.x; g.s[0][1] = sa.y; g.s[0][2] = sa.z;
+    if (NROWS == 2) {
+      const v3f sb = fs_load3(row_rsrc(ps + (long)r.yB * a.W, a.W), off);
+      g.s[NROWS - 1][0] = sb.x; g.s[NROWS - 1][1] = sb.y; g.s[NROWS - 1][2] = sb.z;
+    }
+  }
+}
+
+// The lane's two pixels on a plane that does not qualify for the 12-byte form: exact floor(ix) per pixel, dword loads
+// (range-checked: an out-of-image tap reads as zero), colour taps from the guard-celled LDS row.
+template <bool MIX, int NROWS, bool AUTO>
+__device__ __forceinline__ void fs_general_plane(const SweepArgs& a, const FsRow& r, const float4* __restrict__ col, int n,
+                                                 float sd, float xt0f, int HW, float Wm1, float rcpWm1, const float* t,
+                                                 const float* ea, bool automask, FwdAcc* acc) {
+  const float* pl = plane_ptr(a.logits + (long)r.b * a.N * HW, n, HW);
+  const float* ps = MIX ? plane_ptr(a.sigma + (long)r.b * a.N * HW, n, HW) : pl;
+  const Rsrc lA = row_rsrc(pl + (long)r.yA * a.W, a.W), lB = row_rsrc(pl + (long)r.yB * a.W, a.W);
+  const Rsrc sA = row_rsrc(ps + (long)r.yA * a.W, a.W), sB = row_rsrc(ps + (long)r.yB * a.W, a.W);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const ColTap ct = make_col_tap(xt0f + (float)i + sd, Wm1, rcpWm1);
+    // Columns right of the row are dropped by the descriptor's range check.  Columns LEFT of it are not all: byte offset
+    // -4 (column -1) plus the access size wraps to 0 in the 32-bit check and counts as in range — such a tap gets a zero
+    // weight and a load at column 0 instead (scripts/probes/buf_probe.hip; the row-shift forward's x0 = -1 fix-up).
+    const unsigned o0 = (unsigned)max(ct.x0, 0) << 2, o1 = (unsigned)max(ct.x0 + 1, 0) << 2;
+    const float w0 = (ct.x0 >= 0) ? ct.w0 : 0.0f, w1 = (ct.x0 + 1 >= 0) ? ct.w1 : 0.0f;
+    const float wa0 = (NROWS == 1) ? w0 : w0 * r.wA, wa1 = (NROWS == 1) ? w1 : w1 * r.wA;
+    float l = buf_load(lA, o0) * wa0 + buf_load(lA, o1) * wa1;
+    float s = 0.0f;
+    if (MIX) s = buf_load(sA, o0) * wa0 + buf_load(sA, o1) * wa1;
+    if (NROWS == 2) {
+      const float wb0 = w0 * r.wB, wb1 = w1 * r.wB;
+      l += buf_load(lB, o0) * wb0 + buf_load(lB, o1) * wb1;
+      if (MIX) s += buf_load(sB, o0) * wb0 + buf_load(sB, o1) * wb1;
+    }
+    const int cell = min(max(ct.x0, -kFsGuard), a.W + 2) + kFsGuard;
+    const float4 ca = col[cell], cb = col[cell + 1];
+    const float c0 = ca.x * ct.w0 + cb.x * ct.w1, c1 = ca.y * ct.w0 + cb.y * ct.w1, c2 = ca.z * ct.w0 + cb.z * ct.w1;
+    fwd_accumulate<MIX>(acc[i], l, s, c0, c1, c2, t[i], t[2 + i], t[4 + i], ea[i], automask);
+  }
+}
+
+// One target row (b, y): `tix` / `nthr` = this thread's index among the threads that serve the row (nseg waves), `seg` the
+// wave's segment.  Contains one workgroup barrier (after staging): every thread of the workgroup calls it, `active` = false
+// for the waves of a row beyond the image.
+template <bool MIX, bool AUTO, int NROWS>
+__device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel& row, int b, int y, int tix, int nthr, int seg,
+                                                bool active, float4* __restrict__ col, int2* __restrict__ shift,
+                                                float* __restrict__ rgb_rec, float* __restrict__ ph_map,
+                                                float* __restrict__ stash) {
+  constexpr int D = (NROWS == 1) ? PD_FS_D1 : PD_FS_D2;
+  const int W = a.W, N = a.N, HW = a.H * a.W;
+  FsRow r;
+  r.y = y;
+  r.b = b;
+  r.yA = row.yA; r.yB = (NROWS == 2) ? row.yB : row.yA;
+  r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
+  const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
+  const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
+  const int CW = W + 2 * kFsGuard;
+
+  // ---- stage the row: blended source colour row with zero guard cells, per-plane shifts -----------------------------
+  const float* srcb = a.src + (long)r.b * 3 * HW;
+  for (int cidx = tix; cidx < CW && active; cidx += nthr) {
+    const int x = cidx - kFsGuard;
+    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W) {
+      const float* p = srcb + (long)r.yA * W + x;
+      cc = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
+      if (NROWS == 2) {   // fl(B*wB + fl(A*wA)): the rounding the row-stream backward stages (its knife-edge note applies here too)
+        const float* q = srcb + (long)r.yB * W + x;
+        cc = make_float4(fmaf(q[0], r.wB, cc.x * r.wA), fmaf(q[HW], r.wB, cc.y * r.wA), fmaf(q[2 * HW], r.wB, cc.z * r.wA), 0.0f);
+      }
+    }
+    col[cidx] = cc;
+  }
+  {
+    const float tol = irregular_tol(W);
+    for (int i = tix; i < N && active; i += nthr) {
+      const float sd = staged_shift(a, r.b, i, r.y);
+      const float fl = floorf(sd), fr = sd - fl;
+      const bool inview = fabsf(sd) < (float)(W + 1);
+      const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
+      shift[i] = make_int2(__float_as_int(sd), (int)fl * 2 + irr);
+    }
+  }
+  __syncthreads();
+  if (!active) return 0.0f;
+
+  // ---- this wave's segment -----------------------------------------------------------------------------------------
+  const int lane = threadIdx.x & (kWave - 1);
+  const int xt0 = seg * kFsSeg + lane * 2;
+  const float xt0f = (float)xt0;
+  const bool live = xt0 < W;                 // W is even: a lane's two pixels are inside or outside together
+  const int pix = r.y * W + (live ? xt0 : 0);
+  float t[6], ea[2] = {0.0f, 0.0f};          // target colour (r0 r1 g0 g1 b0 b1), 3 x identity-reprojection error
+  {
+    const float* tp = a.tgt + (long)r.b * 3 * HW + pix;
+    const float2 t0 = *reinterpret_cast<const float2*>(tp), t1 = *reinterpret_cast<const float2*>(tp + HW),
+                 t2 = *reinterpret_cast<const float2*>(tp + 2 * HW);
+    t[0] = t0.x; t[1] = t0.y; t[2] = t1.x; t[3] = t1.y; t[4] = t2.x; t[5] = t2.y;
+    if (automask) {
+      const float* sp = srcb + pix;
+      const float2 s0 = *reinterpret_cast<const float2*>(sp), s1 = *reinterpret_cast<const float2*>(sp + HW),
+                   s2 = *reinterpret_cast<const float2*>(sp + 2 * HW);
+      ea[0] = fabsf(s0.x - t[0]) + fabsf(s1.x - t[2]) + fabsf(s2.x - t[4]);
+      ea[1] = fabsf(s0.y - t[1]) + fabsf(s1.y - t[3]) + fabsf(s2.y - t[5]);
+    }
+  }
+  FwdAcc acc[2];
+  FsTaps<NROWS> g[D + 1];
+  int pn = 0;
+  auto prefetch = [&](FsTaps<NROWS>& grp) {
+    const int n = min(pn, N - 1);   // past the end: re-load the last plane (unused) — unconditional issue keeps the wait counts right
+    const int k = __builtin_amdgcn_readfirstlane(shift[n].y) >> 1;
+    fs_issue<MIX, NROWS>(grp, a, r, n, (unsigned)(xt0 + k) << 2, HW);
+    ++pn;
+  };
+  auto step = [&](const FsTaps<NROWS>& grp, int n) {
+    const int2 sh = shift[n];
+    const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
+    const int kk = __builtin_amdgcn_readfirstlane(sh.y);
+    const int k = kk >> 1;
+    const int c0 = seg * kFsSeg + k;   // source column of the segment's first left tap (wave-uniform); lane i loads c0 + 2i ..
+    // 12-byte form: regular plane, and no lane's load starts at column -3, -2 or -1: a load that starts left of the row reads
+    // as zeros as a whole although its last columns may be inside, and the dword at byte offset -4 passes the 32-bit range
+    // check (offset + 4 wraps to 0).  Loads that start at column <= -4 are dropped cleanly, those at >= 0 are exact.
+    const bool general = (kk & 1) || (c0 < 0 && c0 + 2 * (kWave - 1) >= -3);
+    if (general) {
+      fs_general_plane<MIX, NROWS, AUTO>(a, r, col, n, sd, xt0f, HW, Wm1, rcpWm1, t, ea, automask, acc);
+      return;
+    }
+    const int cell = min(max(xt0 + k, -kFsGuard), W + 1) + kFsGuard;
+    const float4 cv0 = col[cell], cv1 = col[cell + 1], cv2 = col[cell + 2];
+    const float kf = (float)k;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float xtf = xt0f + (float)i;
+      const float ix = stream_ix(xtf, sd, Wm1, rcpWm1);
+      const float xsf = xtf + kf;                               // integers below 2^24: exact
+      const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;        // torch's (ix - x0), (x1 - ix) with x0 = xt + k
+      float l, s = 0.0f;
+      if (NROWS == 1) {
+        l = grp.l[0][i] * w0 + grp.l[0][i + 1] * w1;
+        if (MIX) s = grp.s[0][i] * w0 + grp.s[0][i + 1] * w1;
+      } else {
+        const float a0 = w0 * r.wA, a1 = w1 * r.wA, b0 = w0 * r.wB, b1 = w1 * r.wB;
+        l = grp.l[0][i] * a0 + grp.l[0][i + 1] * a1 + grp.l[NROWS - 1][i] * b0 + grp.l[NROWS - 1][i + 1] * b1;
+        if (MIX) s = grp.s[0][i] * a0 + grp.s[0][i + 1] * a1 + grp.s[NROWS - 1][i] * b0 + grp.s[NROWS - 1][i + 1] * b1;
+      }
+      const float4 ca = (i == 0) ? cv0 : cv1, cb = (i == 0) ? cv1 : cv2;
+      const float c0v = ca.x * w0 + cb.x * w1, c1v = ca.y * w0 + cb.y * w1, c2v = ca.z * w0 + cb.z * w1;
+      fwd_accumulate<MIX>(acc[i], l, s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) prefetch(g[j]);
+  int n = 0;
+  for (; n + (D + 1) <= N; n += D + 1) {
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+      prefetch(g[(j + D) % (D + 1)]);
+      step(g[j], n + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j <= D; ++j) {
+    if (n + j < N) {
+      prefetch(g[(j + D) % (D + 1)]);
+      step(g[j], n + j);
+    }
+  }
+  if (!live) return 0.0f;
+  // ---- finish the two pixels: outputs + the backward's stash, 8-byte stores -------------------------------------------
+  const FwdResult r0 = fwd_finish<MIX>(acc[0], t[0], t[2], t[4], ea[0], automask);
+  const FwdResult r1 = fwd_finish<MIX>(acc[1], t[1], t[3], t[5], ea[1], automask);
+  float* st = stash + (long)r.b * a.stash_k * HW + pix;
+  *reinterpret_cast<float2*>(st) = make_float2(r0.lse2, r1.lse2);
+  *reinterpret_cast<float2*>(st + HW) = make_float2(r0.Sn, r1.Sn);
+  *reinterpret_cast<float2*>(st + 2 * HW) = make_float2(r0.mx, r1.mx);
+  *reinterpret_cast<float2*>(st + 3 * HW) = make_float2(r0.sel, r1.sel);
+  float* rg = rgb_rec + (long)r.b * 3 * HW + pix;
+  *reinterpret_cast<float2*>(rg) = make_float2(r0.r0, r1.r0);
+  *reinterpret_cast<float2*>(rg + HW) = make_float2(r0.r1, r1.r1);
+  *reinterpret_cast<float2*>(rg + 2 * HW) = make_float2(r0.r2, r1.r2);
+  *reinterpret_cast<float2*>(ph_map + (long)r.b * HW + pix) = make_float2(r0.ph, r1.ph);
+  return r0.ph + r1.ph;
+}
+
+template <bool MIX, bool AUTO>
+__global__ __launch_bounds__(kFsThreadsMax, (MIX && AUTO) ? PD_FS_OCC - 1 : PD_FS_OCC) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+                                                                            float* __restrict__ ph_map,
+                                                                            float* __restrict__ stash, int rows) {
+  extern __shared__ float4 lds4[];
+  // LDS per row of the workgroup: colour row float4[W + 8] | shift int2[N] (padded to 16 bytes); then the wave totals of ph_map
+  const int nseg = (a.W + kFsSeg - 1) / kFsSeg;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = wave / nseg, seg = wave - slot * nseg;      // which of the workgroup's rows, which segment of it
+  const int row_f4 = a.W + 2 * kFsGuard + (a.N + 1) / 2;         // float4 per row slot
+  float4* col = lds4 + slot * row_f4;
+  int2* shift = reinterpret_cast<int2*>(col + a.W + 2 * kFsGuard);
+  float* parts = reinterpret_cast<float*>(lds4 + rows * row_f4);
+  const int groups = (a.H + rows - 1) / rows;                    // row groups per image: the grid is (groups, B), dealt row-major
+  const int y = wg_rowid(a.B, groups) * rows + slot, b = wg_image(a.B, groups);
+  const bool active = y < a.H;
+  const RowSel row = two_row_form(make_row_sel(active ? y : 0, a.H), a.fast_rows != 0);
+  const int tix = threadIdx.x - slot * nseg * kWave, nthr = nseg * kWave;
+  float ph_sum;
+  if (row.nrows == 2) ph_sum = fwdstream_body<MIX, AUTO, 2>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
+  else                ph_sum = fwdstream_body<MIX, AUTO, 1>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
+  if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup
+    const float v = wave_sum_hi(ph_sum);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) parts[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tsum = 0.0f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tsum += parts[w];
+      unsafeAtomicAdd(a.ph_mean, tsum * a.inv_numel);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+// rows per workgroup: PD_FS_ROWS where that many rows' waves fit one workgroup, else what fits
+static int fwdstream_rows(const pd_sweep_desc* d) {
+  const int most = (kFsThreadsMax / kWave) / ceil_div(d->W, kFsSeg);
+  const int r = most < PD_FS_ROWS ? most : PD_FS_ROWS;
+  return r < d->H ? r : d->H;
+}
+static size_t fwdstream_lds_bytes(const pd_sweep_desc* d) {
+  const size_t row_f4 = (size_t)d->W + 2 * kFsGuard + ((size_t)d->N + 1) / 2;
+  return fwdstream_rows(d) * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * sizeof(float) + PD_FS_LDS_PAD;
+}
+
+bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
+  if (!rowshift_applicable(d) || (d->flags & PD_RENDER_PROB) || a.has_mask || !switches().fwd_stream) return false;
+  // pixel pairs: even width, 8-byte aligned rows of the per-pixel tensors (their bases come 8-byte aligned from any allocator
+  // that hands out float2-aligned memory; checked because the boundary takes raw pointers)
+  if (d->W % 2 != 0 || ceil_div(d->W, kFsSeg) > kFsThreadsMax / kWave) return false;
+  return fwdstream_lds_bytes(d) <= 64 * 1024;
+}
+
+int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
+  if ((reinterpret_cast<uintptr_t>(a.tgt) | reinterpret_cast<uintptr_t>(a.src) | reinterpret_cast<uintptr_t>(rgb_rec) |
+       reinterpret_cast<uintptr_t>(ph_map) | reinterpret_cast<uintptr_t>(stash)) & 7)
+    return rowshift_fwd(d, a, rgb_rec, ph_map, stash, stream);   // unaligned tensors: the one-pixel-per-lane forward
+  const int rows = fwdstream_rows(d);
+  const dim3 grid(ceil_div(d->H, rows), d->B), block(ceil_div(d->W, kFsSeg) * rows * kWave);
+  const size_t shmem = fwdstream_lds_bytes(d);
+  const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0;
+  if (mix) {
+    if (am) fwdstream_kernel<true, true><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
+    else    fwdstream_kernel<true, false><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
+  } else {
+    fwdstream_kernel<false, false><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
+  }
+  return check_launch("fwdstream_kernel");
+}
+
+}  // namespace pd

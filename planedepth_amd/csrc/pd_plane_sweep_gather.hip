@@ -67,7 +67,8 @@ __device__ __forceinline__ GatherWindow gather_window(const float* __restrict__ 
 }
 
 // flags[0]: some plane of the launch is irregular (the fix-up kernel has work); flags[1]: windows pass 2 cut at kGatherSpan
-// (stays 0 unless the prepare kernel's sample missed a strongly non-uniform map; tests read it)
+// (the prepare kernel's bound on the window growth between its samples rules that out for the planes it accepts; the
+// flag stays as the tests' tripwire: pd_debug_gather_flags)
 __global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* __restrict__ prep, int* __restrict__ flags,
                                    int BN, int W, int H) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,6 +83,7 @@ __global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* 
   p.Hs[6] = (float)(C * inv);  p.Hs[7] = (float)(-(a * k - b * g) * inv); p.Hs[8] = (float)((a * e - b * d) * inv);
   bool ok = (det == det) && fabs(det) > 1e-30 && fabs(inv) < 1e30;
   for (int j = 0; j < 9; ++j) ok = ok && (fabsf(p.Hs[j]) < 1e30f) && (p.Hs[j] == p.Hs[j]);
+  float wspread = 1.0f;   // max |w| / min |w| over the grown image
   if (ok) {   // the denominator is affine in the source position: its extremes over the grown image are at the corners
     float wmin = 3.0e38f, wmax = -3.0e38f;
     for (int q = 0; q < 4; ++q) {
@@ -90,12 +92,20 @@ __global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* 
       wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
     }
     ok = (wmin * wmax > 0.0f) && (fminf(fabsf(wmin), fabsf(wmax)) >= kGatherWRatio * fmaxf(fabsf(wmin), fabsf(wmax)));
+    if (ok) wspread = fmaxf(fabsf(wmin), fabsf(wmax)) / fminf(fabsf(wmin), fabsf(wmax));
   }
   if (ok) {   // window sizes on a 5 x 5 sample of the source image
     for (int qy = 0; qy < 5 && ok; ++qy)
       for (int qx = 0; qx < 5 && ok; ++qx) {
         const GatherWindow w = gather_window(p.Hs, (float)(W - 1) * 0.25f * qx, (float)(H - 1) * 0.25f * qy);
-        ok = (w.x1 - w.x0 + 1.0f <= (float)kGatherSpanOk) && (w.y1 - w.y0 + 1.0f <= (float)kGatherSpanOk);   // (false for NaN)
+        // The window of a block scales with the Jacobian of u = (Hs x)_xy / w(x): terms in 1/w and (Hs x)_xy / w^2, so between
+        // a sample and any other point of the image it grows by at most (max|w| / min|w|)^2 times the variation of the affine
+        // numerator — bounded here by one more power of the spread.  A plane is regular only if that bound keeps EVERY window
+        // inside the kGatherSpan columns / rows pass 2 walks: a cut window would silently drop gradient terms (flags[1]).
+        const float grow = wspread * wspread * wspread;
+        const float sx = w.x1 - w.x0 + 1.0f, sy = w.y1 - w.y0 + 1.0f;
+        ok = (sx <= (float)kGatherSpanOk) && (sy <= (float)kGatherSpanOk) &&
+             (sx * grow <= (float)(kGatherSpan - 1)) && (sy * grow <= (float)(kGatherSpan - 1));   // (false for NaN)
       }
   }
   p.regular = ok ? 1.0f : 0.0f;

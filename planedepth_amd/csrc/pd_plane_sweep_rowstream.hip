@@ -51,8 +51,13 @@ namespace pd {
 #endif                   // 4 every row as one source row, 8 no gradient stores, 16 no coordinate chain
 constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_STORE_AUX
-#define PD_STREAM_STORE_AUX 0   // cache-policy bits of the gradient stores (1 = sc0, 2 = nt, 16 = sc1)
-#endif
+#define PD_STREAM_STORE_AUX 2   // cache-policy bits of the gradient stores (1 = sc0, 2 = nt, 16 = sc1; 0 = write-back).  nt: the
+#endif                          // 385 MB of gradients stream past the caches instead of leaving ~256 MB of dirty lines behind for
+                                // the next kernels to evict.  Measured (round 4, scripts/gpu_r4_nt.sh): in the hot-path loop this
+                                // kernel pays its own writes (0.178 -> 0.194 ms) and the forward that follows stops paying them
+                                // (0.126-0.133 -> 0.108 ms): step +2-3 %; inside the DDP training step, where the fused decoder
+                                // tail's backward is the consumer, BOTH get faster (this kernel 0.177-0.195 -> 0.170 ms, the
+                                // tail's backward 0.241 -> 0.224 ms)
 #ifndef PD_STREAM_LOAD_AUX
 #define PD_STREAM_LOAD_AUX 0    // same for the tap loads
 #endif
@@ -74,12 +79,6 @@ __device__ __forceinline__ void buf_store2(Rsrc r, unsigned voff, unsigned soff,
   __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, (int)voff,
                                         (int)soff, PD_STREAM_STORE_AUX);
 }
-
-// frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
-// chain against exact arithmetic: fl(x + sd) <= ulp(2W)/2, the division, the two additions and the product by W-1
-// each <= ulp(.)/2 scaled by W-1 — 5.4e-7 * W in total (3.1e-4 at W = 640); the threshold keeps a factor of 2.4-3
-// up to W = 4096.
-__device__ __forceinline__ float irregular_tol(int W) { return 2.5e-4f + 1.25e-6f * (float)W; }
 
 struct StreamLds {
   float4* ctx0;   // [CW] (t0, t1, t2, lse2)            cell = pixel + 2, zero-gradient guard cells around the row
@@ -112,16 +111,6 @@ __device__ __forceinline__ float4 col_at(const StreamLds& L, int i) {
     return make_float4(r, gb.x, gb.y, 0.0f);
   }
   return L.col[i];
-}
-
-// ix of the reference for target column xtf (an integer-valued float) under the shift sd: make_col_tap's chain
-__device__ __forceinline__ float stream_ix(float xtf, float sd, float Wm1, float rcpWm1) {
-#pragma clang fp contract(off)
-  const float px = xtf + sd;
-  const float q = div_by(px, Wm1, rcpWm1);
-  const float h = q - 0.5f;
-  const float hh = h + 0.5f;
-  return hh * Wm1;
 }
 
 template <int NROWS>
@@ -488,7 +477,7 @@ static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves, bool packe
 }
 struct StreamShape { int nwaves; bool packed; size_t lds; };
 static StreamShape rowstream_shape(const pd_sweep_desc* d) {
-  constexpr size_t kCuLds = 160 * 1024;
+  const size_t kCuLds = device_lds_bytes();
   // workgroups per CU by LDS (at most three: 24 waves per CU at the kernel's 77 VGPRs); waves per workgroup to fill them:
   // three workgroups of 8, two of 12, one of 16
   const int wg_plain = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, false));
@@ -505,27 +494,31 @@ static StreamShape rowstream_shape(const pd_sweep_desc* d) {
 
 bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
   return rowshift_applicable(d) && !(d->flags & PD_RENDER_PROB) && !a.has_mask && (d->W % 2 == 0) &&
-         rowstream_shape(d).lds <= 160 * 1024;
+         rowstream_shape(d).lds <= device_lds_bytes();   // else: the row-shift backward, which needs less
 }
 
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
 
 template <bool MIX, bool PK>
-static void rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
-  if (shmem > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)rowstream_bwd_kernel<MIX, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+static int rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+  static size_t granted = 64 * 1024;   // per instantiation: the attribute is set once (and checked), not per launch
+  const int rc = grant_dynamic_lds((const void*)rowstream_bwd_kernel<MIX, PK>, shmem, &granted, "rowstream_bwd_kernel");
+  if (rc) return rc;
   rowstream_bwd_kernel<MIX, PK><<<grid, block, shmem, stream>>>(a, o);
+  return PD_OK;
 }
 
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
   const StreamShape sh = rowstream_shape(d);
   dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
-  if (mix) { if (sh.packed) rowstream_launch<true, true>(a, o, grid, block, sh.lds, stream);
-             else           rowstream_launch<true, false>(a, o, grid, block, sh.lds, stream); }
-  else     { if (sh.packed) rowstream_launch<false, true>(a, o, grid, block, sh.lds, stream);
-             else           rowstream_launch<false, false>(a, o, grid, block, sh.lds, stream); }
-  int rc = check_launch("rowstream_bwd_kernel");
+  int rc;
+  if (mix) rc = sh.packed ? rowstream_launch<true, true>(a, o, grid, block, sh.lds, stream)
+                          : rowstream_launch<true, false>(a, o, grid, block, sh.lds, stream);
+  else     rc = sh.packed ? rowstream_launch<false, true>(a, o, grid, block, sh.lds, stream)
+                          : rowstream_launch<false, false>(a, o, grid, block, sh.lds, stream);
+  if (rc) return rc;
+  rc = check_launch("rowstream_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
   reduce_rows_stream_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);
   return check_launch("reduce_rows_kernel");

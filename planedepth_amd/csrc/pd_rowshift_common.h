@@ -301,8 +301,20 @@ __device__ __forceinline__ void colour_dx(const ColourTaps<NROWS>& t, const RowS
   }
 }
 
+// Shift of plane i along target row `yrow` of image b: sign * disparity clamped to +-(W+2) (beyond +-(W+1) nothing is in
+// view either way).
+__device__ __forceinline__ float staged_shift(const SweepArgs& a, int b, int i, int yrow) {
+  const float lim = (float)(a.W + 2);
+  const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
+  const float sd = a.sign * a.plane[di];
+  // PD_MASK_ROWS: a masked plane samples as all-zero features (trainer.py:580) — exactly what a plane shifted out
+  // of view does (every tap is outside the row), so the row's mask value just overrides the shift
+  const bool masked = a.mask_rows && a.mask_rows[((long)b * a.N + i) * a.H + yrow] == 0.0f;
+  return (!masked && sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
+}
+
 // Stage the live source colour rows of image b into LDS as float4 (with zero guard cells), plus the per-plane shifts
-// sdisp[n] = sign * disparity clamped to +-(W+2) (beyond +-(W+1) nothing is in view either way).
+// sdisp[n] (staged_shift).
 template <int NROWS>
 __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, const RowSel& r, float4* __restrict__ lrgb,
                                                     float* __restrict__ sdisp, int yrow) {
@@ -322,15 +334,24 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
     lrgb[g] = z;
     if (NROWS == 2) lrgb[RS + g] = z;
   }
-  const float lim = (float)(W + 2);
-  for (int i = threadIdx.x; i < a.N; i += blockDim.x) {
-    const long di = (a.flags & PD_DISP_ROWS) ? ((long)b * a.N + i) * a.H + yrow : (long)b * a.N + i;
-    const float sd = a.sign * a.plane[di];
-    // PD_MASK_ROWS: a masked plane samples as all-zero features (trainer.py:580) — exactly what a plane shifted out
-    // of view does (every tap is outside the row), so the row's mask value just overrides the shift
-    const bool masked = a.mask_rows && a.mask_rows[((long)b * a.N + i) * a.H + yrow] == 0.0f;
-    sdisp[i] = (!masked && sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
-  }
+  for (int i = threadIdx.x; i < a.N; i += blockDim.x) sdisp[i] = staged_shift(a, b, i, yrow);
+}
+
+// ---- shared by the source-ordered backward (pd_plane_sweep_rowstream.hip) and the segment-stream forward (pd_plane_sweep_fwdstream.hip) ----
+// frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
+// chain against exact arithmetic: fl(x + sd) <= ulp(2W)/2, the division, the two additions and the product by W-1
+// each <= ulp(.)/2 scaled by W-1 — 5.4e-7 * W in total (3.1e-4 at W = 640); the threshold keeps a factor of 2.4-3
+// up to W = 4096.
+__device__ __forceinline__ float irregular_tol(int W) { return 2.5e-4f + 1.25e-6f * (float)W; }
+
+// ix of the reference for target column xtf (an integer-valued float) under the shift sd: make_col_tap's chain
+__device__ __forceinline__ float stream_ix(float xtf, float sd, float Wm1, float rcpWm1) {
+#pragma clang fp contract(off)
+  const float px = xtf + sd;
+  const float q = div_by(px, Wm1, rcpWm1);
+  const float h = q - 0.5f;
+  const float hh = h + 0.5f;
+  return hh * Wm1;
 }
 
 

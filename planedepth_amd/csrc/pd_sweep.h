@@ -258,6 +258,11 @@ int rowshift_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, flo
 int rowshift_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
 size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d);
 
+// Segment-stream forward (pd_plane_sweep_fwdstream.hip): one wave per 128-pixel segment of a target row, two pixels per
+// lane, one plane per iteration behind a deep register ring of 12-byte tap loads.
+bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a);
+int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
+
 // Row-stream backward (pd_plane_sweep_rowstream.hip): lanes own aligned source slots, waves stream along plane rows.
 bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a);
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);

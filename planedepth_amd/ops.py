@@ -57,7 +57,7 @@ class _timed:
     def __exit__(self, *exc):
         if KERNEL_EVENTS is not None:
             self.b.record()
-            KERNEL_EVENTS[self.kind].append((self.a, self.b))
+            KERNEL_EVENTS.setdefault(self.kind, []).append((self.a, self.b))
         return False
 
 
@@ -262,7 +262,9 @@ class _MultiPlaneSweep(torch.autograd.Function):
 
         def pairable(v):   # plane-uniform views with the same kernel configuration gather together (pd_uniform_gather_pair)
             mode, flags, sign = ctx.cfgs[v[0]]
-            return PAIR_GATHER and mode == C.PD_WARP_HOMOGRAPHY and bool(flags & C.PD_HOMO_UNIFORM) and (need_logits or need_sigma)
+            # (PD_UNI_CHUNK, the library's chunked plane-uniform passes, does not serve the deferred gather: sequential views then)
+            return (PAIR_GATHER and not os.environ.get("PD_UNI_CHUNK") and mode == C.PD_WARP_HOMOGRAPHY and
+                    bool(flags & C.PD_HOMO_UNIFORM) and (need_logits or need_sigma))
         k = 0
         while k < len(views):
             i, saved, g, can = views[k]
@@ -283,6 +285,9 @@ class _MultiPlaneSweep(torch.autograd.Function):
                 if mix and g_sigma is None:
                     g_sigma = torch.zeros_like(logits) if started else torch.empty_like(logits)
                 _gather_pair((saved, ws), (saved_j, ws_j), ctx.cfgs[i], g_logits, g_sigma, accumulate=started)
+                # the two (g_l, g_s) scratch workspaces (2 x [B,N,H,W,2] floats: 770 MB at 8x49x192x640, twice what sequential
+                # views hold at a time) go back to the allocator now, not when the node's frame dies
+                del ws, ws_j
                 per_view[i], per_view[j] = (gp, gd), (gp_j, gd_j)
                 k += 2
                 continue
@@ -941,7 +946,10 @@ def smooth_loss_disp(disp, img, gamma=1.0, x0=0):
     graph: the crop is a pointer offset in the forward, and the backward writes the gradient of the uncropped ``disp``
     directly (zeros left of the crop) — no slice node, i.e. no zero-fill, strided copy and three operator calls per step.
     Tensors that already are crops (``x0 = 0``) are read in place through their strides as before."""
-    return _SmoothLoss.apply(disp, img, gamma, int(x0))
+    x0 = int(x0)
+    if not 0 <= x0 <= disp.shape[-1] - 2:   # the crop is a pointer offset: a bad one would read past every row
+        raise ValueError("smooth_loss_disp: x0 = %d is not a crop of a width-%d tensor (need 0 <= x0 <= W - 2)" % (x0, disp.shape[-1]))
+    return _SmoothLoss.apply(disp, img, gamma, x0)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -967,7 +975,7 @@ class _DecoderTail(torch.autograd.Function):
         logits = new(B, N, H, W) if padding_mask is not None else None
         sigma = new(B, N, H, W) if mix else None
         disp, depth, stash = new(B, 1, H, W), new(B, 1, H, W), new(B, 2, H, W)
-        with C.on_device(dev):
+        with C.on_device(dev), _timed("tail_fwd"):
             C.check(lib.pd_decoder_tail_fwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
                                             C.ptr(disp_layered), C.ptr(logits), C.ptr(sigma), C.ptr(disp), C.ptr(depth),
                                             C.ptr(stash), C.stream_handle(dev)), "pd_decoder_tail_fwd")
@@ -999,7 +1007,7 @@ class _DecoderTail(torch.autograd.Function):
             ws = torch.empty(lib.pd_decoder_tail_bwd_workspace_floats(B, N, H, W), device=raw_logits.device,
                              dtype=torch.float32)
         g_logits, g_sigma, g_disp, g_depth = map(_contig, (g_logits, g_sigma if mix else None, g_disp, g_depth))
-        with C.on_device(raw_logits.device):
+        with C.on_device(raw_logits.device), _timed("tail_bwd"):
             C.check(lib.pd_decoder_tail_bwd(B, N, H, W, flags, C.ptr(raw_logits), C.ptr(raw_sigma), C.ptr(padding_mask),
                                             C.ptr(disp_layered), C.ptr(stash), C.ptr(disp), C.ptr(g_logits),
                                             C.ptr(g_sigma), C.ptr(g_disp), C.ptr(g_depth), C.ptr(g_raw_logits),

@@ -267,6 +267,69 @@ def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, m
     _compare(new, {"g_disp_pp": want["g_disp_pp"]}, tag="rowstream/W%d" % W, tol=2e-4)
 
 
+@pytest.mark.parametrize("B,N,H,W,sign,mix,automask,rows", [
+    (8, 49, 24, 640, 1.0, True, False, False),    # the headline row shape: five segments
+    (3, 49, 192, 640, 1.0, True, True, False),    # every row of H = 192 (48 with two live source rows per image), B % 8 != 0
+    (2, 12, 9, 640, -1.0, True, False, False),    # target "l": negative shifts (one segment per plane straddles column 0)
+    (1, 5, 3, 64, 1.0, True, False, False),       # half a segment
+    (2, 7, 17, 132, 1.0, False, False, False),    # ragged width (W % 128 != 0), L1 loss
+    (2, 7, 5, 130, -1.0, True, True, False),      # ragged, negative shifts, automask
+    (2, 63, 21, 200, 1.0, True, True, True),      # per-row disparities (xz planes), PD_DISP_ROWS
+    (2, 49, 48, 1280, 1.0, True, False, False),   # wide rows: ten waves per workgroup
+])
+def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign, mix, automask, rows):
+    """The segment-stream forward (pd_plane_sweep_fwdstream.hip: a wave per 128-pixel segment, two pixels per lane, 12-byte
+    tap loads, one plane per iteration) against the plane-group row-shift forward (PD_IMPL_ROWS1) through the C ABI: rgb_rec,
+    ph_map and the backward's stash agree to a few ulp (same expressions; the planes of a pixel are summed by one wave
+    in order instead of merged plane ranges, and rows with two live source rows blend the colour row before the
+    horizontal taps), mean(ph_map) to summation order — and each kernel reproduces itself bit for bit from call to call."""
+    from planedepth_amd import _capi as C
+    lib = C.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 1000 + W + N)
+    mk = lambda *sh: torch.rand(*sh, generator=g).to(dev)  # noqa: E731
+    src, tgt = mk(B, 3, H, W), mk(B, 3, H, W)
+    logits = (torch.randn(B, N, H, W, generator=g) * 2.0).to(dev)
+    sigma = (torch.rand(B, N, H, W, generator=g) * 1.2).to(dev)
+    disp = (300.0 * (2.0 / 300.0) ** ((torch.arange(N, dtype=torch.float32)[None] + torch.rand(B, N, generator=g) - 0.5) / max(N - 1, 1)))
+    disp = disp * (W / 640.0)
+    flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if automask else 0)
+    if rows:
+        gain = torch.linspace(0.2, 1.6, H)[None, None, :]
+        plane = (disp[:, :, None] * gain).contiguous().to(dev)   # [B,N,H]
+        flags |= C.PD_DISP_ROWS
+    else:
+        plane = disp.contiguous().to(dev)
+    st = C.stream_handle(dev)
+    out = {}
+    for impl in (C.PD_IMPL_AUTO, C.PD_IMPL_ROWS1):
+        d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, flags, sign, impl)
+        k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
+        res = []
+        for rep in range(2):
+            rgb = torch.full((B, 3, H, W), float("nan"), device=dev)
+            ph = torch.full((B, 1, H, W), float("nan"), device=dev)
+            stash = torch.full((B, k, H, W), float("nan"), device=dev)
+            phm = torch.full((1,), float("nan"), device=dev)
+            C.check(lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma if mix else None),
+                                           C.ptr(plane), None, None, None, None, C.ptr(rgb), C.ptr(ph), C.ptr(phm), C.ptr(stash), st), "fwd")
+            torch.cuda.synchronize()
+            res.append((rgb.cpu(), ph.cpu(), stash[:, :4].cpu(), phm.cpu()))
+        for a_, b_ in zip(res[0][:3], res[1][:3]):
+            assert torch.equal(a_, b_), "not reproducible from call to call"
+        out[impl] = res[0]
+    new, old = out[C.PD_IMPL_AUTO], out[C.PD_IMPL_ROWS1]
+    for name, a_, b_ in zip(("rgb_rec", "ph_map", "stash"), new[:3], old[:3]):
+        assert not torch.isnan(a_).any(), name
+        if name == "stash":   # (lse2, sum pi/sigma, sum pi*lap, automask flag): the flag may flip on exact ties only
+            assert float((a_[:, 3] != b_[:, 3]).float().mean()) < 1e-5
+            a_, b_ = a_[:, :3], b_[:, :3]
+        for ch in range(a_.shape[1]):
+            assert rel_err(a_[:, ch], b_[:, ch]) < 3e-6, (name, ch, rel_err(a_[:, ch], b_[:, ch]))
+    assert abs(float(new[3]) - float(old[3])) <= 2e-6 * abs(float(old[3])), (float(new[3]), float(old[3]))
+    assert abs(float(old[3]) - float(old[1].mean())) <= 1e-5 * abs(float(old[3]))
+
+
 def test_rowstream_backward_at_the_high_resolution_configuration():
     """BASELINE configs[4] (384x1280, 49 planes; one image here): the packed LDS context and 12-wave workgroups of the wide
     rows against the target-ordered row-shift backward on the same forward."""
