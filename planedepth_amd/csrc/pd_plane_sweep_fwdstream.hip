@@ -40,6 +40,9 @@ namespace pd {
 #define PD_FS_OCC 5  // waves per SIMD the register allocator must leave room for: 96 VGPRs, which the mixture kernel just fits
 #endif               // (the automask variant needs 8 more for its extra exponential's operands: it runs at 4 waves per SIMD)
 
+#ifndef PD_FS_REVERSE
+#define PD_FS_REVERSE 0   // row groups dispatched bottom-up (the backward then walks top-down: PD_BWD_REVERSE 0)
+#endif
 #ifndef PD_FS_LDS_PAD
 #define PD_FS_LDS_PAD 0   // timing experiments: extra LDS bytes per workgroup (caps the workgroups per CU)
 #endif
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(kFsThreadsMax, (MIX && AUTO) ? PD_FS_OCC - 1 : PD_F
   int2* shift = reinterpret_cast<int2*>(col + a.W + 2 * kFsGuard);
   float* parts = reinterpret_cast<float*>(lds4 + rows * row_f4);
   const int groups = (a.H + rows - 1) / rows;                    // row groups per image: the grid is (groups, B), dealt row-major
-  const int y = wg_rowid(a.B, groups) * rows + slot, b = wg_image(a.B, groups);
+  const int grp = PD_FS_REVERSE ? groups - 1 - wg_rowid(a.B, groups) : wg_rowid(a.B, groups);
+  const int y = grp * rows + slot, b = wg_image(a.B, groups);
   const bool active = y < a.H;
   const RowSel row = two_row_form(make_row_sel(active ? y : 0, a.H), a.fast_rows != 0);
   const int tix = threadIdx.x - slot * nseg * kWave, nthr = nseg * kWave;

@@ -799,203 +799,10 @@ __global__ __launch_bounds__(kStageThreads) void uniform_bwd_pass2_pair_kernel(P
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Backward, fused: pass 1 and pass 2 in one kernel, the per-plane gradients handed over through LDS
-// ---------------------------------------------------------------------------------------------------------------
-// A workgroup of 1024 threads owns a 16 x 40 tile of source pixels of image b (192 x 640: 12 x 16 tiles, six full
-// rounds of workgroups on 256 CUs; the box of such a tile stays below 1024 pixels for in-plane rotations up to ~5 degrees).  Because the map is the same for every
-// plane, so is the set of target pixels whose samples touch the tile (the bounding box of the tile's pre-image, as in
-// pass 2), and everything that depends on the geometry only is set up ONCE per thread and kept in registers:
-//   * thread t < npx owns target pixel t of the box: its context, tap offsets / weights, colour samples;
-//   * thread t < nsrc owns source pixel t of the tile: its gather list (box slot, bilinear weight), found as in pass 2.
-// Per plane: every target thread computes (g_l, g_s) of its pixel (8 loads, requested one plane ahead; the closed-form
-// gradients) and writes them to the LDS slot of its pixel; barrier; every source thread sums its list out of LDS and
-// stores its gradient element — plain coalesced stores, each element once, no scratch tensor in HBM (the two-pass form
-// moves 770 MB through it per launch).  Two LDS buffers alternate: one barrier per plane.  The price of ownership is
-// the box's margin: (16+3)(40+3)/(16*40) = 1.28x the per-plane work of pass 1 — cheap here, the geometry being amortised.
-// The kernel serves the regular case only (box <= 1024 pixels, gather lists <= 12 entries).  A
-// workgroup that meets anything else raises a device flag; the two-pass kernels, launched behind it, return at once
-// unless that flag is set and otherwise recompute the whole launch (large rotations, zooms: rare, exact either way).
-#ifdef PD_EXPERIMENTS   // measured slower than the two-pass form: not in the product library
-#ifndef PD_FUSE_K
-#define PD_FUSE_K 12
+#ifdef PD_EXPERIMENTS   // the one-kernel form (LDS hand-over, no scratch): measured slower; lives in scripts/experiments/
+#include "pd_plane_sweep_uniform_fused.inc"
 #endif
-constexpr int kFuseThreads = 1024, kFuseR = 16, kFuseC = 40, kFuseK = PD_FUSE_K;
 
-template <bool MIX>
-__global__ __launch_bounds__(kFuseThreads) void uniform_bwd_fused_kernel(SweepArgs a, BwdOut o, const UniPrep* __restrict__ prep,
-                                                                        float* __restrict__ partials, const float* __restrict__ tw,
-                                                                        int tiles_x, int* __restrict__ irregular_flag) {
-  __shared__ float2 gbuf[2][kFuseThreads];
-  __shared__ float red[kUniG * 9];
-  const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-  const int xs0 = txi * kFuseC, ys0 = tyi * kFuseR;
-  const int tw_ = min(kFuseC, W - xs0), th = min(kFuseR, H - ys0);
-  const bool want_plane = (o.g_plane != nullptr);
-  if (tid < kUniG * 9) red[tid] = 0.0f;
-  const CoordNorm cn = make_coord_norm(W, H);
-  const float* Hm = a.plane + (long)b * kUniH;
-  const float* Ki = a.inv_K3 + (long)b * 9;
-  const float* srcb = a.src + (long)b * 3 * HW;
-  const float* Rn = a.plane_aux + (long)b * N * 3;
-  const float* twb = tw ? tw + (long)b * N * 3 : nullptr;
-  const UniPrep pr = prep[b];
-  // box of the tile: union of its four corner pixels' windows (the pre-image of a convex region is convex)
-  int bx0, bx1, by0, by1;
-  {
-    const UniWindow w0 = uni_window(pr, xs0, ys0, W, H), w1 = uni_window(pr, xs0 + tw_ - 1, ys0 + th - 1, W, H);
-    const UniWindow w2 = uni_window(pr, xs0 + tw_ - 1, ys0, W, H), w3 = uni_window(pr, xs0, ys0 + th - 1, W, H);
-    bx0 = min(min(w0.x0, w1.x0), min(w2.x0, w3.x0)); bx1 = max(max(w0.x1, w1.x1), max(w2.x1, w3.x1));
-    by0 = min(min(w0.y0, w1.y0), min(w2.y0, w3.y0)); by1 = max(max(w0.y1, w1.y1), max(w2.y1, w3.y1));
-  }
-  const int bw = max(bx1 - bx0 + 1, 0), bh = max(by1 - by0 + 1, 0);
-  const int npx = bw * bh, nsrc = tw_ * th;
-  if (npx > kFuseThreads) {              // workgroup-uniform: not the regular case
-    if (tid == 0) atomicOr(irregular_flag, 1);
-    return;
-  }
-  __syncthreads();
-
-  // ---- target-side setup (thread = box slot) ----
-  const bool has_t = tid < npx;
-  PixelCtx c = zero_pixel_ctx();
-  TapK tk;
-  tk.o00 = tk.o01 = tk.o10 = tk.o11 = 0u;
-  tk.w00 = tk.w01 = tk.w10 = tk.w11 = 0.0f;
-  tk.x00 = tk.x01 = tk.x10 = tk.x11 = tk.y00 = tk.y01 = tk.y10 = tk.y11 = 0.0f;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0x = 0.f, d0y = 0.f, d1x = 0.f, d1y = 0.f, d2x = 0.f, d2y = 0.f;
-  float r0 = 0.f, r1 = 0.f, r2 = 0.f, p0 = 0.f, p1 = 0.f, inv_z = 0.f, fxx = 0.f, fyy = 0.f;
-  bool z_ok = false, zcl = false, owner = false;
-  if (has_t) {
-    const int ry = tid / bw, rx = tid - ry * bw;
-    const int x = bx0 + rx, y = by0 + ry;
-    c = make_pixel_ctx<MIX>(a, o, b, y * W + x, HW);
-    const UniGeom u = uni_geom(Hm, Ki, cn, x, y);
-    const Tap t = make_tap(u.g.ix, u.g.iy, W, H);
-    tk = tap_kernel(t, W, H);
-    s0 = sample_vg_k(srcb, tk, d0x, d0y); s1 = sample_vg_k(srcb + HW, tk, d1x, d1y); s2 = sample_vg_k(srcb + 2 * HW, tk, d2x, d2y);
-    r0 = u.r0; r1 = u.r1; r2 = u.r2; z_ok = u.z_ok; zcl = u.g.z_clamped; p0 = u.g.p0; p1 = u.g.p1;
-    inv_z = fast_rcp(u.g.zc);
-    inv_z = fmaf(fmaf(-u.g.zc, inv_z, 1.0f), inv_z, inv_z);
-    fxx = (float)x; fyy = (float)y;
-    // the homography gradient of a target pixel is counted by the tile that holds its (clamped) top-left tap
-    const int ox = min(max(t.x0, 0), W - 1) - xs0, oy = min(max(t.y0, 0), H - 1) - ys0;
-    owner = want_plane && (unsigned)ox < (unsigned)tw_ && (unsigned)oy < (unsigned)th;
-  }
-  float gixw[kUniG], giyw[kUniG];
-#pragma unroll
-  for (int j = 0; j < kUniG; ++j) gixw[j] = giyw[j] = 0.0f;
-
-  // ---- source-side setup (thread = pixel of the tile): gather list over box slots ----
-  const bool has_s = tid < nsrc;
-  int sx = 0, sy = 0, cnt = 0;
-  int idx[kFuseK];
-  float wgt[kFuseK];
-#pragma unroll
-  for (int k = 0; k < kFuseK; ++k) { idx[k] = 0; wgt[k] = 0.0f; }
-  if (has_s) {
-    const int ry = tid / tw_, rx = tid - ry * tw_;
-    sx = xs0 + rx; sy = ys0 + ry;
-    const UniWindow win = uni_window(pr, sx, sy, W, H);
-    for (int ty = win.y0; ty <= win.y1; ++ty)
-      for (int tx = win.x0; tx <= win.x1; ++tx) {
-        const UniGeom u = uni_geom(Hm, Ki, cn, tx, ty);
-        const float w = tap_weight_on(u.g.ix, u.g.iy, sx, sy);
-        if (w != 0.0f) {
-#pragma unroll
-          for (int k = 0; k < kFuseK; ++k)
-            if (k == cnt) { idx[k] = (ty - by0) * bw + (tx - bx0); wgt[k] = w; }
-          ++cnt;
-        }
-      }
-    if (cnt > kFuseK) atomicOr(irregular_flag, 1);   // the two-pass kernels redo the launch
-  }
-  int kmax = min(cnt, kFuseK);
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, kWave));
-  kmax = __builtin_amdgcn_readfirstlane(kmax);
-  float* gl = (has_s && o.g_logits) ? o.g_logits + (long)b * N * HW + (long)sy * W + sx : nullptr;
-  float* gs = (has_s && MIX && o.g_sigma) ? o.g_sigma + (long)b * N * HW + (long)sy * W + sx : nullptr;
-
-  // ---- planes ----
-  // The eight tap values of plane n + 1 are requested before plane n is reduced, and the workgroup barrier is issued as
-  // inline assembly: the compiler drains every counter in front of an s_barrier it knows about (gfx9 rule), which would
-  // wait for exactly those loads; the hardware keeps VMEM in flight across a barrier.
-  struct TapVals { float l00, l01, l10, l11, s00, s01, s10, s11; };
-  auto fetch = [&](int n) {
-    TapVals v;
-    const long pl = ((long)b * N + n) * HW;
-    const float* L = a.logits + pl;
-    v.l00 = at_byte(L, tk.o00); v.l01 = at_byte(L, tk.o01); v.l10 = at_byte(L, tk.o10); v.l11 = at_byte(L, tk.o11);
-    v.s00 = v.s01 = v.s10 = v.s11 = 0.0f;
-    if (MIX) {
-      const float* S = a.sigma + pl;
-      v.s00 = at_byte(S, tk.o00); v.s01 = at_byte(S, tk.o01); v.s10 = at_byte(S, tk.o10); v.s11 = at_byte(S, tk.o11);
-    }
-    return v;
-  };
-  TapVals cur = fetch(0);
-  for (int n = 0; n < N; ++n) {
-    const int p = n & 1;
-    const TapVals nxt = fetch(min(n + 1, N - 1));   // unconditional (see the row kernels' note on vmcnt bookkeeping)
-    float g_l = 0.0f, g_s = 0.0f;
-    if (has_t && ((r0 * Rn[n * 3] + r1 * Rn[n * 3 + 1] + r2 * Rn[n * 3 + 2]) > 0.0f) && z_ok) {
-      const float l = cur.l00 * tk.w00 + cur.l01 * tk.w01 + cur.l10 * tk.w10 + cur.l11 * tk.w11;
-      const float s = MIX ? cur.s00 * tk.w00 + cur.s01 * tk.w01 + cur.s10 * tk.w10 + cur.s11 * tk.w11 : 0.0f;
-      const PlaneGrad pg = plane_grad<MIX>(c, l, s, s0, s1, s2);
-      g_l = pg.g_l; g_s = pg.g_s;
-      if (owner) {
-        const float dlx = cur.l00 * tk.x00 + cur.l01 * tk.x01 + cur.l10 * tk.x10 + cur.l11 * tk.x11;
-        const float dly = cur.l00 * tk.y00 + cur.l01 * tk.y01 + cur.l10 * tk.y10 + cur.l11 * tk.y11;
-        const float dsx = MIX ? cur.s00 * tk.x00 + cur.s01 * tk.x01 + cur.s10 * tk.x10 + cur.s11 * tk.x11 : 0.0f;
-        const float dsy = MIX ? cur.s00 * tk.y00 + cur.s01 * tk.y01 + cur.s10 * tk.y10 + cur.s11 * tk.y11 : 0.0f;
-        const float gx = pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * d0x + pg.gc1 * d1x + pg.gc2 * d2x;
-        const float gy = pg.g_l * dly + pg.g_s * dsy + pg.gc0 * d0y + pg.gc1 * d1y + pg.gc2 * d2y;
-        gixw[0] += gx; giyw[0] += gy;
-        if (twb) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { const float w = twb[n * 3 + j]; gixw[1 + j] += gx * w; giyw[1 + j] += gy * w; }
-        }
-      }
-    }
-    cur = nxt;
-    gbuf[p][tid] = make_float2(g_l, g_s);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (has_s) {
-      float accl = 0.0f, accs = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const float2 v = gbuf[p][idx[k]]; accl += wgt[k] * v.x; if (MIX) accs += wgt[k] * v.y; }
-#pragma unroll
-      for (int k = 4; k < kFuseK; ++k)
-        if (k < kmax) { const float2 v = gbuf[p][idx[k]]; accl += wgt[k] * v.x; if (MIX) accs += wgt[k] * v.y; }
-      if (gl) gl[(long)n * HW] = accl;
-      if (gs) gs[(long)n * HW] = accs;
-    }
-  }
-  if (want_plane) {   // the homography gradient of the targets this tile owns
-    const float gscale_x = (float)(W - 1) / 2 * 2.0f / (float)(W - 1), gscale_y = (float)(H - 1) / 2 * 2.0f / (float)(H - 1);
-    const int ln = tid & (kWave - 1);
-#pragma unroll
-    for (int j = 0; j < kUniG; ++j) {
-      const float gp0 = gixw[j] * gscale_x * inv_z, gp1 = giyw[j] * gscale_y * inv_z;
-      const float gz = zcl ? 0.0f : -(gp0 * p0 + gp1 * p1) * inv_z;
-      const float gk[9] = {gp0 * fxx, gp0 * fyy, gp0, gp1 * fxx, gp1 * fyy, gp1, gz * fxx, gz * fyy, gz};
-#pragma unroll
-      for (int k = 0; k + 1 < 9; k += 2) {
-        const float v = half_wave_sums_hi(gk[k], gk[k + 1]);
-        if ((ln & 31) == 31) lds_add(&red[j * 9 + k + (ln >> 5)], v);
-      }
-      const float v8 = wave_sum_hi(gk[8]);
-      if (ln == kWave - 1) lds_add(&red[j * 9 + 8], v8);
-    }
-    __syncthreads();
-    if (tid < kUniG * 9) partials[((long)b * gridDim.x + blockIdx.x) * (kUniG * 9) + tid] = red[tid];
-  }
-}
-
-#endif  // PD_EXPERIMENTS
 
 // partial sums of the kernels that ran: the fused kernel's unless it raised the flag
 __global__ void uniform_reduce_kernel(const float* __restrict__ part_fused, int nblk_fused, const float* __restrict__ part_two,

@@ -37,8 +37,12 @@ constexpr int kMaxRowThreads = 1024;
 #define PD_LOAD_AUX 0   // same for the tap loads
 #endif
 #ifndef PD_BWD_REVERSE
-#define PD_BWD_REVERSE 0  // experiment: backward walks the rows in reverse (measured 1.4 % slower per step)
-#endif
+#define PD_BWD_REVERSE 1  // the backward walks the rows in the opposite order of the forward: what the forward read last is
+#endif                    // what the backward reads first, and the other way round for the next step's forward — with the
+                          // gradient stores streaming past the caches (PD_STREAM_STORE_AUX = nt) the 256 MB memory-side cache
+                          // still holds those rows: step +2.4-2.8 % (forward 0.109 -> 0.105 ms, backward 0.178 -> 0.174), and
+                          // the same inside the DDP training step.  (Round 1, write-back stores: no gain — the dirty gradient
+                          // lines cycled the cache.  Forward bottom-up / backward top-down instead: +1 %, worse in the DDP step.)
 #ifndef PD_BWD_HANDOVER
 #define PD_BWD_HANDOVER 1  // lane 0 takes its left neighbour's hand-over out of LDS when it is already there
 #endif
@@ -78,9 +82,8 @@ __device__ __forceinline__ int wg_rowid(int B, int H) {
   if (kVariant & 8) return blockIdx.x;
   return (int)((blockIdx.y * gridDim.x + blockIdx.x) / (unsigned)B);
 }
-// Experiment (PD_BWD_REVERSE): the backward walking the rows in the opposite order of the forward, hoping that what the
-// forward touched last is still in the memory-side cache when autograd starts the backward right after it.  Measured:
-// step 0.437 vs 0.431 ms — no cache benefit, and the long two-source-row rows end up in the tail.
+// PD_BWD_REVERSE: the backward walks the rows in the opposite order of the forward, so that what the forward touched last
+// is still in the memory-side cache when autograd starts the backward right after it (see the switch above for the numbers).
 __device__ __forceinline__ int bwd_rowid(int B, int H) {
   const int r = wg_rowid(B, H);
   return PD_BWD_REVERSE ? H - 1 - r : r;

@@ -44,7 +44,8 @@ def run_product(case, run, device="cuda", force_dense=False, through_trainer=Tru
     planedepth_amd.pred_novel_images(ns, inputs, outputs)
     losses = planedepth_amd.compute_losses(ns, inputs, outputs)
     rgb_rec = outputs[("rgb_rec", side)]
-    (losses["loss/ph_loss"] + (rgb_rec * c["g_rgb_rec"]).sum()).backward()
+    # (run["ph_scale"]: weight of the photometric head in the test objective — a full batch against its data-parallel shards)
+    (losses["loss/ph_loss"] * run.get("ph_scale", 1.0) + (rgb_rec * c["g_rgb_rec"]).sum()).backward()
     z = torch.zeros_like
     res = dict(rgb_rec=rgb_rec, ph_loss=losses["loss/ph_loss"], ph_map=outputs[("ph_map", side)],
                smooth_loss=losses["loss/smooth_loss"], total_loss=losses["loss/total_loss"],

@@ -4,12 +4,12 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md"]
+DOCS = ["DESIGN.md", "NOTEBOOK.md", "README.md", "INTEGRATION.md", "profiles/README.md", "scripts/README.md"]
 
 
 def _defined_tests():
     names = set()
-    for f in glob.glob(os.path.join(ROOT, "tests", "test_*.py")):
+    for f in glob.glob(os.path.join(ROOT, "tests", "**", "test_*.py"), recursive=True):
         names.update(re.findall(r"^def (test_\w+)", open(f).read(), flags=re.M))
     return names
 
