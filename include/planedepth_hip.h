@@ -95,7 +95,7 @@ enum pd_sweep_impl {
                             as GENERAL, and homography_warp's backward runs the owned-tile kernel (pd_plane_sweep_tile.hip:
                             LDS accumulators per source tile, plain stores, no zero-fill) instead of the atomic scatter.
                             Exact and atomic-free in HBM, but 2-2.5x SLOWER on gfx950 (ds_add_f32 costs ~110 cycles per
-                            wave instruction: DESIGN.md 3.4.6) - kept as an in-suite cross-check and as the record of
+                            wave instruction: NOTEBOOK.md 3.4.6) - kept as an in-suite cross-check and as the record of
                             that measurement */
   ,
   PD_IMPL_ROWS1 = 4      /* as AUTO, but forward and backward are the target-ordered, one-pixel-per-lane row-shift kernels
@@ -122,7 +122,7 @@ const char* pd_last_error(void);
  * include/: __graft_entry__.source_hash), baked in at build time (-DPD_SRC_HASH); "unknown" for a build without it. */
 const char* pd_source_hash(void);
 /* 1 if the library was built with -DPD_EXPERIMENTS: the kernels measured SLOWER than the defaults (four-pixels-per-lane
- * row kernels, owned-tile backward, one-kernel plane-uniform backward) are then compiled in and selectable
+ * row kernels, owned-tile backward, one-kernel plane-uniform backward; NOTEBOOK.md 3.5) are then compiled in and selectable
  * (PD_IMPL_TILE; PD_QUAD_FWD / PD_QUAD_BWD / PD_UNI_FUSED in the environment).  The product library returns 0. */
 int pd_experiments(void);
 

@@ -514,7 +514,7 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
     // default for the headline shape: one wave per 128-pixel segment streams over the planes (pd_plane_sweep_fwdstream.hip);
     // PD_IMPL_ROWS1 keeps the plane-group row-shift forward (cross-check, A/B)
     if (d->impl != PD_IMPL_ROWS1 && fwdstream_applicable(d, a)) return fwdstream_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
-#ifdef PD_EXPERIMENTS   // wide-access forward (2 / 4 pixels per lane): faster isolated, slower inside the step
+#ifdef PD_EXPERIMENTS   // wide-access forward (2 / 4 pixels per lane): faster isolated, slower inside the step (NOTEBOOK.md 3.5.6)
     if (rowquad_applicable(d, a.has_mask != 0) && getenv("PD_QUAD_FWD"))
       return rowquad_fwd(d, a, rgb_rec, ph_map, stash, (hipStream_t)stream);
 #endif

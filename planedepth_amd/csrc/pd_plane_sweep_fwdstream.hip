@@ -1,26 +1,30 @@
 // Segment-stream forward of the fused plane sweep: PD_WARP_DISP with one disparity per (image, plane) or per (image,
-// plane, row), no per-pixel mask, softmax probabilities (reference trainer.py:540-603 + 728-742) — the headline forward.
+// plane, row), no per-pixel mask; softmax probabilities or, PD_RENDER_PROB, alpha compositing (reference trainer.py:540-603
+// + 728-742) — the headline forward.
 //
 // The plane-group forward (pd_plane_sweep_rowshift.hip) keeps two groups of four planes in registers per wave (taps,
 // colour taps, coordinates: 148 VGPRs = 3 waves per SIMD, 12 per CU) and splits a row's segments and planes over four
 // waves that meet in LDS.  Measured: its load phase and its arithmetic are both latency-bound at that occupancy (all
 // arithmetic compiled out: 0.136 ms; all tap loads compiled out: 0.092 ms; 30 VALU per pixel and plane are 0.02 ms of
 // issue time), and neither persistent workgroups nor overlapped row staging move it (scripts/experiments/
-// pd_plane_sweep_rowpersist.hip.txt).  This kernel is the forward counterpart of the row-stream backward's loop:
+// pd_plane_sweep_rowpersist.hip.txt, NOTEBOOK.md 9.1).  This kernel is the forward counterpart of the row-stream
+// backward's loop (0.123 -> 0.104 ms isolated at 8x49x192x640, NOTEBOOK.md 9.2):
 //   * one wave owns one 128-pixel segment of a target row and ALL planes: no split of the online softmax, no partial
-//     sums through LDS, no barrier after the row's constants are staged; the waves of a row (5 at W = 640) start together
-//     and do the same work, so between them they read a plane's whole source row at about the same time;
+//     sums through LDS, no barrier after the row's constants are staged, one pipeline fill per wave;
 //   * a lane owns two adjacent target pixels; the taps of both on plane n are the three source values at xt + k ..
 //     xt + k + 2, k = floor(s d_n): ONE 12-byte load per tensor and live source row (4-byte aligned; the buffer
 //     descriptor's range check is padding_mode = "zeros"), half the memory instructions per pixel of the 8-byte form;
 //   * one plane per iteration behind a register ring of PD_FS_D1 iterations of loads (6 VGPRs per slot): the state per
-//     wave is two accumulator sets + the ring, ~90 VGPRs instead of 148 — five waves per SIMD, 20 per CU, each with
-//     three planes of loads in flight;
+//     wave is two accumulator sets + the ring, 94 VGPRs instead of 148;
+//   * a workgroup serves PD_FS_ROWS = 3 consecutive target rows (15 waves at W = 640, one workgroup per CU): its waves start
+//     together and do the same work, so between them they read three adjacent rows of every plane at about the same
+//     time, and the second source row of an inexact row is its neighbour's main row in the same L1;
 //   * the colour taps come out of LDS (packed float4 row, vertically pre-blended for rows with two live source rows, as
-//     the row-stream backward stages it) when the plane is reduced.
+//     the row-stream backward stages it) when the plane is reduced;
+//   * PD_RENDER_PROB: the planes of a pixel arrive in order in one wave, so the transmittance is a register.
 //
 // Exactness.  The pairing "left tap of target xt on plane n = source column xt + k" is the row-stream backward's premise
-// (pd_rowshift_common.h: stream_ix, irregular_tol): planes whose frac(s d) is closer than irregular_tol
+// (pd_rowshift_common.h: stream_ix, irregular_tol; NOTEBOOK.md 3.6.3): planes whose frac(s d) is closer than irregular_tol
 // to an integer take a general per-pixel path (exact floor(ix) per pixel, dword loads), and so does the one segment per
 // plane that straddles column 0 under a negative shift (a 12-byte load that STARTS left of the row reads as zeros as a
 // whole).  Weights and samples are the reference's expressions in the row-shift forward's order.
@@ -43,6 +47,9 @@ namespace pd {
 #ifndef PD_FS_REVERSE
 #define PD_FS_REVERSE 0   // row groups dispatched bottom-up (the backward then walks top-down: PD_BWD_REVERSE 0)
 #endif
+#ifndef PD_FS_ABL
+#define PD_FS_ABL 0
+#endif
 #ifndef PD_FS_LDS_PAD
 #define PD_FS_LDS_PAD 0   // timing experiments: extra LDS bytes per workgroup (caps the workgroups per CU)
 #endif
@@ -63,6 +70,7 @@ __device__ __forceinline__ v3f fs_load3(Rsrc r, unsigned byte_off) {
 template <int NROWS>
 struct FsTaps {   // the taps of one plane for the lane's two pixels: L[c .. c+2] per live source row
   float l[NROWS][3], s[NROWS][3];
+  float dist[2];  // PD_RENDER_PROB: the decoder's inter-plane distances at the two TARGET pixels (trainer.py:587)
 };
 
 struct FsRow {    // workgroup-uniform
@@ -92,10 +100,20 @@ __device__ __forceinline__ void fs_issue(FsTaps<NROWS>& g, const SweepArgs& a, c
 
 // The lane's two pixels on a plane that does not qualify for the 12-byte form: exact floor(ix) per pixel, dword loads
 // (range-checked: an out-of-image tap reads as zero), colour taps from the guard-celled LDS row.
-template <bool MIX, int NROWS, bool AUTO>
+// One plane's samples of pixel i enter its running sums: the softmax, or (RENDER) front-to-back alpha compositing —
+// the planes of a pixel arrive in order in this kernel (one wave walks them all), so the transmittance is one register.
+template <bool MIX, bool RENDER>
+__device__ __forceinline__ void fs_accumulate(FwdAcc& acc, RenderState& rs, float l, float s, float c0, float c1, float c2,
+                                              float t0, float t1, float t2, float ea, bool automask, float dist, bool last) {
+  if (RENDER) mixture_accumulate<MIX>(acc, render_prob(rs, render_alpha(l, dist, last)), s, c0, c1, c2, t0, t1, t2, ea, automask);
+  else fwd_accumulate<MIX>(acc, l, s, c0, c1, c2, t0, t1, t2, ea, automask);
+}
+
+template <bool MIX, int NROWS, bool RENDER>
 __device__ __forceinline__ void fs_general_plane(const SweepArgs& a, const FsRow& r, const float4* __restrict__ col, int n,
                                                  float sd, float xt0f, int HW, float Wm1, float rcpWm1, const float* t,
-                                                 const float* ea, bool automask, FwdAcc* acc) {
+                                                 const float* ea, bool automask, FwdAcc* acc, RenderState* rs,
+                                                 const float* dist) {
   const float* pl = plane_ptr(a.logits + (long)r.b * a.N * HW, n, HW);
   const float* ps = MIX ? plane_ptr(a.sigma + (long)r.b * a.N * HW, n, HW) : pl;
   const Rsrc lA = row_rsrc(pl + (long)r.yA * a.W, a.W), lB = row_rsrc(pl + (long)r.yB * a.W, a.W);
@@ -120,14 +138,14 @@ __device__ __forceinline__ void fs_general_plane(const SweepArgs& a, const FsRow
     const int cell = min(max(ct.x0, -kFsGuard), a.W + 2) + kFsGuard;
     const float4 ca = col[cell], cb = col[cell + 1];
     const float c0 = ca.x * ct.w0 + cb.x * ct.w1, c1 = ca.y * ct.w0 + cb.y * ct.w1, c2 = ca.z * ct.w0 + cb.z * ct.w1;
-    fwd_accumulate<MIX>(acc[i], l, s, c0, c1, c2, t[i], t[2 + i], t[4 + i], ea[i], automask);
+    fs_accumulate<MIX, RENDER>(acc[i], rs[i], l, s, c0, c1, c2, t[i], t[2 + i], t[4 + i], ea[i], automask, dist[i], n == a.N - 1);
   }
 }
 
 // One target row (b, y): `tix` / `nthr` = this thread's index among the threads that serve the row (nseg waves), `seg` the
 // wave's segment.  Contains one workgroup barrier (after staging): every thread of the workgroup calls it, `active` = false
 // for the waves of a row beyond the image.
-template <bool MIX, bool AUTO, int NROWS>
+template <bool MIX, bool AUTO, int NROWS, bool RENDER>
 __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel& row, int b, int y, int tix, int nthr, int seg,
                                                 bool active, float4* __restrict__ col, int2* __restrict__ shift,
                                                 float* __restrict__ rgb_rec, float* __restrict__ ph_map,
@@ -192,12 +210,17 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
     }
   }
   FwdAcc acc[2];
+  RenderState rs[2];
   FsTaps<NROWS> g[D + 1];
   int pn = 0;
   auto prefetch = [&](FsTaps<NROWS>& grp) {
     const int n = min(pn, N - 1);   // past the end: re-load the last plane (unused) — unconditional issue keeps the wait counts right
     const int k = __builtin_amdgcn_readfirstlane(shift[n].y) >> 1;
     fs_issue<MIX, NROWS>(grp, a, r, n, (unsigned)(xt0 + k) << 2, HW);
+    if (RENDER) {   // unshifted, coalesced: read where the pixels are, not where they sample (the last plane has none: alpha = 1)
+      const float2 d2 = *reinterpret_cast<const float2*>(a.dists + ((long)r.b * (N - 1) + min(n, N - 2)) * HW + pix);
+      grp.dist[0] = d2.x; grp.dist[1] = d2.y;
+    }
     ++pn;
   };
   auto step = [&](const FsTaps<NROWS>& grp, int n) {
@@ -211,10 +234,14 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
     // check (offset + 4 wraps to 0).  Loads that start at column <= -4 are dropped cleanly, those at >= 0 are exact.
     const bool general = (kk & 1) || (c0 < 0 && c0 + 2 * (kWave - 1) >= -3);
     if (general) {
-      fs_general_plane<MIX, NROWS, AUTO>(a, r, col, n, sd, xt0f, HW, Wm1, rcpWm1, t, ea, automask, acc);
+      fs_general_plane<MIX, NROWS, RENDER>(a, r, col, n, sd, xt0f, HW, Wm1, rcpWm1, t, ea, automask, acc, rs, grp.dist);
       return;
     }
+#if PD_FS_ABL & 1   // timing only (wrong colours): cells at a 16-byte lane stride — what the reads cost without the 2-way bank conflict
+    const int cell = min(max((xt0 >> 1) + k, -kFsGuard), W + 1) + kFsGuard;
+#else
     const int cell = min(max(xt0 + k, -kFsGuard), W + 1) + kFsGuard;
+#endif
     const float4 cv0 = col[cell], cv1 = col[cell + 1], cv2 = col[cell + 2];
     const float kf = (float)k;
 #pragma unroll
@@ -234,7 +261,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
       }
       const float4 ca = (i == 0) ? cv0 : cv1, cb = (i == 0) ? cv1 : cv2;
       const float c0v = ca.x * w0 + cb.x * w1, c1v = ca.y * w0 + cb.y * w1, c2v = ca.z * w0 + cb.z * w1;
-      fwd_accumulate<MIX>(acc[i], l, s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask);
+      fs_accumulate<MIX, RENDER>(acc[i], rs[i], l, s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask, grp.dist[i], n == N - 1);
     }
   };
 #pragma unroll
@@ -256,8 +283,8 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   }
   if (!live) return 0.0f;
   // ---- finish the two pixels: outputs + the backward's stash, 8-byte stores -------------------------------------------
-  const FwdResult r0 = fwd_finish<MIX>(acc[0], t[0], t[2], t[4], ea[0], automask);
-  const FwdResult r1 = fwd_finish<MIX>(acc[1], t[1], t[3], t[5], ea[1], automask);
+  const FwdResult r0 = fwd_finish<MIX>(acc[0], t[0], t[2], t[4], ea[0], automask, !RENDER);   // (compositing weights are used as they are)
+  const FwdResult r1 = fwd_finish<MIX>(acc[1], t[1], t[3], t[5], ea[1], automask, !RENDER);
   float* st = stash + (long)r.b * a.stash_k * HW + pix;
   *reinterpret_cast<float2*>(st) = make_float2(r0.lse2, r1.lse2);
   *reinterpret_cast<float2*>(st + HW) = make_float2(r0.Sn, r1.Sn);
@@ -271,8 +298,8 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   return r0.ph + r1.ph;
 }
 
-template <bool MIX, bool AUTO>
-__global__ __launch_bounds__(kFsThreadsMax, (MIX && AUTO) ? PD_FS_OCC - 1 : PD_FS_OCC) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+template <bool MIX, bool AUTO, bool RENDER>
+__global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OCC - 1 : PD_FS_OCC) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                             float* __restrict__ ph_map,
                                                                             float* __restrict__ stash, int rows) {
   extern __shared__ float4 lds4[];
@@ -291,8 +318,8 @@ __global__ __launch_bounds__(kFsThreadsMax, (MIX && AUTO) ? PD_FS_OCC - 1 : PD_F
   const RowSel row = two_row_form(make_row_sel(active ? y : 0, a.H), a.fast_rows != 0);
   const int tix = threadIdx.x - slot * nseg * kWave, nthr = nseg * kWave;
   float ph_sum;
-  if (row.nrows == 2) ph_sum = fwdstream_body<MIX, AUTO, 2>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
-  else                ph_sum = fwdstream_body<MIX, AUTO, 1>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
+  if (row.nrows == 2) ph_sum = fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
+  else                ph_sum = fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
   if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup
     const float v = wave_sum_hi(ph_sum);
     if ((threadIdx.x & (kWave - 1)) == kWave - 1) parts[wave] = v;
@@ -320,7 +347,8 @@ static size_t fwdstream_lds_bytes(const pd_sweep_desc* d) {
 }
 
 bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
-  if (!rowshift_applicable(d) || (d->flags & PD_RENDER_PROB) || a.has_mask || !switches().fwd_stream) return false;
+  if (!rowshift_applicable(d) || a.has_mask || !switches().fwd_stream) return false;
+  if ((d->flags & PD_RENDER_PROB) && (((long)d->H * d->W) % 2 != 0 || (reinterpret_cast<uintptr_t>(a.dists) & 7))) return false;
   // pixel pairs: even width, 8-byte aligned rows of the per-pixel tensors (their bases come 8-byte aligned from any allocator
   // that hands out float2-aligned memory; checked because the boundary takes raw pointers)
   if (d->W % 2 != 0 || ceil_div(d->W, kFsSeg) > kFsThreadsMax / kWave) return false;
@@ -334,13 +362,16 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
   const int rows = fwdstream_rows(d);
   const dim3 grid(ceil_div(d->H, rows), d->B), block(ceil_div(d->W, kFsSeg) * rows * kWave);
   const size_t shmem = fwdstream_lds_bytes(d);
-  const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0;
-  if (mix) {
-    if (am) fwdstream_kernel<true, true><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
-    else    fwdstream_kernel<true, false><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
+  const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
+#define PD_FS_LAUNCH(M, A, R) fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows)
+  if (render) {
+    if (mix) { if (am) PD_FS_LAUNCH(true, true, true); else PD_FS_LAUNCH(true, false, true); }
+    else PD_FS_LAUNCH(false, false, true);
   } else {
-    fwdstream_kernel<false, false><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows);
+    if (mix) { if (am) PD_FS_LAUNCH(true, true, false); else PD_FS_LAUNCH(true, false, false); }
+    else PD_FS_LAUNCH(false, false, false);
   }
+#undef PD_FS_LAUNCH
   return check_launch("fwdstream_kernel");
 }
 

@@ -2,7 +2,7 @@
 // a translation, layers.py:206-219) — the backward without atomics.
 //
 // The general backward (pd_plane_sweep.hip) scatters every sample's gradient into its four taps with atomics and is
-// bound by the L2's atomic unit (1.2 ms at 8x49x192x640, 0.42 ms of it without the scatter).  Here the
+// bound by the L2's atomic unit (NOTEBOOK.md 3.4.6: 1.2 ms at 8x49x192x640, 0.42 ms of it without the scatter).  Here the
 // adjoint of the bilinear gather is turned round, as in the plane-uniform kernels (pd_plane_sweep_uniform.hip), but per
 // plane:
 //   pass 1 = sweep_bwd_kernel<.., TOSCRATCH> (pd_plane_sweep.hip): the target-anchored closed-form gradients, written

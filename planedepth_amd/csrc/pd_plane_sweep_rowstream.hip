@@ -24,7 +24,7 @@
 // header): planes with frac(s*d) closer than kIrrTol(W) to an integer ("irregular", decided when the shifts are
 // staged) take a general per-lane path instead — exact floor(ix) per target, gradient rows zero-filled up front,
 // contributions added with atomics (two addends per slot: the order cannot change the sum).  For every other plane
-// the premise holds with a margin of 2.4-3x the worst-case rounding error of the chain (bound in DESIGN.md 3.6.3).
+// the premise holds with a margin of 2.4-3x the worst-case rounding error of the chain (bound in NOTEBOOK.md 3.6.3).
 // Targets whose left tap is column -1 (negative shifts) have no slot: a short epilogue serves them (lanes = planes).
 //
 // Vertical: rows whose y round trip is inexact blend two source rows (weights 1-eps, eps); values and per-pixel
@@ -157,7 +157,8 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
   const float xs0f = (float)(seg * kSeg) + lane2f;
   const float xt0f = xs0f - (float)k;   // integers below 2^24: exact
   // context of the two paired targets xt, xt+1: adjacent cells (guard cells two deep on both sides keep them adjacent)
-  const int cell = min(max(xs0 - k, -2), a.W) + 2;
+  // (PD_STREAM_ABL & 32, timing only: cells at a 16-byte lane stride — the context reads without their 2-way bank conflict)
+  const int cell = (kStreamAbl & 32) ? min(max((xs0 >> 1) - k, -2), a.W) + 2 : min(max(xs0 - k, -2), a.W) + 2;
   const float4 cv0 = col_at<PK>(L, xs0 + 2), cv1 = col_at<PK>(L, xs0 + 3), cv2 = col_at<PK>(L, xs0 + 4);
   float cl0[kSlots], cl1[kSlots], cs0[kSlots], cs1[kSlots];
 #pragma unroll
@@ -215,7 +216,7 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
 // floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
 // Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
 template <bool MIX, int NROWS, bool PK>
-__device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs + scratch — measured)
+__device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs + scratch — measured, NOTEBOOK.md 3.6.4)
     const SweepArgs& a, const BwdOut& o, const StreamRow& r,
                                                      const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
                                                      float Wm1, float rcpWm1) {

@@ -344,7 +344,7 @@ __device__ __forceinline__ void stage_row_constants(const SweepArgs& a, int b, c
 // frac(s*d) closer than this to an integer: the plane takes the general path.  Worst-case error of the coordinate
 // chain against exact arithmetic: fl(x + sd) <= ulp(2W)/2, the division, the two additions and the product by W-1
 // each <= ulp(.)/2 scaled by W-1 — 5.4e-7 * W in total (3.1e-4 at W = 640); the threshold keeps a factor of 2.4-3
-// up to W = 4096.
+// up to W = 4096 (NOTEBOOK.md 3.6.3).
 __device__ __forceinline__ float irregular_tol(int W) { return 2.5e-4f + 1.25e-6f * (float)W; }
 
 // ix of the reference for target column xtf (an integer-valued float) under the shift sd: make_col_tap's chain

@@ -78,7 +78,7 @@ __device__ __forceinline__ SsimCoef ssim_coef(const SsimStats& s, float g) {
 // One workgroup owns a 32x8 tile of one image plane.  The per-centre coefficients are computed ONCE per centre (tile +
 // 1 ring, from an LDS copy of the inputs with a 2-ring halo filled through the reflection) and then gathered by the
 // pixels — instead of every pixel recomputing the window statistics and coefficients of its nine centres from global
-// memory (162 loads and two divisions x 9 per pixel: 141 us for 8x3x192x640; this form: see DESIGN.md §3.3).
+// memory (162 loads and two divisions x 9 per pixel: 141 us for 8x3x192x640; this form: see NOTEBOOK.md §3.3).
 constexpr int kTileW = 32, kTileH = 8;
 static_assert(kTileW * kTileH == kBlock, "one thread per tile pixel");
 constexpr int kInW = kTileW + 4, kInH = kTileH + 4;     // inputs: 2-ring halo

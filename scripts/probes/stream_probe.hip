@@ -413,6 +413,12 @@ int main(int argc, char** argv) {
     runf<2, 40, 8, 4>(B, N, H, 512); runf<2, 40, 4, 4, 2>(B, N, H, 512); runf<2, 40, 8, 4, 2>(B, N, H, 512); runf<2, 40, 2, 4, 4>(B, N, H, 512);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'F') {   // calibration of FETCH_SIZE on the segment-stream FORWARD's access shape (round 4): one wave per
+    // 128-pixel segment, 12-byte loads at 4-byte alignment (xt + k), all planes; known bytes printed below
+    runr<2, 0, 4, 1>(B, N, H, W);
+    printf("known bytes per launch: tap loads %.0f, colour staging + target loads %.0f, stores %.0f\n", 2.0 * n * 4, 6.0 * B * H * W * 4, 8.0 * B * H * W * 4);
+    return 0;
+  }
   if (argc > 1) {   // calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (scripts/gpu_r3_profile.sh): the row-stream
     // backward's access shape (12-byte aligned loads, 8-byte aligned stores), loads alone and loads + stores
     run<2, 2, 0, 1>(B, N, H, W); run<2, 2, 0, 3>(B, N, H, W);

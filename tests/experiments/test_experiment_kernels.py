@@ -90,7 +90,7 @@ def test_rowquad_kernels_equal_rowshift_kernels(W, H, N, side, kw, mix, automask
     kw = dict(kw)
     kw.setdefault("disp_min", 0.5)
     kw.setdefault("disp_max", 9.0)
-    monkeypatch.setenv("PD_QUAD_FWD", "1")     # the wide-access kernels are opt-in
+    monkeypatch.setenv("PD_QUAD_FWD", "1")     # the wide-access kernels are opt-in (NOTEBOOK.md 3.5)
     if quad_bwd:
         monkeypatch.setenv("PD_QUAD_BWD", "1")
     else:

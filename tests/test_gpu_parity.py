@@ -270,7 +270,7 @@ def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, m
     _compare(new, {"g_disp_pp": want["g_disp_pp"]}, tag="rowstream/W%d" % W, tol=2e-4)
 
 
-@pytest.mark.parametrize("B,N,H,W,sign,mix,automask,rows", [
+_FS_CASES = [
     (8, 49, 24, 640, 1.0, True, False, False),    # the headline row shape: five segments
     (3, 49, 192, 640, 1.0, True, True, False),    # every row of H = 192 (48 with two live source rows per image), B % 8 != 0
     (2, 12, 9, 640, -1.0, True, False, False),    # target "l": negative shifts (one segment per plane straddles column 0)
@@ -279,8 +279,13 @@ def test_rowstream_backward_equals_rowshift_backward_and_oracle(W, H, N, side, m
     (2, 7, 5, 130, -1.0, True, True, False),      # ragged, negative shifts, automask
     (2, 63, 21, 200, 1.0, True, True, True),      # per-row disparities (xz planes), PD_DISP_ROWS
     (2, 49, 48, 1280, 1.0, True, False, False),   # wide rows: ten waves per workgroup
-])
-def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign, mix, automask, rows):
+]
+
+
+# (alpha compositing, PD_RENDER_PROB: the shapes up to 24 x 640 cover it)
+@pytest.mark.parametrize("B,N,H,W,sign,mix,automask,rows,render", [c + (False,) for c in _FS_CASES] +
+                         [c + (True,) for c in _FS_CASES if c[2] * c[3] <= 24 * 640])
+def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign, mix, automask, rows, render):
     """The segment-stream forward (pd_plane_sweep_fwdstream.hip: a wave per 128-pixel segment, two pixels per lane, 12-byte
     tap loads, one plane per iteration) against the plane-group row-shift forward (PD_IMPL_ROWS1) through the C ABI: rgb_rec,
     ph_map and the backward's stash agree to a few ulp (same expressions; the planes of a pixel are summed by one wave
@@ -296,7 +301,8 @@ def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign,
     sigma = (torch.rand(B, N, H, W, generator=g) * 1.2).to(dev)
     disp = (300.0 * (2.0 / 300.0) ** ((torch.arange(N, dtype=torch.float32)[None] + torch.rand(B, N, generator=g) - 0.5) / max(N - 1, 1)))
     disp = disp * (W / 640.0)
-    flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if automask else 0)
+    flags = (C.PD_MIXTURE if mix else 0) | (C.PD_AUTOMASK if automask else 0) | (C.PD_RENDER_PROB if render else 0)
+    dists = (torch.rand(B, N - 1, H, W, generator=g) * 2.0).to(dev) if render else None   # (trainer.py:587; a decoder output)
     if rows:
         gain = torch.linspace(0.2, 1.6, H)[None, None, :]
         plane = (disp[:, :, None] * gain).contiguous().to(dev)   # [B,N,H]
@@ -315,7 +321,7 @@ def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign,
             stash = torch.full((B, k, H, W), float("nan"), device=dev)
             phm = torch.full((1,), float("nan"), device=dev)
             C.check(lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma if mix else None),
-                                           C.ptr(plane), None, None, None, None, C.ptr(rgb), C.ptr(ph), C.ptr(phm), C.ptr(stash), st), "fwd")
+                                           C.ptr(plane), None, None, None, C.ptr(dists), C.ptr(rgb), C.ptr(ph), C.ptr(phm), C.ptr(stash), st), "fwd")
             torch.cuda.synchronize()
             res.append((rgb.cpu(), ph.cpu(), stash[:, :4].cpu(), phm.cpu()))
         for a_, b_ in zip(res[0][:3], res[1][:3]):
@@ -1156,7 +1162,7 @@ def test_render_probability_on_the_homography_shortcuts(view, mix):
             res[fast]["g_distance"] = dd.grad.cpu()
     f, s_ = res[True], res[False]
     assert float(s_["g_dists"].abs().max()) > 0 and float(s_["g_logits"].abs().max()) > 0
-    tol = 3e-6 if view == "pose_net" else 2e-4    # same coordinates / the row kernels' own coordinate chain
+    tol = 3e-6 if view == "pose_net" else 2e-4    # same coordinates / the row kernels' own coordinate chain (NOTEBOOK 3.5.2)
     for k in f:
         # g_distance of the stereo view: a bilinear DERIVATIVE through two different fp32 coordinate chains (the accuracy of
         # either against fp64 is what test_stereo_homography_as_row_shifts bounds)
@@ -1952,7 +1958,7 @@ def test_randomised_shapes_homography_shortcuts_vs_general():
             if float(b_.abs().max()) == 0.0:
                 assert float(a_.abs().max()) < 1e-6, (tag, k)
                 continue
-            # the stereo view's row kernels follow their own (the reference's disp_warp) coordinate chain: 2e-4
+            # the stereo view's row kernels follow their own (the reference's disp_warp) coordinate chain: 2e-4 (NOTEBOOK 3.5.2)
             tol = 2e-4 if "stereo" in views else 5e-6
             assert rel_err(a_, b_) < tol, (tag, k, rel_err(a_, b_))
 
