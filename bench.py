@@ -372,7 +372,17 @@ def next_rows_times(args, device, iters=100):
             torch.cuda.synchronize(device)
             return "graph capture failed: %s" % type(e).__name__
 
+    raw_lp = raw_l.detach()[:, :N - 1].contiguous().requires_grad_(True)     # PladeNet's conv0: N - 1 logit channels
+    gt = mk(B, N - 1, H, W)
+
+    def plade_fwd_bwd():   # PladeNet's tail with --render_probability (plade_net.py:309-341): the producer of outputs["dists"]
+        dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+        logits, dists, sigma, disp, depth, _ = ops.plade_tail(raw_lp, raw_s, dl)
+        torch.autograd.backward([logits, dists, sigma, disp], [gl, gt, gs, gd])
+        raw_lp.grad = raw_s.grad = lv.grad = None
+
     t_f, t_fb, t_s, t_p = timed(tail_fwd), timed(tail_fwd_bwd), timed(smooth_fwd_bwd), timed(post)
+    t_pl = timed(plade_fwd_bwd)
     t_r = timed(reproj_fwd_bwd)
     g_s, g_r = timed_graph(smooth_fwd_bwd), timed_graph(reproj_fwd_bwd)
     hw4 = H * W * 4
@@ -383,6 +393,9 @@ def next_rows_times(args, device, iters=100):
                          "fwd_GBs": round(tail_f_bytes / (t_f * 1e-3) / 1e9, 1),
                          "fwd_bwd_GBs": round((tail_f_bytes + tail_b_bytes) / (t_fb * 1e-3) / 1e9, 1),
                          "shape": [B, N, H, W]},
+        # fwd reads 2N-1, writes 3N-1 (+3) planes; bwd reads 2N-1 + 3N-1 (+5), writes 2N-1
+        "plade_tail_render": {"fwd_bwd_ms": round(t_pl, 4),
+                              "fwd_bwd_GBs": round((12 * N - 4 + 8) * hw4 * B / (t_pl * 1e-3) / 1e9, 1), "shape": [B, N, H, W]},
         "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "fwd_bwd_device_ms": g_s, "shape": [B, 1, H, W - x0]},
         "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "fwd_bwd_device_ms": g_r, "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),

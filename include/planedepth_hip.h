@@ -246,6 +246,33 @@ int pd_decoder_tail_bwd(int B, int N, int H, int W, int flags, const float* raw_
                         pd_stream_t stream);
 
 /*
+ * Fused tail of PladeNet.forward with --render_probability (networks/plade_net.py:309-341; the live producer of
+ * outputs["dists"], which the sweep's PD_RENDER_PROB branch consumes, trainer.py:584-591):
+ *   depth_layered = 0.1 * 0.58 * W / disp_layered; dists_n = (depth_layered_{n+1} - depth_layered_n) * ray_norm;
+ *   alpha_n = 1 - exp(-relu(raw_logits_n) * dists_n) (n < N-1), alpha_{N-1} = 1; pi_n = alpha_n prod_{m<n}(1 - alpha_m + 1e-10);
+ *   logits = cat(raw_logits, ones); sigma = clamp(sigmoid(raw_sigma), .01, 1);
+ *   probability = (pi / sigma) / sum_N (mixture) or pi; disp = sum_N probability * disp_layered; depth = 0.1 * 0.58 * W / disp.
+ * raw_logits [B,N-1,H,W] (conv0's output), raw_sigma [B,N,H,W] (conv_sigma's, mixture only); disp_layered [B,N], or [B,N,H,W]
+ * with PD_TAIL_DISP_DENSE; ray_norm [H,W] = |K^-1 [x, y, 1]| of layers.py:468-492 (create_camera_plane).  fwd writes logits
+ * [B,N,H,W], dists [B,N-1,H,W], sigma (mixture), disp, depth [B,1,H,W] and a stash [B,1,H,W] {sum pi/sigma};
+ * pd_plade_tail_layers writes pi / probability on demand.  bwd: upstream g_logits [B,N,H,W] (its last channel is the constant
+ * ones plane), g_dists [B,N-1,H,W], g_sigma [B,N,H,W], g_disp, g_depth (each may be NULL = zero) -> g_raw_logits [B,N-1,H,W],
+ * g_raw_sigma, g_disp_layered (layout of disp_layered; the [B,N] form needs `workspace` of
+ * pd_decoder_tail_bwd_workspace_floats floats); outputs that are NULL are skipped.
+ */
+int pd_plade_tail_fwd(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                      const float* disp_layered, const float* ray_norm, float* logits, float* dists, float* sigma, float* disp,
+                      float* depth, float* stash, pd_stream_t stream);
+int pd_plade_tail_layers(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                         const float* disp_layered, const float* ray_norm, const float* stash, float* pi, float* probability,
+                         pd_stream_t stream);
+int pd_plade_tail_bwd(int B, int N, int H, int W, int flags, const float* raw_logits, const float* raw_sigma,
+                      const float* disp_layered, const float* ray_norm, const float* stash, const float* disp,
+                      const float* g_logits, const float* g_dists, const float* g_sigma, const float* g_disp,
+                      const float* g_depth, float* g_raw_logits, float* g_raw_sigma, float* g_disp_layered, float* workspace,
+                      pd_stream_t stream);
+
+/*
  * get_smooth_loss_disp (layers.py:243-256; trainer.py:768):
  *   out[0] = mean_x |d(x)-d(x+1)| exp(-gamma mean_c|I(x)-I(x+1)|) + the same along y.
  * disp [B,1,H,W], img [B,C,H,W]; both may be crops of wider tensors: unit column stride, the other strides (in floats)

@@ -350,6 +350,44 @@ def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, width, use_m
     return out
 
 
+def camera_ray_norm(height, width, dtype=torch.float32):
+    """layers.py:468-492 (create_camera_plane) followed by the norm PladeNet takes of it (plade_net.py:315): length of the
+    camera ray K^-1 [x, y, 1] of every pixel for the KITTI-shaped intrinsics; [1, H, W].  The reference inverts K with
+    torch.inverse in fp32; so does this (dtype = float32), and in float64 for the fp64 evaluation."""
+    K = torch.tensor([[0.58 * width, 0, 0.5 * width], [0, 1.92 * height, 0.5 * height], [0, 0, 1]], dtype=torch.float32).to(dtype)
+    K_inv = torch.inverse(K)
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=dtype), torch.arange(width, dtype=dtype), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(height * width, dtype=dtype)], 0)
+    cam = torch.matmul(K_inv, pix).reshape(1, 3, height, width)
+    return torch.linalg.norm(cam, dim=1)
+
+
+def plade_tail(raw_logits, raw_sigma, disp_layered, width, ray_norm, use_mixture_loss=True):
+    """networks/plade_net.py:309-341 with --render_probability: what PladeNet.forward does with the outputs of ``conv0``
+    (N-1 logit channels) and ``conv_sigma``.  ``ray_norm`` = camera_ray_norm(H, W).  Returns the dict entries it writes."""
+    out = {}
+    depth_layered = 0.1 * 0.58 * width / disp_layered                                   # :311
+    dists = depth_layered[:, 1:] - depth_layered[:, :-1]                                # :312
+    dists = dists * ray_norm[:, None]                                                   # :314-315
+    out["dists"] = dists
+    alpha = 1.0 - torch.exp(-torch.relu(raw_logits) * dists)                            # :317
+    ones = torch.ones_like(alpha[:, :1])
+    alpha = torch.cat([alpha, ones], 1)                                                 # :318-319
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], 1), 1)[:, :-1]
+    probability = alpha * trans                                                         # :320
+    out["probability"] = probability
+    out["logits"] = torch.cat([raw_logits, ones], 1)                                    # :322
+    if use_mixture_loss:
+        sigma = torch.clamp(torch.sigmoid(raw_sigma), 0.01, 1.0)                        # :327-328
+        out["sigma"] = sigma
+        out["pi"] = pi = probability                                                    # :330
+        weights = pi / sigma                                                            # :331
+        out["probability"] = weights / weights.sum(1, True)                             # :332-333
+    out["disp"] = (out["probability"] * disp_layered).sum(1, True)                      # :338
+    out["depth"] = 0.1 * 0.58 * width / out["disp"]                                     # :340
+    return out
+
+
 def post_process_disp(logits, probability, disp, disp_layered):
     """trainer.py:421-466: the occlusion-aware blend of the prediction for the image and for its mirror image.  The
     arguments are the fixed model's outputs for the batch cat([image, flipped image]) (2B leading entries)."""

@@ -58,6 +58,9 @@ SIGNATURES = {
     "pd_decoder_tail_fwd": (_I, [_I] * 5 + [_P] * 10),
     "pd_decoder_tail_layers": (_I, [_I] * 5 + [_P] * 7),
     "pd_decoder_tail_bwd": (_I, [_I] * 5 + [_P] * 15),
+    "pd_plade_tail_fwd": (_I, [_I] * 5 + [_P] * 11),
+    "pd_plade_tail_layers": (_I, [_I] * 5 + [_P] * 8),
+    "pd_plade_tail_bwd": (_I, [_I] * 5 + [_P] * 16),
     "pd_smooth_loss_fwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P]),
     "pd_smooth_loss_bwd": (_I, [_I] * 4 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),
     "pd_smooth_loss_bwd_padded": (_I, [_I] * 5 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),

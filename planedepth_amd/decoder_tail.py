@@ -15,7 +15,13 @@ a maintainer replaces lines 256-291 of ``depth_decoder.py`` with::
                        self.convs["sigmaconv"](x) if self.use_mixture_loss else None,
                        use_mixture_loss=self.use_mixture_loss, all_ones_mask=(self.xz_levels + self.yz_levels == 0))
 
-``--render_probability`` keeps the reference's own code (alpha compositing has no fused tail here).
+``DepthDecoder`` with ``--render_probability`` keeps the reference's own code (its compositing branch raises on its own: the
+padding mask has N channels, ``dispconv`` N-1).  The live producer of ``outputs["dists"]`` is ``PladeNet``
+(networks/plade_net.py:309-341), whose tail ``fused_plade_tail`` replaces the same way: lines 309-340 become::
+
+    from planedepth_amd.decoder_tail import fused_plade_tail
+    fused_plade_tail(self.outputs, self.conv0(dlog), self.conv_sigma(features) if self.use_mixture_loss else None,
+                     use_mixture_loss=self.use_mixture_loss)
 """
 import torch
 
@@ -83,6 +89,34 @@ def fused_decoder_tail(outputs, dispconv_out, sigmaconv_out=None, *, use_mixture
             outputs["pi"] = pi
     else:
         dev, dt = dispconv_out.device, dispconv_out.dtype
+        outputs["probability"] = LazyLayers(shape, lambda: layers(False, True)[1], dev, dt)
+        if use_mixture_loss:
+            outputs["pi"] = LazyLayers(shape, lambda: layers(True, False)[0], dev, dt)
+    outputs["disp"] = disp
+    outputs["depth"] = depth
+    return outputs
+
+
+def fused_plade_tail(outputs, conv0_out, conv_sigma_out=None, *, use_mixture_loss=True, materialize_layers=False):
+    """Fills ``outputs`` with "logits", "dists", "sigma", "pi", "probability", "disp", "depth" as plade_net.py:309-340 does
+    with ``render_probability`` (alpha compositing of the N-1 logit channels of ``conv0`` against the distances between the
+    depth layers).  Reads ``outputs["disp_layered"]`` (per-plane levels with the learnt residual, or the dense map with
+    ground planes)."""
+    B, Nm1, H, W = conv0_out.shape
+    logits, dists, sigma, disp, depth, layers = ops.plade_tail(conv0_out, conv_sigma_out, outputs["disp_layered"],
+                                                                use_mixture_loss=use_mixture_loss)
+    outputs["logits"] = logits
+    outputs["dists"] = dists
+    if use_mixture_loss:
+        outputs["sigma"] = sigma
+    shape = (B, Nm1 + 1, H, W)
+    if materialize_layers:
+        pi, prob = layers(want_pi=use_mixture_loss, want_probability=True)
+        outputs["probability"] = prob
+        if use_mixture_loss:
+            outputs["pi"] = pi
+    else:
+        dev, dt = conv0_out.device, conv0_out.dtype
         outputs["probability"] = LazyLayers(shape, lambda: layers(False, True)[1], dev, dt)
         if use_mixture_loss:
             outputs["pi"] = LazyLayers(shape, lambda: layers(True, False)[0], dev, dt)

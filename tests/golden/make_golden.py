@@ -196,6 +196,57 @@ def decoder_tail_vectors(ref):
     return out
 
 
+def plade_tail_vectors(ref):
+    """The reference PladeNet's own tail (networks/plade_net.py:277-341) with --render_probability: forward hooks replace
+    what conv0 (the N-1 logit channels) and conv_sigma return by seeded leaf tensors, everything after them — plane levels
+    with the learnt residual, depth-layer distances scaled by the camera rays, alpha compositing, mixture weights, disp,
+    depth — is the reference's code.  The backbone runs on a seeded image but its output is discarded by the hooks."""
+    out = {}
+    g = torch.Generator().manual_seed(777)
+    H, W, B = 32, 64, 1
+    for tag, kw in (("mix_xy", dict(no_levels=6, xz_levels=0, use_mixture_loss=True, plane_residual=True)),
+                    ("mix_xz", dict(no_levels=4, xz_levels=3, use_mixture_loss=True, plane_residual=True)),
+                    ("l1_xy", dict(no_levels=5, xz_levels=0, use_mixture_loss=False, plane_residual=False))):
+        torch.manual_seed(23)
+        net = ref.networks.PladeNet(False, kw["no_levels"], 2.0, 300.0 * W / 640.0, xz_levels=kw["xz_levels"],
+                                    use_mixture_loss=kw["use_mixture_loss"], render_probability=True,
+                                    plane_residual=kw["plane_residual"])
+        N = kw["no_levels"] + kw["xz_levels"]
+        raw_logits = (torch.randn(B, N - 1, H, W, generator=g) * 1.5).requires_grad_(True)   # relu(): about half are inactive
+        raw_sigma = (torch.randn(B, N, H, W, generator=g) * 3.5 - 1.0).requires_grad_(True)  # both clamp bounds are hit
+        net.conv0.register_forward_hook(lambda m, i, o: raw_logits)
+        if kw["use_mixture_loss"]:
+            net.conv_sigma.register_forward_hook(lambda m, i, o: raw_sigma)
+        image = torch.rand(B, 3, H, W, generator=g)
+        ys = torch.linspace(0.3, 1, H)[None, None, :, None].expand(B, 1, H, W)   # below the horizon: ground planes in front
+        xs = torch.linspace(-1, 1, W)[None, None, None, :].expand(B, 1, H, W)
+        grid = torch.cat([xs, ys], 1).contiguous()
+        o = net(image, grid)
+        if o["disp_layered"].requires_grad:
+            o["disp_layered"].retain_grad()
+        gw_l = torch.randn(B, N, H, W, generator=g)
+        gw_t = torch.randn(B, N - 1, H, W, generator=g) * 0.05
+        gw_s = torch.randn(B, N, H, W, generator=g)
+        gw_d = torch.randn(B, 1, H, W, generator=g)
+        gw_z = torch.randn(B, 1, H, W, generator=g) * 0.1
+        obj = (o["logits"] * gw_l).sum() + (o["dists"] * gw_t).sum() + (o["disp"] * gw_d).sum() + (o["depth"] * gw_z).sum()
+        if kw["use_mixture_loss"]:
+            obj = obj + (o["sigma"] * gw_s).sum()
+        obj.backward()
+        blob = dict(raw_logits=raw_logits, raw_sigma=raw_sigma, disp_layered=o["disp_layered"], logits=o["logits"],
+                    dists=o["dists"], probability=o["probability"], disp=o["disp"], depth=o["depth"],
+                    gw_logits=gw_l, gw_dists=gw_t, gw_sigma=gw_s, gw_disp=gw_d, gw_depth=gw_z,
+                    g_raw_logits=raw_logits.grad, ray_norm=torch.linalg.norm(ref.layers.create_camera_plane(H, W), dim=1))
+        if o["disp_layered"].grad is not None:
+            blob.update(g_disp_layered=o["disp_layered"].grad)
+        if kw["use_mixture_loss"]:
+            blob.update(sigma=o["sigma"], pi=o["pi"], g_raw_sigma=raw_sigma.grad)
+        out.update({"%s/%s" % (tag, k): v.detach().numpy() for k, v in blob.items()})
+        out["%s/mixture" % tag] = np.asarray(int(kw["use_mixture_loss"]))
+        print("plade_tail %-8s disp mean %.5f" % (tag, float(o["disp"].detach().mean())))
+    return out
+
+
 def post_process_vectors(ref):
     """Trainer.generate_post_process_disp (trainer.py:404-466) with the fixed networks replaced by a stub that returns
     prescribed decoder outputs for the batch cat([image, mirrored image])."""
@@ -387,6 +438,7 @@ def main():
         print("%-24s ph=%.8f sum_rgb=%.6f" % (name, float(res["ph_loss"]), float(res["rgb_rec"].sum())))
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "decoder_tail.npz"), **decoder_tail_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "plade_tail.npz"), **plade_tail_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "post_process.npz"), **post_process_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **pipeline_vectors(ref))

@@ -39,7 +39,15 @@ def _install_stand_ins():
         resnet = _module("torchvision.models.resnet", ResNet=_ResNet,
                          BasicBlock=object, Bottleneck=object)
         models = _module("torchvision.models", resnet=resnet, ResNet=_ResNet)
-        transforms = _module("torchvision.transforms")
+        class _Normalize(nn.Module):  # PladeNet normalises its input image (plade_net.py:248); the backbone's output is
+            def __init__(self, mean, std):  # replaced by hooks in the golden generator, so only the call has to exist
+                super().__init__()
+                self.mean, self.std = torch.tensor(mean)[None, :, None, None], torch.tensor(std)[None, :, None, None]
+
+            def forward(self, x):
+                return (x - self.mean) / self.std
+
+        transforms = _module("torchvision.transforms", Normalize=_Normalize)
         _module("torchvision", models=models, transforms=transforms)
     if "torch._six" not in sys.modules:
         _module("torch._six", string_classes=(str, bytes))

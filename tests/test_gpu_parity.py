@@ -701,6 +701,135 @@ def test_decoder_tail_against_reference_vectors(tag):
         assert rel_err(dl.grad.cpu(), z["g_disp_layered"]) < TOL, rel_err(dl.grad.cpu(), z["g_disp_layered"])
 
 
+@pytest.mark.parametrize("tag", ["mix_xy", "mix_xz", "l1_xy"])
+def test_plade_tail_against_reference_vectors(tag):
+    """HIP PladeNet tail with --render_probability (forward, lazily materialised pi / probability, backward) against what
+    the reference PladeNet produced from the same conv outputs (tests/golden/plade_tail.npz, make_golden.plade_tail_vectors:
+    networks/plade_net.py:309-341 run by the reference itself).  mix_xz: ground planes behind the frontal ones — the depth
+    layers are not sorted there, distances go negative and the reference's compositing weights leave [0, 1] by orders of
+    magnitude; the kernels follow the same arithmetic, so the vectors still have to match."""
+    from planedepth_amd.decoder_tail import fused_plade_tail
+    raw = np.load(os.path.join(GOLDEN, "plade_tail.npz"))
+    z = {k.split("/", 1)[1]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(tag + "/")}
+    mix = bool(int(z["mixture"]))
+    dev = "cuda"
+    rl = z["raw_logits"].to(dev).requires_grad_(True)
+    rs = z["raw_sigma"].to(dev).requires_grad_(True)
+    dl = z["disp_layered"].to(dev).requires_grad_(True)
+    outputs = {"disp_layered": dl}
+    fused_plade_tail(outputs, rl, rs if mix else None, use_mixture_loss=mix)
+    B, N, H, W = z["disp_layered"].shape
+    assert tuple(outputs["probability"].shape) == (B, N, H, W) and tuple(outputs["logits"].shape) == (B, N, H, W)
+    for k in ("logits", "dists", "disp", "depth") + (("sigma",) if mix else ()):
+        assert rel_err(outputs[k].detach().cpu(), z[k]) < TOL, (tag, k, rel_err(outputs[k].detach().cpu(), z[k]))
+    assert rel_err(outputs["probability"].tensor().cpu(), z["probability"]) < TOL
+    if mix:
+        assert rel_err(outputs["pi"].tensor().cpu(), z["pi"]) < TOL
+    obj = (outputs["logits"] * z["gw_logits"].to(dev)).sum() + (outputs["dists"] * z["gw_dists"].to(dev)).sum() + \
+          (outputs["disp"] * z["gw_disp"].to(dev)).sum() + (outputs["depth"] * z["gw_depth"].to(dev)).sum()
+    if mix:
+        obj = obj + (outputs["sigma"] * z["gw_sigma"].to(dev)).sum()
+    obj.backward()
+    assert rel_err(rl.grad.cpu(), z["g_raw_logits"]) < TOL, rel_err(rl.grad.cpu(), z["g_raw_logits"])
+    if mix:
+        assert rel_err(rs.grad.cpu(), z["g_raw_sigma"]) < TOL, rel_err(rs.grad.cpu(), z["g_raw_sigma"])
+    if "g_disp_layered" in z:
+        assert rel_err(dl.grad.cpu(), z["g_disp_layered"]) < TOL, rel_err(dl.grad.cpu(), z["g_disp_layered"])
+
+
+@pytest.mark.parametrize("mix,shape", [(True, (2, 49, 24, 80)), (False, (3, 9, 17, 33)), (True, (1, 2, 5, 7))])
+def test_plade_tail_vs_oracle_per_plane_disparities(mix, shape):
+    """The PladeNet tail at other shapes (49 planes; H*W not a multiple of 4: one pixel per thread; the two-plane minimum)
+    with the network's per-plane levels as an expanded [B,N,1,1] view (the [B,N] disparity gradient goes through the
+    workspace reduction), against the oracle in fp32 and — gradients — three-way against its fp64 evaluation."""
+    from planedepth_amd.decoder_tail import fused_plade_tail
+    from oracle import planedepth_oracle as orc
+    B, N, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    rl0 = torch.randn(B, N - 1, H, W, generator=g) * 1.5
+    rs0 = torch.randn(B, N, H, W, generator=g) * 2.0
+    lv = torch.arange(N, dtype=torch.float32)[None, :, None, None] + torch.rand(B, N, 1, 1, generator=g) - 0.5
+    dl0 = 300.0 * (W / 640.0) * (2.0 / 300.0) ** (lv / max(N - 1, 1))      # plade_net.py:285, descending disparity = ascending depth
+    gws = [torch.randn(B, N, H, W, generator=g), torch.randn(B, N - 1, H, W, generator=g) * 0.05, torch.randn(B, N, H, W, generator=g),
+           torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g) * 0.1]
+
+    def run(device, dtype, fused):
+        rl, rs, d0 = (t.detach().clone().to(device=device, dtype=dtype).requires_grad_(True) for t in (rl0, rs0, dl0))
+        dl = d0.expand(-1, -1, H, W)
+        if fused:
+            o = {"disp_layered": dl}
+            fused_plade_tail(o, rl, rs if mix else None, use_mixture_loss=mix)
+        else:
+            o = orc.plade_tail(rl, rs if mix else None, dl, W, orc.camera_ray_norm(H, W, dtype), mix)
+        w = [t.to(device=device, dtype=dtype) for t in gws]
+        obj = (o["logits"] * w[0]).sum() + (o["dists"] * w[1]).sum() + (o["disp"] * w[3]).sum() + (o["depth"] * w[4]).sum()
+        if mix:
+            obj = obj + (o["sigma"] * w[2]).sum()
+        obj.backward()
+        res = {k: o[k].detach().cpu().float() for k in ("logits", "dists", "disp", "depth") + (("sigma",) if mix else ())}
+        res.update(g_raw_logits=rl.grad.cpu().float(), g_disp_pp=d0.grad.cpu().float())
+        if mix:
+            res["g_raw_sigma"] = rs.grad.cpu().float()
+        return res
+
+    got, want, exact = run("cuda", torch.float32, True), run("cpu", torch.float32, False), run("cpu", torch.float64, False)
+    for k in want:
+        if k.startswith("g_"):   # three-way: the fp32 oracle's own distance from fp64 is the yardstick for the gradients
+            e_got, e_ref = rel_err(got[k], exact[k]), rel_err(want[k], exact[k])
+            assert e_got <= 2.0 * e_ref + TOL, (k, e_got, e_ref)
+        else:
+            assert rel_err(got[k], want[k]) < TOL, (k, rel_err(got[k], want[k]))
+
+
+def test_plade_tail_feeds_the_compositing_sweep():
+    """PladeNet's fused tail as the producer of what the sweep's --render_probability branch consumes (trainer.py:584-591):
+    conv outputs -> fused_plade_tail -> pred_novel_images + compute_losses (alpha compositing over the warped logits with the
+    tail's `dists`) -> backward to the conv outputs and the plane levels, against the same chain through the oracle
+    (plade_tail -> warp_and_loss) in fp32, gradients three-way against its fp64 evaluation."""
+    import types
+    import planedepth_amd
+    from planedepth_amd.decoder_tail import fused_plade_tail
+    from oracle import planedepth_oracle as orc
+    B, N, H, W = 2, 9, 24, 80
+    g = torch.Generator().manual_seed(31)
+    rl0, rs0 = torch.randn(B, N - 1, H, W, generator=g) * 1.5, torch.randn(B, N, H, W, generator=g) * 0.8
+    lv = torch.arange(N, dtype=torch.float32)[None, :, None, None] + torch.rand(B, N, 1, 1, generator=g) - 0.5
+    d00 = 40.0 * (0.5 / 40.0) ** (lv / (N - 1))
+    cl, cr = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    gw = torch.randn(B, 3, H, W, generator=g) * 0.05
+
+    def run(device, dtype, fused):
+        rl, rs, d0 = (t.detach().clone().to(device=device, dtype=dtype).requires_grad_(True) for t in (rl0, rs0, d00))
+        dl = d0.expand(-1, -1, H, W)
+        a, b, w = (t.to(device=device, dtype=dtype) for t in (cl, cr, gw))
+        if fused:
+            outputs = {"disp_layered": dl, "padding_mask": None}
+            fused_plade_tail(outputs, rl, rs)
+            opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                        render_probability=True, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                        gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, xz_levels=0, yz_levels=0)
+            ns = types.SimpleNamespace(opt=opt, target_sides=["r"], perceptual_loss=lambda *x, **k: torch.zeros((), device=device))
+            planedepth_amd.pred_novel_images(ns, {("color", "l"): a, ("color", "r"): b}, outputs)
+            rgb, ph = outputs[("rgb_rec", "r")], outputs[("ph_mean", "r")]
+        else:
+            o = orc.plade_tail(rl, rs, dl, W, orc.camera_ray_norm(H, W, dtype), True)
+            r = orc.warp_and_loss(a, b, o["logits"], o["sigma"], warp_type="disp_warp", target_side="r", disp_layered=dl,
+                                  padding_mask=torch.ones_like(dl), distance=None, norm=None, T=None, K=None, inv_K=None,
+                                  use_mixture_loss=True, automask=False, render_probability=True, dists=o["dists"])
+            rgb, ph = r["rgb_rec"], r["ph_loss"]
+        (ph + (rgb * w).sum()).backward()
+        return dict(rgb_rec=rgb.detach().cpu().float(), ph_loss=ph.detach().cpu().float(), g_raw_logits=rl.grad.cpu().float(),
+                    g_raw_sigma=rs.grad.cpu().float(), g_levels=d0.grad.cpu().float())
+
+    got, want, exact = run("cuda", torch.float32, True), run("cpu", torch.float32, False), run("cpu", torch.float64, False)
+    for k in want:
+        if k.startswith("g_"):
+            e_got, e_ref = rel_err(got[k], exact[k]), rel_err(want[k], exact[k])
+            assert e_got <= 2.0 * e_ref + TOL, (k, e_got, e_ref)
+        else:
+            assert rel_err(got[k], want[k]) < TOL, (k, rel_err(got[k], want[k]))
+
+
 @pytest.mark.parametrize("mix,mask,shape", [(True, False, (2, 49, 24, 80)), (True, True, (2, 63, 20, 72)),
                                             (False, False, (3, 9, 17, 33))])
 def test_decoder_tail_vs_oracle_per_plane_disparities(mix, mask, shape):

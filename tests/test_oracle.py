@@ -164,3 +164,31 @@ def test_crop_grid_restatement_against_reference_grids():
         fw, fh, w0, h0 = (int(v) for v in z[tag + "/params"])
         H, W = (int(v) for v in z[tag + "/hw"])
         assert torch.equal(crop_grid(H, W, fh, fw, h0, w0), torch.from_numpy(z[tag + "/grid"])), tag
+
+
+@pytest.mark.parametrize("tag", ["mix_xy", "mix_xz", "l1_xy"])
+def test_plade_tail_oracle_against_reference_vectors(tag):
+    """oracle.plade_tail (restatement of networks/plade_net.py:309-341, --render_probability) against the vectors
+    make_golden.plade_tail_vectors captured from the reference PladeNet itself: outputs and every gradient."""
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "plade_tail.npz"))
+    g = lambda k: torch.from_numpy(z["%s/%s" % (tag, k)])  # noqa: E731
+    mix = bool(z[tag + "/mixture"])
+    rl, rs, dl = (g(k).clone().requires_grad_(True) for k in ("raw_logits", "raw_sigma", "disp_layered"))
+    B, N, H, W = dl.shape
+    ray = orc.camera_ray_norm(H, W)
+    assert torch.equal(ray, g("ray_norm"))
+    o = orc.plade_tail(rl, rs if mix else None, dl, W, ray, mix)
+    obj = (o["logits"] * g("gw_logits")).sum() + (o["dists"] * g("gw_dists")).sum() + (o["disp"] * g("gw_disp")).sum() + \
+        (o["depth"] * g("gw_depth")).sum()
+    if mix:
+        obj = obj + (o["sigma"] * g("gw_sigma")).sum()
+    obj.backward()
+    for k in ("logits", "dists", "probability", "disp", "depth") + (("sigma", "pi") if mix else ()):
+        assert rel_err(o[k].detach(), g(k)) < 1e-6, (tag, k)
+    assert rel_err(rl.grad, g("g_raw_logits")) < 1e-6
+    if mix:
+        assert rel_err(rs.grad, g("g_raw_sigma")) < 1e-6
+    if "%s/g_disp_layered" % tag in z.files:
+        assert rel_err(dl.grad, g("g_disp_layered")) < 1e-6
