@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--mono_pose", action="store_true",
                     help="homography_warp only: the pose of a novel frame as Trainer.predict_poses produces it without "
                          "COLMAP (BASELINE configs[3]: pose_net): small rotation, zero translation, Rt[3,3] = 0")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="how the timed steps are issued: eager (one host launch per kernel), graph (HIP-graph replay of one "
+                         "captured step), auto (default): both are timed for 30 steps before the window and the faster one "
+                         "runs it — eager on a box whose host keeps ahead of the device (the eager step costs the host "
+                         "0.24 ms, the device 0.29), graph replay (0.02 ms of host per step) on one that does not")
     ap.add_argument("--hip_graph", action="store_true",
                     help="capture one step (forward + backward, every launch of it) in a HIP graph and time replays: "
                          "takes the host-side launch cost of the small torch operators around the sweep out of the step")
@@ -752,22 +757,35 @@ def main():
     c = make_batch(args, device, seed=rank)  # every rank draws its own shard: no data-path collective
     step, _ = build_step(args, c, device)
     eager_step = step
-    if args.hip_graph:
+
+    def capture_step():
         # whole-step capture (the pattern torch documents for graphs with a backward): warm up on a side stream so every
-        # lazy initialisation (workspace sizes, kernel attributes, rocSOLVER handles) has happened, then record one
-        # step; the product's launches go to torch's current stream, which is the capturing one.
+        # lazy initialisation (workspace sizes, kernel attributes) has happened, then record one step; the product's
+        # launches go to torch's current stream, which is the capturing one.
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                step()
+                eager_step()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            step()
-        step = graph.replay
+            eager_step()
+        return graph.replay
 
+    if args.hip_graph:
+        args.launch = "graph"
+    # capture FIRST, before any eager step has run on the default stream (autograd's AccumulateGrad nodes remember the
+    # stream they were created on; a capture after eager steps breaks for the multi-view configurations)
+    launch_probe = None
+    graph_step = None
+    if args.launch in ("auto", "graph"):
+        try:
+            graph_step = capture_step()
+        except Exception as e:   # a capture that fails must not take the bench line with it
+            torch.cuda.synchronize(device)
+            launch_probe = {"graph_capture_failed": type(e).__name__}
     # The kernel-timing legs of the roofline block run BEFORE the timed window, on every rank: a process's first ~50
     # steps run ~10 % slower than its steady state (the same 20 steps take 0.355 ms after 5 warm-up steps, 0.316 ms after
     # 200: scripts/gpu_r3_warm.sh, DESIGN.md section 6 — the device's power state, not the host: a HIP-graph replay shows
@@ -778,12 +796,35 @@ def main():
     iso = kernel_times(args, c, device, iters=leg_iters)
     pre_timed = {"in_step_kernel_timing_steps": 2 * leg_iters, "isolated_fwd_launches": (leg_iters + 1) if iso else 0,
                  "isolated_bwd_launches": (leg_iters + 1) if iso else 0, "warmup_steps": args.warmup,
-                 "hip_graph_capture_steps": 4 if args.hip_graph else 0,
+                 "hip_graph_capture_steps": 0,
                  "why": "steady state: a fresh process runs its first ~50 steps ~10 % slower (device power state; DESIGN.md "
                         "section 6), and the roofline legs need the kernel times anyway"}
     pre_timed["steps_total"] = pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"]
     if "copy" not in args.skip_context:
         hbm_copy = measured_copy_rate(device)
+    # ---- how the timed steps are issued ----
+    if args.launch == "graph" and graph_step is not None:
+        step = graph_step
+    elif args.launch == "auto" and graph_step is not None:
+        def probe(fn, n=30):
+            fn()
+            torch.cuda.synchronize(device)
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t) / n * 1e3
+        t_eager, t_graph = probe(eager_step), probe(graph_step)
+        t_eager, t_graph = min(t_eager, probe(eager_step)), min(t_graph, probe(graph_step))
+        # every rank must take the same decision (the ranks meet in the timing barrier): the slowest rank's view decides
+        t_eager, t_graph = parallel.max_over_ranks(t_eager, device), parallel.max_over_ranks(t_graph, device)
+        launch_probe = {"eager_ms_per_step": round(t_eager, 4), "graph_ms_per_step": round(t_graph, 4), "steps_each": 2 * 31}
+        step = graph_step if t_graph < t_eager else eager_step
+    used_graph = step is not eager_step
+    pre_timed["hip_graph_capture_steps"] = 4 if graph_step is not None else 0
+    pre_timed["launch_probe_steps"] = 4 * 31 if (launch_probe and "steps_each" in launch_probe) else 0
+    pre_timed["steps_total"] = (pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"] +
+                                pre_timed["launch_probe_steps"])
     for _ in range(args.warmup):
         step()
     parallel.barrier(device)
@@ -798,7 +839,8 @@ def main():
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "launch": "HIP graph replay of one captured step" if args.hip_graph else "eager (one host launch per kernel)",
+        "launch": "HIP graph replay of one captured step" if used_graph else "eager (one host launch per kernel)",
+        "launch_policy": args.launch, "launch_probe": launch_probe,
         "pre_timed_steps": pre_timed,
         "library": dict(entry.BUILD_INFO),   # "built" here from source, or "reused" (the travelling .so matches this source hash)
         "known_deviation": "row kernels' backward (row-stream by default, row-shift under PD_IMPL_ROWS1): the adjoint drops the "

@@ -163,7 +163,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
 
   // ---- stage the row: blended source colour row with zero guard cells, per-plane shifts -----------------------------
   const float* srcb = a.src + (long)r.b * 3 * HW;
-  for (int cidx = tix; cidx < CW && active; cidx += nthr) {
+  for (int cidx = tix; cidx < CW && y < a.H; cidx += nthr) {
     const int x = cidx - kFsGuard;
     float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x >= 0 && x < W) {
@@ -178,7 +178,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   }
   {
     const float tol = irregular_tol(W);
-    for (int i = tix; i < N && active; i += nthr) {
+    for (int i = tix; i < N && y < a.H; i += nthr) {
       const float sd = staged_shift(a, r.b, i, r.y);
       const float fl = floorf(sd), fr = sd - fl;
       const bool inview = fabsf(sd) < (float)(W + 1);
@@ -301,22 +301,26 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
 template <bool MIX, bool AUTO, bool RENDER>
 __global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OCC - 1 : PD_FS_OCC) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                             float* __restrict__ ph_map,
-                                                                            float* __restrict__ stash, int rows) {
+                                                                            float* __restrict__ stash, int rows, int cblocks) {
   extern __shared__ float4 lds4[];
   // LDS per row of the workgroup: colour row float4[W + 8] | shift int2[N] (padded to 16 bytes); then the wave totals of ph_map
-  const int nseg = (a.W + kFsSeg - 1) / kFsSeg;
+  // A workgroup serves `rows` consecutive rows x one of `cblocks` column blocks of `segs` segments each (rows wider than
+  // 640 pixels are cut into column blocks so that three rows still fit the 16 waves of a workgroup).
+  const int nseg = (a.W + kFsSeg - 1) / kFsSeg, segs = (nseg + cblocks - 1) / cblocks;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slot = wave / nseg, seg = wave - slot * nseg;      // which of the workgroup's rows, which segment of it
+  const int slot = wave / segs;                                  // which of the workgroup's rows
   const int row_f4 = a.W + 2 * kFsGuard + (a.N + 1) / 2;         // float4 per row slot
   float4* col = lds4 + slot * row_f4;
   int2* shift = reinterpret_cast<int2*>(col + a.W + 2 * kFsGuard);
   float* parts = reinterpret_cast<float*>(lds4 + rows * row_f4);
-  const int groups = (a.H + rows - 1) / rows;                    // row groups per image: the grid is (groups, B), dealt row-major
-  const int grp = PD_FS_REVERSE ? groups - 1 - wg_rowid(a.B, groups) : wg_rowid(a.B, groups);
-  const int y = grp * rows + slot, b = wg_image(a.B, groups);
-  const bool active = y < a.H;
-  const RowSel row = two_row_form(make_row_sel(active ? y : 0, a.H), a.fast_rows != 0);
-  const int tix = threadIdx.x - slot * nseg * kWave, nthr = nseg * kWave;
+  const int groups = (a.H + rows - 1) / rows;                    // row groups per image; the grid is (groups * cblocks, B), dealt row-major
+  const int rid = wg_rowid(a.B, groups * cblocks);
+  const int grp = PD_FS_REVERSE ? groups - 1 - rid / cblocks : rid / cblocks, cb = rid % cblocks;
+  const int seg = cb * segs + (wave - slot * segs);              // which segment of the row
+  const int y = grp * rows + slot, b = wg_image(a.B, groups * cblocks);
+  const bool active = y < a.H && seg < nseg;
+  const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.fast_rows != 0);
+  const int tix = threadIdx.x - slot * segs * kWave, nthr = segs * kWave;
   float ph_sum;
   if (row.nrows == 2) ph_sum = fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
   else                ph_sum = fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
@@ -335,15 +339,20 @@ __global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OC
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-// rows per workgroup: PD_FS_ROWS where that many rows' waves fit one workgroup, else what fits
-static int fwdstream_rows(const pd_sweep_desc* d) {
-  const int most = (kFsThreadsMax / kWave) / ceil_div(d->W, kFsSeg);
-  const int r = most < PD_FS_ROWS ? most : PD_FS_ROWS;
-  return r < d->H ? r : d->H;
-}
-static size_t fwdstream_lds_bytes(const pd_sweep_desc* d) {
+// Workgroup shape: rows of up to 5 segments (640 pixels) go whole, wider ones in column blocks of equal size; PD_FS_ROWS rows
+// per workgroup where their waves fit its 16, else what fits.
+struct FsShape { int rows, cblocks, segs; size_t lds; };
+static FsShape fwdstream_shape(const pd_sweep_desc* d) {
+  FsShape s;
+  const int nseg = ceil_div(d->W, kFsSeg);
+  s.cblocks = ceil_div(nseg, 5);
+  s.segs = ceil_div(nseg, s.cblocks);
+  const int most = (kFsThreadsMax / kWave) / s.segs;
+  s.rows = most < PD_FS_ROWS ? most : PD_FS_ROWS;
+  if (s.rows > d->H) s.rows = d->H;
   const size_t row_f4 = (size_t)d->W + 2 * kFsGuard + ((size_t)d->N + 1) / 2;
-  return fwdstream_rows(d) * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * sizeof(float) + PD_FS_LDS_PAD;
+  s.lds = s.rows * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * sizeof(float) + PD_FS_LDS_PAD;
+  return s;
 }
 
 bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
@@ -351,19 +360,24 @@ bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
   if ((d->flags & PD_RENDER_PROB) && (((long)d->H * d->W) % 2 != 0 || (reinterpret_cast<uintptr_t>(a.dists) & 7))) return false;
   // pixel pairs: even width, 8-byte aligned rows of the per-pixel tensors (their bases come 8-byte aligned from any allocator
   // that hands out float2-aligned memory; checked because the boundary takes raw pointers)
-  if (d->W % 2 != 0 || ceil_div(d->W, kFsSeg) > kFsThreadsMax / kWave) return false;
-  return fwdstream_lds_bytes(d) <= 64 * 1024;
+  if (d->W % 2 != 0) return false;
+  return fwdstream_shape(d).lds <= device_lds_bytes();
 }
 
 int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
   if ((reinterpret_cast<uintptr_t>(a.tgt) | reinterpret_cast<uintptr_t>(a.src) | reinterpret_cast<uintptr_t>(rgb_rec) |
        reinterpret_cast<uintptr_t>(ph_map) | reinterpret_cast<uintptr_t>(stash)) & 7)
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, stream);   // unaligned tensors: the one-pixel-per-lane forward
-  const int rows = fwdstream_rows(d);
-  const dim3 grid(ceil_div(d->H, rows), d->B), block(ceil_div(d->W, kFsSeg) * rows * kWave);
-  const size_t shmem = fwdstream_lds_bytes(d);
+  const FsShape sh = fwdstream_shape(d);
+  const dim3 grid(ceil_div(d->H, sh.rows) * sh.cblocks, d->B), block(sh.segs * sh.rows * kWave);
+  const size_t shmem = sh.lds;
   const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
-#define PD_FS_LAUNCH(M, A, R) fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, rows)
+#define PD_FS_LAUNCH(M, A, R)                                                                                              \
+  do {                                                                                                                    \
+    static size_t granted = 64 * 1024;                                                                                    \
+    if (int rc = grant_dynamic_lds((const void*)fwdstream_kernel<M, A, R>, shmem, &granted, "fwdstream_kernel")) return rc; \
+    fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks);            \
+  } while (0)
   if (render) {
     if (mix) { if (am) PD_FS_LAUNCH(true, true, true); else PD_FS_LAUNCH(true, false, true); }
     else PD_FS_LAUNCH(false, false, true);

@@ -278,7 +278,9 @@ _FS_CASES = [
     (2, 7, 17, 132, 1.0, False, False, False),    # ragged width (W % 128 != 0), L1 loss
     (2, 7, 5, 130, -1.0, True, True, False),      # ragged, negative shifts, automask
     (2, 63, 21, 200, 1.0, True, True, True),      # per-row disparities (xz planes), PD_DISP_ROWS
-    (2, 49, 48, 1280, 1.0, True, False, False),   # wide rows: ten waves per workgroup
+    (2, 49, 48, 1280, 1.0, True, False, False),   # wide rows: two column blocks of five segments, three rows per workgroup
+    (1, 9, 7, 2048, -1.0, True, False, False),    # four column blocks of four segments (100 KB of LDS), a ragged row group
+    (1, 9, 4, 1416, 1.0, True, True, False),      # twelve segments in three blocks, the last one ragged
 ]
 
 
