@@ -98,11 +98,13 @@ __global__ void gather_prep_kernel(const float* __restrict__ H_t2s, GatherPrep* 
     for (int qy = 0; qy < 5 && ok; ++qy)
       for (int qx = 0; qx < 5 && ok; ++qx) {
         const GatherWindow w = gather_window(p.Hs, (float)(W - 1) * 0.25f * qx, (float)(H - 1) * 0.25f * qy);
-        // The window of a block scales with the Jacobian of u = (Hs x)_xy / w(x): terms in 1/w and (Hs x)_xy / w^2, so between
-        // a sample and any other point of the image it grows by at most (max|w| / min|w|)^2 times the variation of the affine
-        // numerator — bounded here by one more power of the spread.  A plane is regular only if that bound keeps EVERY window
-        // inside the kGatherSpan columns / rows pass 2 walks: a cut window would silently drop gradient terms (flags[1]).
-        const float grow = wspread * wspread * wspread;
+        // The window of a block scales with the Jacobian of u = (Hs x)_xy / w(x): J = (N' - u w') / w with N = Hs_xy x affine
+        // and u confined to the image (plus the window) wherever a target samples the plane, i.e. |J| ~ 1 / |w| times a
+        // factor that varies like u w' / N' — bounded here by one more power of the spread.  A plane is regular only if that
+        // bound keeps EVERY window inside the kGatherSpan columns / rows pass 2 walks (a cut window would silently drop
+        // gradient terms, flags[1]): with the acceptance thresholds below, kGatherSpanOk / kGatherWRatio^2 = 7 / 0.49 =
+        // 14.3 < kGatherSpan - 1, so the explicit test only bites if those constants are ever loosened.
+        const float grow = wspread * wspread;
         const float sx = w.x1 - w.x0 + 1.0f, sy = w.y1 - w.y0 + 1.0f;
         ok = (sx <= (float)kGatherSpanOk) && (sy <= (float)kGatherSpanOk) &&
              (sx * grow <= (float)(kGatherSpan - 1)) && (sy * grow <= (float)(kGatherSpan - 1));   // (false for NaN)
