@@ -803,6 +803,9 @@ def main():
     if "copy" not in args.skip_context:
         hbm_copy = measured_copy_rate(device)
     # ---- how the timed steps are issued ----
+    # every rank must take the same path through the probe's collectives: a capture that failed anywhere means eager everywhere
+    if args.launch in ("auto", "graph") and parallel.max_over_ranks(0.0 if graph_step is not None else 1.0, device) > 0.0:
+        graph_step = None
     if args.launch == "graph" and graph_step is not None:
         step = graph_step
     elif args.launch == "auto" and graph_step is not None:
