@@ -74,6 +74,10 @@ enum pd_sweep_flags {
                          then hands the workspaces of TWO such calls over the same logits / sigma to
                          pd_uniform_gather_pair, which gathers both views in one kernel (one store per gradient element
                          instead of a read-modify-write per view) */
+  ,
+  PD_PH_MEAN_ZEROED = 512 /* pd_plane_sweep_fwd: the caller hands `ph_mean` over holding 0.0f already (e.g. a slot of a buffer it
+                         zeroed once for many calls): the kernels add into it, and the entry point then issues no memset
+                         launch of its own (4-5 us per call next to a 0.1 ms kernel).  Ignored by the other entry points */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };

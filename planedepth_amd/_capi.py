@@ -15,6 +15,7 @@ PD_WARP_DISP, PD_WARP_HOMOGRAPHY = 0, 1
 PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_ROWS, PD_HOMO_UNIFORM = 1, 2, 4, 8, 16, 32, 64
 PD_BWD_ACCUMULATE = 128
 PD_BWD_DEFER_GATHER = 256
+PD_PH_MEAN_ZEROED = 512
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2

@@ -506,9 +506,10 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   // the stash always reserves the mask words in disp mode (pd_sweep_stash_floats); they are written when a mask exists
   SweepArgs a = make_args(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists);
-  if (ph_mean) {  // the kernels add into it: start from zero (an async memset on the same stream)
+  if (ph_mean) {  // the kernels add into it: start from zero (an async memset on the same stream, unless the caller did it)
     a.ph_mean = ph_mean;
-    if (hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
+    if (!(d->flags & PD_PH_MEAN_ZEROED) &&
+        hipMemsetAsync(ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
   }
   if (wants_rowshift(d) && rowshift_applicable(d)) {
     // default for the headline shape: one wave per 128-pixel segment streams over the planes (pd_plane_sweep_fwdstream.hip);

@@ -69,6 +69,27 @@ def _contig(t):
     return None if t is None else t.contiguous()
 
 
+ZERO_POOL = os.environ.get("PD_ZERO_POOL", "1") != "0"   # A/B switch: 0 = a memset launch per forward call instead
+_ZERO_POOL = {}   # (device, stream) -> [pool tensor, next free slot]
+
+
+def _zero_scalar(device, slots=4096):
+    """A fresh [1] float32 tensor that holds 0.0: slot i of a pool zeroed ONCE per `slots` calls (one fill launch for 4096
+    forward calls instead of one memset launch each).  Every call gets its own slot, so a result the caller keeps (the
+    loss value of an earlier step) is never written again; an exhausted pool is simply replaced (its slots live on through
+    the tensors that view them).  Under stream capture (HIP graphs) the slot is zeroed in the captured work itself —
+    a replay must start from zero every time."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(1, device=device, dtype=torch.float32)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # zeroed on the stream its slots are used on
+    st = _ZERO_POOL.get(key)
+    if st is None or st[1] >= slots:
+        st = _ZERO_POOL[key] = [torch.zeros(slots, device=device, dtype=torch.float32), 0]
+    i = st[1]
+    st[1] = i + 1
+    return st[0][i:i + 1]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused plane sweep + photometric loss
 # ---------------------------------------------------------------------------------------------------------------------
@@ -104,7 +125,11 @@ def _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_ma
     k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
     rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
     ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
-    ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
+    if ZERO_POOL:
+        ph_mean = _zero_scalar(logits.device)   # a pre-zeroed slot: the entry point then launches no memset (PD_PH_MEAN_ZEROED)
+        d.flags |= C.PD_PH_MEAN_ZEROED
+    else:
+        ph_mean = torch.empty(1, device=logits.device, dtype=torch.float32)
     stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
     with C.on_device(logits.device), _timed("fwd"):
         rc = lib.pd_plane_sweep_fwd(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma),
