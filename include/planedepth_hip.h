@@ -400,6 +400,44 @@ int pd_uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const f
                            pd_stream_t stream);
 
 /*
+ * TWO plane-uniform target views of the same source image in one call each way (the novel frames -1 / +1 of the reference's
+ * mono training: `for target_side in self.target_sides` over the same outputs, trainer.py:532).  The views' workgroups for
+ * the same image tile are dispatched next to each other on one XCD, so the second view finds the logits / sigma lines of the
+ * first in that XCD's L2; results are those of two pd_plane_sweep_fwd / pd_plane_sweep_bwd calls, bit for bit.
+ *   pd_sweep_view: what differs between the views.  Forward: tgt, plane [B,4,3,3], plane_aux [B*N,3], inv_K3 [B,3,3], dists
+ *                  (PD_RENDER_PROB) in; rgb_rec, ph_map, ph_mean (may be NULL), stash out.  Backward: the same inputs +
+ *                  padding_mask ([B,N,3] translation weights or NULL), rgb_rec, stash, g_rgb_rec / g_ph_map / g_ph_mean
+ *                  (each may be NULL) in; g_plane [B,4,3,3] (may be NULL), g_dists (may be NULL) and `workspace`
+ *                  (pd_sweep_bwd_workspace_floats(d) floats per view) out.
+ *   pd_uniform_fwd_pair   d: PD_WARP_HOMOGRAPHY | PD_HOMO_UNIFORM; PD_PH_MEAN_ZEROED as in pd_plane_sweep_fwd.
+ *   pd_uniform_bwd_pair   g_logits / g_sigma [B,N,H,W] = (PD_BWD_ACCUMULATE: their old contents +) both views' gradients;
+ *                         g_logits NULL: only g_plane / g_dists are produced.
+ */
+typedef struct pd_sweep_view {
+  const float* tgt;
+  const float* plane;
+  const float* plane_aux;
+  const float* inv_K3;
+  const float* padding_mask;
+  const float* dists;
+  float* rgb_rec;
+  float* ph_map;
+  float* ph_mean;
+  float* stash;
+  const float* g_rgb_rec;
+  const float* g_ph_map;
+  const float* g_ph_mean;
+  float* g_plane;
+  float* g_dists;
+  float* workspace;
+} pd_sweep_view;
+int pd_uniform_fwd_pair(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                        const pd_sweep_view* view_a, const pd_sweep_view* view_b, pd_stream_t stream);
+int pd_uniform_bwd_pair(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                        const pd_sweep_view* view_a, const pd_sweep_view* view_b, float* g_logits, float* g_sigma,
+                        pd_stream_t stream);
+
+/*
  * F.grid_sample(input, grid, mode="bilinear", padding_mode=zeros|border, align_corners=True) as the reference calls it
  * (trainer.py:444-463, 573-577, 624-628) — SURVEY.md row A5.
  *   input [M,C,Hi,Wi], grid [M,Ho,Wo,2] -> out [M,C,Ho,Wo]

@@ -30,6 +30,21 @@ class SweepDesc(ctypes.Structure):
                 ("impl", ctypes.c_int32)]
 
 
+class SweepView(ctypes.Structure):
+    """Mirror of ``pd_sweep_view``: what differs between two target views of one source image (pd_uniform_*_pair)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "tgt", "plane", "plane_aux", "inv_K3", "padding_mask", "dists", "rgb_rec", "ph_map", "ph_mean", "stash",
+        "g_rgb_rec", "g_ph_map", "g_ph_mean", "g_plane", "g_dists", "workspace")]
+
+
+def sweep_view(**tensors):
+    """SweepView from keyword tensors (missing / None -> NULL)."""
+    v = SweepView()
+    for name, t in tensors.items():
+        setattr(v, name, None if t is None else t.data_ptr())
+    return v
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -49,6 +64,8 @@ SIGNATURES = {
     "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 20),
     "pd_plane_sweep_layers": (_I, [_D] + [_P] * 14),
     "pd_uniform_gather_pair": (_I, [_D] + [_P] * 9),
+    "pd_uniform_fwd_pair": (_I, [_D] + [_P] * 3 + [ctypes.POINTER(SweepView)] * 2 + [_P]),
+    "pd_uniform_bwd_pair": (_I, [_D] + [_P] * 3 + [ctypes.POINTER(SweepView)] * 2 + [_P] * 3),
     "pd_ssim_fwd": (_I, [_I] * 4 + [_P] * 4),
     "pd_ssim_bwd": (_I, [_I] * 4 + [_P] * 6),
     "pd_reproj_loss_fwd": (_I, [_I] * 4 + [_P] * 4),

@@ -400,6 +400,8 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
     PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM), "PD_HOMO_UNIFORM is a homography-mode flag");
   }
   PD_REQUIRE(!(d->flags & PD_BWD_DEFER_GATHER) || (d->flags & PD_HOMO_UNIFORM), "PD_BWD_DEFER_GATHER goes with PD_HOMO_UNIFORM");
+  PD_REQUIRE(!(d->flags & PD_HOMO_UNIFORM) || (size_t)d->N * d->H * d->W < ((size_t)1 << 29),
+             "PD_HOMO_UNIFORM: one image's N*H*W = %zu needs 32-bit byte offsets (< 2^29 elements)", (size_t)d->N * d->H * d->W);
   PD_REQUIRE(!((d->flags & PD_DISP_DENSE) && (d->flags & PD_DISP_ROWS)), "PD_DISP_DENSE and PD_DISP_ROWS exclude each other");
   if ((d->flags & PD_DISP_ROWS) && !pd_sweep_uses_rowshift(d)) {
     set_error("PD_DISP_ROWS is served by the row-shift kernels only (pd_sweep_uses_rowshift); pass a dense map instead");
@@ -625,6 +627,60 @@ extern "C" int pd_uniform_gather_pair(const pd_sweep_desc* d, const float* plane
   PD_REQUIRE(!(d->flags & PD_MIXTURE) || g_sigma, "PD_MIXTURE needs g_sigma");
   return uniform_gather_pair(d, plane_a, inv_K3_a, workspace_a, plane_b, inv_K3_b, workspace_b, g_logits, g_sigma,
                              (hipStream_t)stream);
+}
+
+static int validate_pair(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                         const pd_sweep_view* va, const pd_sweep_view* vb) {
+  PD_REQUIRE(d && va && vb, "desc / view is NULL");
+  PD_REQUIRE(d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM), "the pair entry points serve PD_HOMO_UNIFORM views");
+  for (const pd_sweep_view* v : {va, vb}) {
+    const int rc = validate(d, src, logits, sigma, v->plane, v->plane_aux, v->inv_K3, v->padding_mask);
+    if (rc) return rc;
+    PD_REQUIRE(v->tgt && v->rgb_rec && v->stash, "view: tgt / rgb_rec / stash must not be NULL");
+    PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (v->dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
+  }
+  return PD_OK;
+}
+
+extern "C" int pd_uniform_fwd_pair(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                                   const pd_sweep_view* va, const pd_sweep_view* vb, pd_stream_t stream) {
+  int rc = validate_pair(d, src, logits, sigma, va, vb);
+  if (rc) return rc;
+  PD_REQUIRE(va->ph_map && vb->ph_map, "view: ph_map must not be NULL");
+  PD_REQUIRE((va->ph_mean == nullptr) == (vb->ph_mean == nullptr), "ph_mean: both views or neither");
+  SweepArgs a = make_args(d, src, va->tgt, logits, sigma, va->plane, va->plane_aux, va->inv_K3, nullptr, va->dists);
+  SweepArgs b = make_args(d, src, vb->tgt, logits, sigma, vb->plane, vb->plane_aux, vb->inv_K3, nullptr, vb->dists);
+  a.ph_mean = va->ph_mean; b.ph_mean = vb->ph_mean;
+  if (a.ph_mean && !(d->flags & PD_PH_MEAN_ZEROED)) {
+    if (hipMemsetAsync(a.ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(b.ph_mean, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("hipMemsetAsync");
+  }
+  return uniform_fwd_pair(d, a, va->rgb_rec, va->ph_map, va->stash, b, vb->rgb_rec, vb->ph_map, vb->stash, (hipStream_t)stream);
+}
+
+extern "C" int pd_uniform_bwd_pair(const pd_sweep_desc* d, const float* src, const float* logits, const float* sigma,
+                                   const pd_sweep_view* va, const pd_sweep_view* vb, float* g_logits, float* g_sigma,
+                                   pd_stream_t stream) {
+  int rc = validate_pair(d, src, logits, sigma, va, vb);
+  if (rc) return rc;
+  PD_REQUIRE(va->workspace && vb->workspace, "view: workspace (pd_sweep_bwd_workspace_floats) must not be NULL");
+  const bool mix = (d->flags & PD_MIXTURE) != 0;
+  PD_REQUIRE(!g_logits || !mix || g_sigma, "PD_MIXTURE needs g_sigma next to g_logits");
+  if (switches().uni_chunk && switches().uni_chunk < d->B) {
+    set_error("pd_uniform_bwd_pair needs the whole batch's scratch (PD_UNI_CHUNK is set)");
+    return PD_ERR_UNSUPPORTED;
+  }
+  SweepArgs a = make_args(d, src, va->tgt, logits, sigma, va->plane, va->plane_aux, va->inv_K3, va->padding_mask, va->dists);
+  SweepArgs b = make_args(d, src, vb->tgt, logits, sigma, vb->plane, vb->plane_aux, vb->inv_K3, vb->padding_mask, vb->dists);
+  BwdOut oa{}, ob{};
+  for (int i = 0; i < 2; ++i) {
+    const pd_sweep_view* v = i ? vb : va;
+    BwdOut& o = i ? ob : oa;
+    o.g_logits = nullptr; o.g_sigma = nullptr; o.g_plane = v->g_plane; o.partials = v->workspace; o.side = nullptr; o.scratch = nullptr;
+    o.g_dists = (d->flags & PD_RENDER_PROB) ? v->g_dists : nullptr;
+    o.rgb_rec = v->rgb_rec; o.stash = v->stash; o.g_rgb_rec = v->g_rgb_rec; o.g_ph_map = v->g_ph_map; o.g_ph_mean = v->g_ph_mean;
+  }
+  return uniform_bwd_pair(d, a, oa, va->workspace, b, ob, vb->workspace, g_logits, mix ? g_sigma : nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pd_debug_gather_flags(const pd_sweep_desc* d, const float* workspace, int* host_out, pd_stream_t stream) {

@@ -27,6 +27,8 @@
 //           (uniform_bwd_pass2_staged_kernel; uniform_bwd_pass2_kernel is the direct-gather form and the follow-up for
 //           source pixels with more than 12 contributors, i.e. strong minification).  Every element of g_logits /
 //           g_sigma is written exactly once: no zero-fill, no atomics, deterministic.
+// Two views of one source image (the novel frames -1 / +1): pd_uniform_fwd_pair runs both forwards in one launch (PairSlot),
+// pd_uniform_bwd_pair the whole backward in one call (first passes, pair gather, reductions).
 // The whole batch goes through each pass in one launch (parallelism beat keeping one image's scratch in the 256 MB
 // memory-side cache: uniform_chunk); workgroups are dealt to the XCDs in contiguous bands of the image (xcd_banded).
 // Opt-in alternative (PD_UNI_FUSED): both passes in one kernel with an LDS hand-over per plane — exact, slower.
@@ -75,15 +77,80 @@ __device__ __forceinline__ UniGeom uni_geom(const float* __restrict__ Hm, const 
 __device__ __forceinline__ bool uni_mask(const UniGeom& u, const float* __restrict__ Rn) {
   return ((u.r0 * Rn[0] + u.r1 * Rn[1] + u.r2 * Rn[2]) > 0.0f) && u.z_ok;   // layers.py:223-225, same operation order
 }
+// The plane loops fetch plane n+1's normal (three scalar loads) while plane n is reduced: loaded where it is used, every
+// iteration began with a wait for the scalar cache.
+struct RnAhead {
+  float q0, q1, q2;
+  __device__ __forceinline__ void fetch(const float* __restrict__ Rn, int n) { q0 = Rn[n * 3]; q1 = Rn[n * 3 + 1]; q2 = Rn[n * 3 + 2]; }
+  __device__ __forceinline__ bool mask(const UniGeom& u) const { return ((u.r0 * q0 + u.r1 * q1 + u.r2 * q2) > 0.0f) && u.z_ok; }
+};
+
+// One image's [N,H,W] block as a buffer resource: a tap load is then "descriptor + the lane's 32-bit tap offset + the plane's
+// offset in an SGPR" — no per-lane 64-bit address arithmetic (with flat loads the plane loop spent 16 v_lshl_add_u64 per
+// plane on its eight addresses: a quarter of its VALU instructions, and these kernels are VALU-paced: r04 PMC,
+// SQ_ACTIVE_INST_VALU = 0.63 of the kernel's cycles).  The offsets are clamped into the plane (tap_kernel), so the range
+// check never fires; the host checks that 2 N H W floats fit 32-bit byte offsets.
+typedef __amdgpu_buffer_rsrc_t URsrc;
+__device__ __forceinline__ URsrc image_rsrc(const float* base, unsigned bytes) {   // `base` must be workgroup-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ubuf(URsrc r, unsigned lane_off, unsigned plane_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)plane_off, 0));
+}
+__device__ __forceinline__ float usample_k(URsrc r, const TapK& k, unsigned po) {
+  return ubuf(r, k.o00, po) * k.w00 + ubuf(r, k.o01, po) * k.w01 + ubuf(r, k.o10, po) * k.w10 + ubuf(r, k.o11, po) * k.w11;
+}
+__device__ __forceinline__ float usample_vg_k(URsrc r, const TapK& k, unsigned po, float& dx, float& dy) {
+  const float nw = ubuf(r, k.o00, po), ne = ubuf(r, k.o01, po), sw = ubuf(r, k.o10, po), se = ubuf(r, k.o11, po);
+  dx = nw * k.x00 + ne * k.x01 + sw * k.x10 + se * k.x11;
+  dy = nw * k.y00 + ne * k.y01 + sw * k.y10 + se * k.y11;
+  return nw * k.w00 + ne * k.w01 + sw * k.w10 + se * k.w11;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MIX, bool RENDER = false>
+// PAIR: two target views of the same source image (trainer.py:532, the novel frames -1 / +1) in ONE launch.  The grid holds
+// every tile twice; workgroup ids 8 apart land on the same XCD (ids are dealt round-robin to the 8 XCDs) right after each
+// other, so slot 2k of an XCD serves tile k for view A and slot 2k+1 the same tile for view B: the second workgroup finds
+// the logits / sigma lines the first one pulled in in that XCD's L2 (pose_net rotations move the footprint by a few
+// pixels).  Measured with both halves on the same view (8x49x192x640): forward 2 x 0.140 -> 0.221 ms, pass 1 2 x 0.191 ->
+// 0.326 ms.  The arithmetic per view is exactly the single-view kernel's.
+struct UniViewB {   // what differs for view B
+  const float* tgt; const float* plane; const float* plane_aux; const float* inv_K3; const float* dists;
+  float* ph_mean; float* rgb_rec; float* ph_map; float* stash;
+};
+struct PairSlot { int tile, view; };
+__device__ __forceinline__ PairSlot pair_slot(int bx, int nblk2) {   // nblk2 = 2 x tiles
+  const int nblk = nblk2 >> 1, full = (nblk / kXcds) * kXcds;   // tiles in whole rounds of the XCDs
+  PairSlot p;
+  if (bx < 2 * full) {
+    const int xcd = bx % kXcds, slot = bx / kXcds;
+    p.view = slot & 1;
+    p.tile = xcd_banded((slot >> 1) * kXcds + xcd, nblk);
+  } else {   // the remainder: neighbours in dispatch order
+    p.view = (bx - 2 * full) & 1;
+    p.tile = full + ((bx - 2 * full) >> 1);
+  }
+  return p;
+}
+
+template <bool MIX, bool RENDER = false, bool PAIR = false>
 __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float* __restrict__ rgb_rec,
-                                                             float* __restrict__ ph_map, float* __restrict__ stash) {
+                                                             float* __restrict__ ph_map, float* __restrict__ stash, UniViewB vb) {
   const int HW = a.H * a.W;
-  const int pix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+  int tile = 0;
+  if (PAIR) {
+    const PairSlot ps = pair_slot(blockIdx.x, gridDim.x);
+    tile = ps.tile;
+    if (ps.view) {
+      a.tgt = vb.tgt; a.plane = vb.plane; a.plane_aux = vb.plane_aux; a.inv_K3 = vb.inv_K3; a.dists = vb.dists;
+      a.ph_mean = vb.ph_mean; rgb_rec = vb.rgb_rec; ph_map = vb.ph_map; stash = vb.stash;
+    }
+  } else {
+    tile = xcd_banded(blockIdx.x, gridDim.x);
+  }
+  const int pix = tile * kBlock + threadIdx.x;
   const int b = blockIdx.y;
   float ph_val = 0.0f;
   if (pix < HW) {
@@ -104,13 +171,19 @@ __global__ __launch_bounds__(kBlock) void uniform_fwd_kernel(SweepArgs a, float*
     constexpr bool render = RENDER;   // alpha compositing over the planes instead of the softmax (a template flag: as a
                                       // run-time one it cost the softmax path 10 % — registers and branches in the plane loop)
     const float* Rn = a.plane_aux + (long)b * a.N * 3;
-    for (int n = 0; n < a.N; ++n) {
-      const bool mk = uni_mask(u, Rn + n * 3);
+    const unsigned image_bytes = (unsigned)(a.N * HW) * 4u, plane_bytes = (unsigned)HW * 4u;
+    const URsrc rl = image_rsrc(a.logits + (long)b * a.N * HW, image_bytes);
+    const URsrc rsg = image_rsrc(MIX ? a.sigma + (long)b * a.N * HW : a.logits, MIX ? image_bytes : 0u);
+    unsigned po = 0;
+    RnAhead rn;
+    rn.fetch(Rn, 0);
+    for (int n = 0; n < a.N; ++n, po += plane_bytes) {
+      const bool mk = rn.mask(u);
+      rn.fetch(Rn, min(n + 1, a.N - 1));
       float l = 0.0f, s = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
       if (mk) {   // a masked plane samples as all-zero features (trainer.py:580)
-        const long pl = ((long)b * a.N + n) * HW;
-        l = sample_k(a.logits + pl, t);
-        if (MIX) s = sample_k(a.sigma + pl, t);
+        l = usample_k(rl, t, po);
+        if (MIX) s = usample_k(rsg, t, po);
         c0 = s0; c1 = s1; c2 = s2;
       }
       if (render) {
@@ -160,11 +233,14 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
   if (run_flag && *run_flag == 0) return;   // the fused kernel served the whole launch
   __shared__ float red[kUniG * 9];
   const int HW = a.H * a.W, N = a.N;
-  const int pix = xcd_banded(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-  const int b = b0 + blockIdx.y;
+  const int ntiles = gridDim.x;
+  const int tile = xcd_banded(blockIdx.x, gridDim.x);
+  const int by = blockIdx.y;
+  const int pix = tile * kBlock + threadIdx.x;
+  const int b = b0 + by;
   // (g_l, g_s) of a pixel-plane side by side: one 8-byte store here, one 8-byte load per list entry in pass 2 (pass 2
   // is paced by its number of memory instructions: 0.386 -> see DESIGN.md with the two tensors apart)
-  float* __restrict__ tmp_b = tmp + (long)blockIdx.y * 2 * N * HW;
+  float* __restrict__ tmp_b = tmp + (long)by * 2 * N * HW;
   if (threadIdx.x < kUniG * 9) red[threadIdx.x] = 0.0f;
   __syncthreads();
   const bool want_plane = (o.g_plane != nullptr);
@@ -188,19 +264,28 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
     constexpr bool render = RENDER;
     const float Rtot = MIX ? -c.A * c.mx : c.gdotr;   // sum_k p_k dL/dp_k in closed form
     float T = 1.0f, prefix = 0.0f;
-    for (int n = 0; n < N; ++n) {
+    const unsigned image_bytes = (unsigned)(N * HW) * 4u, plane_bytes = (unsigned)HW * 4u;
+    const URsrc rl = image_rsrc(a.logits + (long)b * N * HW, image_bytes);
+    const URsrc rsg = image_rsrc(MIX ? a.sigma + (long)b * N * HW : a.logits, MIX ? image_bytes : 0u);
+    const URsrc rtmp = image_rsrc(tmp_b, image_bytes * (MIX ? 2u : 1u));   // the scratch of this image: [N][HW] float2 / float
+    const unsigned tmp_lane = (unsigned)pix * (MIX ? 8u : 4u), tmp_plane = plane_bytes * (MIX ? 2u : 1u);
+    unsigned po = 0, pt = 0;
+    RnAhead rn;
+    rn.fetch(Rn, 0);
+    for (int n = 0; n < N; ++n, po += plane_bytes, pt += tmp_plane) {
       float g_l = 0.0f, g_s = 0.0f;
       if (render && o.g_dists && n < N - 1) o.g_dists[((long)b * (N - 1) + n) * HW + pix] = 0.0f;   // (masked planes keep this)
-      if (uni_mask(u, Rn + n * 3)) {
-        const long pl = ((long)b * N + n) * HW;
+      const bool mk = rn.mask(u);
+      rn.fetch(Rn, min(n + 1, N - 1));
+      if (mk) {
         float dlx = 0.0f, dly = 0.0f, dsx = 0.0f, dsy = 0.0f;
         float l, s = 0.0f;
         if (want_plane) {
-          l = sample_vg_k(a.logits + pl, t, dlx, dly);
-          if (MIX) s = sample_vg_k(a.sigma + pl, t, dsx, dsy);
+          l = usample_vg_k(rl, t, po, dlx, dly);
+          if (MIX) s = usample_vg_k(rsg, t, po, dsx, dsy);
         } else {
-          l = sample_k(a.logits + pl, t);
-          if (MIX) s = sample_k(a.sigma + pl, t);
+          l = usample_k(rl, t, po);
+          if (MIX) s = usample_k(rsg, t, po);
         }
         PlaneGrad pg;
         if (render) {   // d prob_k / d alpha_n for k >= n through the transmittance (trainer.py:584-591)
@@ -230,8 +315,13 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
           }
         }
       }
-      if (MIX) reinterpret_cast<float2*>(tmp_b)[(long)n * HW + pix] = make_float2(g_l, g_s);
-      else tmp_b[(long)n * HW + pix] = g_l;
+      if (MIX) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v v; v.x = __builtin_bit_cast(unsigned, g_l); v.y = __builtin_bit_cast(unsigned, g_s);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rtmp, (int)tmp_lane, (int)pt, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g_l), rtmp, (int)tmp_lane, (int)pt, 0);
+      }
     }
     float inv_z = fast_rcp(u.g.zc);
     inv_z = fmaf(fmaf(-u.g.zc, inv_z, 1.0f), inv_z, inv_z);
@@ -255,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void uniform_bwd_pass1_kernel(SweepArgs a, 
     }
     __syncthreads();
     if (threadIdx.x < kUniG * 9)
-      partials[((long)b * gridDim.x + blockIdx.x) * (kUniG * 9) + threadIdx.x] = red[threadIdx.x];
+      partials[((long)b * ntiles + tile) * (kUniG * 9) + threadIdx.x] = red[threadIdx.x];
   }
 }
 
@@ -464,12 +554,13 @@ __global__ __launch_bounds__(kStageThreads) void uniform_bwd_pass2_staged_kernel
   typedef typename std::conditional<MIX, float2, float>::type Elem;
   __shared__ Elem buf[2][kStageP][kStageBox];
   const int HW = a.H * a.W, N = a.N, W = a.W, H = a.H;
-  const int b = b0 + blockIdx.y, tid = threadIdx.x;
+  const int by = blockIdx.y;
+  const int b = b0 + by, tid = threadIdx.x;
   const int blk = xcd_banded(blockIdx.x, gridDim.x);
   const int tyi = blk / tiles_x, txi = blk - tyi * tiles_x;
   const int xs0 = txi * kStageW, ys0 = tyi * kStageH;
   const int tw_ = min(kStageW, W - xs0), th = min(kStageH, H - ys0);
-  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp + (long)blockIdx.y * 2 * N * HW);
+  const Elem* __restrict__ tmp_b = reinterpret_cast<const Elem*>(tmp + (long)by * 2 * N * HW);
   const CoordNorm cn = make_coord_norm(W, H);
   const float* Hm = a.plane + (long)b * kUniH;
   const float* Ki = a.inv_K3 + (long)b * 9;
@@ -673,7 +764,7 @@ __global__ __launch_bounds__(kStageThreads) void uniform_bwd_pass2_pair_kernel(P
     bw[v] = max(bx1 - bx0[v] + 1, 0);
     npx[v] = bw[v] * max(by1 - by0[v] + 1, 0);
     staged = staged && npx[v] <= kStageBox;
-    tmp_b[v] = reinterpret_cast<const Elem*>(pa.tmp[v] + (long)blockIdx.y * 2 * N * HW);
+    tmp_b[v] = reinterpret_cast<const Elem*>(pa.tmp[v] + (long)b * 2 * N * HW);
   }
 #pragma unroll
   for (int v = 0; v < kPairViews; ++v) {
@@ -838,32 +929,59 @@ size_t uniform_bwd_workspace_floats(const pd_sweep_desc* d) {
          (size_t)uniform_chunk(d) * 2 * d->N * d->H * d->W + 8;
 }
 
-int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
-  dim3 grid(ceil_div(d->H * d->W, kBlock), d->B);
+template <bool PAIR>
+static int uniform_fwd_launch(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
+                              const UniViewB& vb, hipStream_t stream) {
+  dim3 grid((PAIR ? 2 : 1) * ceil_div(d->H * d->W, kBlock), d->B);
   const bool mix = (d->flags & PD_MIXTURE) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
-  if (mix) { if (render) uniform_fwd_kernel<true, true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
-             else        uniform_fwd_kernel<true, false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash); }
-  else     { if (render) uniform_fwd_kernel<false, true><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash);
-             else        uniform_fwd_kernel<false, false><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash); }
+  if (mix) { if (render) uniform_fwd_kernel<true, true, PAIR><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash, vb);
+             else        uniform_fwd_kernel<true, false, PAIR><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash, vb); }
+  else     { if (render) uniform_fwd_kernel<false, true, PAIR><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash, vb);
+             else        uniform_fwd_kernel<false, false, PAIR><<<grid, kBlock, 0, stream>>>(a, rgb_rec, ph_map, stash, vb); }
   return check_launch("uniform_fwd_kernel");
+}
+int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream) {
+  return uniform_fwd_launch<false>(d, a, rgb_rec, ph_map, stash, UniViewB{}, stream);
+}
+// two views of the same src / logits / sigma in one launch (pd_uniform_fwd_pair)
+int uniform_fwd_pair(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
+                     const SweepArgs& b, float* rgb_rec_b, float* ph_map_b, float* stash_b, hipStream_t stream) {
+  UniViewB vb{b.tgt, b.plane, b.plane_aux, b.inv_K3, b.dists, b.ph_mean, rgb_rec_b, ph_map_b, stash_b};
+  return uniform_fwd_launch<true>(d, a, rgb_rec, ph_map, stash, vb, stream);
+}
+
+// where the backward keeps its pieces inside a workspace
+struct UniformWs { float* part_two; float* part_fused; UniPrep* prep; float* tmp; int* overflow; int* irregular; };
+static UniformWs uniform_ws(const pd_sweep_desc* d, float* workspace) {
+  const int nblk = ceil_div(d->H * d->W, kBlock);
+  const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+  UniformWs w;
+  w.part_two = reinterpret_cast<float*>(base);
+  w.part_fused = w.part_two + ualign4((size_t)d->B * nblk * kUniG * 9);
+  w.prep = reinterpret_cast<UniPrep*>(w.part_fused + ualign4((size_t)d->B * nblk * kUniG * 9));
+  w.tmp = reinterpret_cast<float*>(w.prep) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float)));
+  w.overflow = reinterpret_cast<int*>(&w.prep[0].pad[0]);    // both written 0 by uniform_prep_kernel
+  w.irregular = reinterpret_cast<int*>(&w.prep[0].pad[1]);
+  return w;
 }
 
 // `tw` = a.padding_mask slot: [B][N][3] translation weights n/d, or NULL (no translation gradient wanted)
 int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream) {
   const int HW = d->H * d->W, nblk = ceil_div(HW, kBlock);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
-  uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
-  float* part_two = reinterpret_cast<float*>(base);
-  float* part_fused = part_two + ualign4((size_t)d->B * nblk * kUniG * 9);
-  UniPrep* prep = reinterpret_cast<UniPrep*>(part_fused + ualign4((size_t)d->B * nblk * kUniG * 9));
-  float* tmp = reinterpret_cast<float*>(prep) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float)));
+  const UniformWs w = uniform_ws(d, workspace);
+  float* part_two = w.part_two;
+  float* part_fused = w.part_fused;
+  UniPrep* prep = w.prep;
+  float* tmp = w.tmp;
   const float* tw = a.padding_mask;
   SweepArgs ak = a;
   ak.padding_mask = nullptr;
   uniform_prep_kernel<<<ceil_div(d->B, 64), 64, 0, stream>>>(a.plane, prep, d->B);
   int rc = check_launch("uniform_prep_kernel");
-  int* overflow = reinterpret_cast<int*>(&prep[0].pad[0]);    // both written 0 by uniform_prep_kernel
-  int* irregular = reinterpret_cast<int*>(&prep[0].pad[1]);
+  int* overflow = w.overflow;
+  int* irregular = w.irregular;
+  (void)part_fused;
   // Measured at 8x49x192x640 (pose_net-like rotations): two-pass 0.27 + 0.38 = 0.65 ms, fused 0.75 ms — sixteen waves
   // meeting at a barrier 49 times cost more than the 770 MB the scratch tensor moves.  The fused kernel stays opt-in.
   const int accumulate = (d->flags & PD_BWD_ACCUMULATE) ? 1 : 0;
@@ -928,20 +1046,6 @@ int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, flo
   return check_launch("uniform_reduce_kernel");
 }
 
-// where uniform_bwd keeps its pieces inside a workspace (the same arithmetic as there)
-struct UniformWs { UniPrep* prep; float* tmp; int* overflow; };
-static UniformWs uniform_ws(const pd_sweep_desc* d, float* workspace) {
-  const int nblk = ceil_div(d->H * d->W, kBlock);
-  const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
-  float* part_two = reinterpret_cast<float*>(base);
-  float* part_fused = part_two + ualign4((size_t)d->B * nblk * kUniG * 9);
-  UniformWs w;
-  w.prep = reinterpret_cast<UniPrep*>(part_fused + ualign4((size_t)d->B * nblk * kUniG * 9));
-  w.tmp = reinterpret_cast<float*>(w.prep) + ualign4((size_t)d->B * (sizeof(UniPrep) / sizeof(float)));
-  w.overflow = reinterpret_cast<int*>(&w.prep[0].pad[0]);
-  return w;
-}
-
 int uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,
                         const float* plane_b, const float* inv_K3_b, float* workspace_b, float* g_logits, float* g_sigma,
                         hipStream_t stream) {
@@ -969,6 +1073,42 @@ int uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const floa
     else     uniform_bwd_pass2_kernel<false, true><<<grid, kBlock, 0, stream>>>(a, 0, w.tmp, w.prep, g_logits, nullptr, w.overflow, nullptr, 1, kPairK);
   }
   return check_launch("uniform_bwd_pass2_pair_kernel");
+}
+
+// The whole backward of two plane-uniform views of one source image (pd_uniform_bwd_pair): the first passes, the pair
+// gather, the homography gradients' reductions.
+int uniform_bwd_pair(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& oa, float* workspace_a, const SweepArgs& b,
+                     const BwdOut& ob, float* workspace_b, float* g_logits, float* g_sigma, hipStream_t stream) {
+  const int nblk = ceil_div(d->H * d->W, kBlock);
+  const bool mix = (d->flags & PD_MIXTURE) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
+  const UniformWs wa = uniform_ws(d, workspace_a), wb = uniform_ws(d, workspace_b);
+  uniform_prep_kernel<<<ceil_div(d->B, 64), 64, 0, stream>>>(a.plane, wa.prep, d->B);
+  uniform_prep_kernel<<<ceil_div(d->B, 64), 64, 0, stream>>>(b.plane, wb.prep, d->B);
+  int rc = check_launch("uniform_prep_kernel");
+  if (rc) return rc;
+  // (both first passes in ONE launch, as the forward does it, was measured: 0.400 ms against 2 x 0.193 — they are paced by
+  // their scratch stores, 770 MB for the two views, not by the logits / sigma reads the views could share)
+  for (int v = 0; v < 2 && !rc; ++v) {
+    const SweepArgs& s = v ? b : a;
+    const BwdOut& o = v ? ob : oa;
+    const UniformWs& w = v ? wb : wa;
+    SweepArgs ak = s;
+    ak.padding_mask = nullptr;
+    const dim3 grid(nblk, d->B);
+    if (mix) { if (render) uniform_bwd_pass1_kernel<true, true><<<grid, kBlock, 0, stream>>>(ak, o, 0, w.tmp, w.part_two, s.padding_mask, nullptr);
+               else        uniform_bwd_pass1_kernel<true, false><<<grid, kBlock, 0, stream>>>(ak, o, 0, w.tmp, w.part_two, s.padding_mask, nullptr); }
+    else     { if (render) uniform_bwd_pass1_kernel<false, true><<<grid, kBlock, 0, stream>>>(ak, o, 0, w.tmp, w.part_two, s.padding_mask, nullptr);
+               else        uniform_bwd_pass1_kernel<false, false><<<grid, kBlock, 0, stream>>>(ak, o, 0, w.tmp, w.part_two, s.padding_mask, nullptr); }
+    rc = check_launch("uniform_bwd_pass1_kernel");
+  }
+  if (rc) return rc;
+  if (g_logits) {
+    rc = uniform_gather_pair(d, a.plane, a.inv_K3, workspace_a, b.plane, b.inv_K3, workspace_b, g_logits, g_sigma, stream);
+    if (rc) return rc;
+  }
+  if (oa.g_plane) uniform_reduce_kernel<<<dim3(kUniG * 9, d->B), kWave, 0, stream>>>(nullptr, 0, wa.part_two, nblk, wa.irregular, oa.g_plane, kUniG * 9);
+  if (ob.g_plane) uniform_reduce_kernel<<<dim3(kUniG * 9, d->B), kWave, 0, stream>>>(nullptr, 0, wb.part_two, nblk, wb.irregular, ob.g_plane, kUniG * 9);
+  return check_launch("uniform_reduce_kernel");
 }
 
 }  // namespace pd

@@ -284,6 +284,10 @@ int tile_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float*
 // Plane-uniform homography (pd_plane_sweep_uniform.hip, PD_HOMO_UNIFORM)
 int uniform_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
 int uniform_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, float* workspace, hipStream_t stream);
+int uniform_fwd_pair(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash,
+                     const SweepArgs& b, float* rgb_rec_b, float* ph_map_b, float* stash_b, hipStream_t stream);
+int uniform_bwd_pair(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& oa, float* workspace_a, const SweepArgs& b,
+                     const BwdOut& ob, float* workspace_b, float* g_logits, float* g_sigma, hipStream_t stream);
 
 // Per-plane homographies (6-DoF poses) without atomics (pd_plane_sweep_gather.hip): pass 1 is sweep_bwd_kernel<.., true>
 // (pd_plane_sweep.hip, launched by the caller between gather_bwd_prepare and gather_bwd_finish).

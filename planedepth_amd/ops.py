@@ -17,6 +17,7 @@ SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 g
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
 PAIR_GATHER = os.environ.get("PD_PAIR_GATHER", "1") != "0"   # two plane-uniform views of a step: their second passes in one kernel
+PAIR_FORWARD = os.environ.get("PD_PAIR_FORWARD", "1") != "0"   # ... and their forwards / first passes in one launch each
 DEBUG_WORKSPACE = None   # diagnostics (tests): set to a list to collect (descriptor, workspace) of every sweep backward
 if int(os.environ.get("PD_DEBUG_POISON_MEM", "0")):
     # diagnostics: every buffer this module allocates uninitialised (outputs, stash, workspaces) starts as NaNs, so a
@@ -142,6 +143,92 @@ def _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_ma
     return (rgb_rec, ph_map, ph_mean), (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)
 
 
+def _sweep_forward_pair(src, logits, sigma, side_a, side_b):
+    """pd_uniform_fwd_pair: two plane-uniform target views (``side_*`` = (tgt, plane, plane_aux, inv_K3, padding_mask, dists,
+    mode, flags, sign) with equal mode / flags / sign) of the same src / logits / sigma in one launch.  Returns what two
+    ``_sweep_forward`` calls return."""
+    global LAST_SWEEP_FLAGS
+    lib = C.load()
+    mode, flags, sign = side_a[6:9]
+    LAST_SWEEP_FLAGS = flags
+    B, N, H, W = logits.shape
+    C.require_gpu_tensor("logits", logits)
+    C.require_gpu_tensor("src", src, (B, 3, H, W))
+    if flags & C.PD_MIXTURE:
+        C.require_gpu_tensor("sigma", sigma, (B, N, H, W))
+    src, logits, sigma = _contig(src), _contig(logits), _contig(sigma)
+    d = _desc(B, N, H, W, mode, flags, sign)
+    k = lib.pd_sweep_stash_floats(ctypes.byref(d)) // (H * W)
+    if ZERO_POOL:
+        d.flags |= C.PD_PH_MEAN_ZEROED
+    views, results = [], []
+    for tgt, plane, plane_aux, inv_K3, padding_mask, dists, _, _, _ in (side_a, side_b):
+        C.require_gpu_tensor("tgt", tgt, (B, 3, H, W))
+        C.require_gpu_tensor("H_t2s", plane, (B, 4, 3, 3))
+        C.require_gpu_tensor("Rn", plane_aux, (B * N, 3))
+        C.require_gpu_tensor("inv_K3", inv_K3, (B, 3, 3))
+        if padding_mask is not None:
+            C.require_gpu_tensor("translation weights", padding_mask, (B, N, 3))
+        if flags & C.PD_RENDER_PROB:
+            C.require_gpu_tensor("dists", dists, (B, N - 1, H, W))
+        else:
+            dists = None
+        tgt, plane, plane_aux, inv_K3, padding_mask, dists = map(_contig, (tgt, plane, plane_aux, inv_K3, padding_mask, dists))
+        rgb_rec = torch.empty(B, 3, H, W, device=logits.device, dtype=torch.float32)
+        ph_map = torch.empty(B, 1, H, W, device=logits.device, dtype=torch.float32)
+        ph_mean = _zero_scalar(logits.device) if ZERO_POOL else torch.empty(1, device=logits.device, dtype=torch.float32)
+        stash = torch.empty(B, k, H, W, device=logits.device, dtype=torch.float32)
+        views.append(C.sweep_view(tgt=tgt, plane=plane, plane_aux=plane_aux, inv_K3=inv_K3, dists=dists, rgb_rec=rgb_rec,
+                                  ph_map=ph_map, ph_mean=ph_mean, stash=stash))
+        results.append(((rgb_rec, ph_map, ph_mean),
+                        (src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash)))
+        if DEBUG_STASH is not None:
+            DEBUG_STASH.append(stash)
+    with C.on_device(logits.device), _timed("fwd"):
+        rc = lib.pd_uniform_fwd_pair(ctypes.byref(d), C.ptr(src), C.ptr(logits), C.ptr(sigma), ctypes.byref(views[0]),
+                                     ctypes.byref(views[1]), C.stream_handle(logits.device))
+    C.check(rc, "pd_uniform_fwd_pair")
+    return results
+
+
+def _sweep_backward_pair(view_a, view_b, cfg, need_a, need_b, g_logits, g_sigma, accumulate):
+    """pd_uniform_bwd_pair: the backward of two plane-uniform views (``view_*`` = (saved tensors, upstream gradients)) of the
+    same logits / sigma — both first passes in one launch, then the pair gather into (``accumulate``: added to)
+    g_logits / g_sigma (None: only the views' own gradients).  Returns ((g_plane_a, g_dists_a), (g_plane_b, g_dists_b))."""
+    lib = C.load()
+    mode, flags, sign = cfg
+    logits = view_a[0][2]
+    B, N, H, W = logits.shape
+    mix = bool(flags & C.PD_MIXTURE)
+    d = _desc(B, N, H, W, mode, flags | C.PD_BWD_DEFER_GATHER | (C.PD_BWD_ACCUMULATE if accumulate else 0), sign)
+    nws = max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1)
+    views, outs, keep = [], [], []
+    for (saved, grads), need in ((view_a, need_a), (view_b, need_b)):
+        src, tgt, _, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash = saved
+        g_rgb_rec, g_ph_map, g_ph_mean = grads
+        g_rgb_rec, g_ph_map = _contig(g_rgb_rec), _contig(g_ph_map)
+        if g_ph_mean is not None:
+            g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
+        g_plane = torch.empty_like(plane) if need[2] else None
+        g_dists = torch.empty_like(dists) if (dists is not None and need[3]) else None
+        ws = torch.empty(nws, device=logits.device, dtype=torch.float32)
+        views.append(C.sweep_view(tgt=tgt, plane=plane, plane_aux=plane_aux, inv_K3=inv_K3, padding_mask=padding_mask,
+                                  dists=dists, rgb_rec=rgb_rec, stash=stash, g_rgb_rec=g_rgb_rec, g_ph_map=g_ph_map,
+                                  g_ph_mean=g_ph_mean, g_plane=g_plane, g_dists=g_dists, workspace=ws))
+        outs.append((g_plane, g_dists))
+        keep.append((g_rgb_rec, g_ph_map, g_ph_mean, ws))   # alive until the call is enqueued
+        if DEBUG_WORKSPACE is not None:
+            DEBUG_WORKSPACE.append((d, ws))
+    src, sigma = view_a[0][0], view_a[0][3]
+    with C.on_device(logits.device), _timed("bwd"):
+        rc = lib.pd_uniform_bwd_pair(ctypes.byref(d), C.ptr(src), C.ptr(logits), C.ptr(sigma), ctypes.byref(views[0]),
+                                     ctypes.byref(views[1]), C.ptr(g_logits), C.ptr(g_sigma if mix else None),
+                                     C.stream_handle(logits.device))
+    C.check(rc, "pd_uniform_bwd_pair")
+    del keep
+    return outs
+
+
 def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=False):
     """pd_plane_sweep_bwd of one target view.  ``need`` = (logits, sigma, plane, dists) gradients wanted; ``into`` =
     (g_logits, g_sigma) buffers to write (or, ``accumulate``: add) into instead of fresh ones.
@@ -245,10 +332,25 @@ class _MultiPlaneSweep(torch.autograd.Function):
     def forward(ctx, src, logits, sigma, *flat):
         n = len(flat) // _PER_SIDE
         outs, tensors, cfgs, layout = [], [], [], []
+        sides = [flat[i * _PER_SIDE:(i + 1) * _PER_SIDE] for i in range(n)]
+        done = {}   # plane-uniform views of equal configuration go through the forward two at a time (pd_uniform_fwd_pair)
+        if PAIR_FORWARD:
+            uni = [i for i in range(n) if sides[i][6] == C.PD_WARP_HOMOGRAPHY and sides[i][7] & C.PD_HOMO_UNIFORM]
+            while len(uni) >= 2:
+                i = uni.pop(0)
+                j = next((q for q in uni if tuple(sides[q][6:9]) == tuple(sides[i][6:9])), None)
+                if j is None:
+                    continue
+                uni.remove(j)
+                done[i], done[j] = _sweep_forward_pair(src, logits, sigma if sides[i][7] & C.PD_MIXTURE else None,
+                                                       sides[i], sides[j])
         for i in range(n):
-            tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign = flat[i * _PER_SIDE:(i + 1) * _PER_SIDE]
-            (rgb_rec, ph_map, ph_mean), saved = _sweep_forward(src, tgt, logits, sigma if flags & C.PD_MIXTURE else None,
-                                                               plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign)
+            tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign = sides[i]
+            if i in done:
+                (rgb_rec, ph_map, ph_mean), saved = done[i]
+            else:
+                (rgb_rec, ph_map, ph_mean), saved = _sweep_forward(src, tgt, logits, sigma if flags & C.PD_MIXTURE else None,
+                                                                   plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign)
             outs += [rgb_rec, ph_map, ph_mean.reshape(())]
             cfgs.append((mode, flags, sign))
             idx = []
@@ -300,8 +402,6 @@ class _MultiPlaneSweep(torch.autograd.Function):
                 j, saved_j, g_j, _ = nxt
                 base_j = 3 + j * _PER_SIDE
                 need_j = (need_logits, need_sigma, ctx.needs_input_grad[base_j + 1], ctx.needs_input_grad[base_j + 5])
-                gp, gd, ws = _sweep_backward(saved, ctx.cfgs[i], g, need, defer=True)
-                gp_j, gd_j, ws_j = _sweep_backward(saved_j, ctx.cfgs[j], g_j, need_j, defer=True)
                 started = g_logits is not None or g_sigma is not None
                 logits = saved[2]
                 mix = bool(ctx.cfgs[i][1] & C.PD_MIXTURE)
@@ -309,10 +409,16 @@ class _MultiPlaneSweep(torch.autograd.Function):
                     g_logits = torch.zeros_like(logits) if started else torch.empty_like(logits)
                 if mix and g_sigma is None:
                     g_sigma = torch.zeros_like(logits) if started else torch.empty_like(logits)
-                _gather_pair((saved, ws), (saved_j, ws_j), ctx.cfgs[i], g_logits, g_sigma, accumulate=started)
-                # the two (g_l, g_s) scratch workspaces (2 x [B,N,H,W,2] floats: 770 MB at 8x49x192x640, twice what sequential
-                # views hold at a time) go back to the allocator now, not when the node's frame dies
-                del ws, ws_j
+                if PAIR_FORWARD:   # both first passes in one launch, the pair gather, the reductions: one call
+                    (gp, gd), (gp_j, gd_j) = _sweep_backward_pair((saved, g), (saved_j, g_j), ctx.cfgs[i], need, need_j,
+                                                                  g_logits, g_sigma, accumulate=started)
+                else:
+                    gp, gd, ws = _sweep_backward(saved, ctx.cfgs[i], g, need, defer=True)
+                    gp_j, gd_j, ws_j = _sweep_backward(saved_j, ctx.cfgs[j], g_j, need_j, defer=True)
+                    _gather_pair((saved, ws), (saved_j, ws_j), ctx.cfgs[i], g_logits, g_sigma, accumulate=started)
+                    # the two (g_l, g_s) scratch workspaces (2 x [B,N,H,W,2] floats: 770 MB at 8x49x192x640, twice what
+                    # sequential views hold at a time) go back to the allocator now, not when the node's frame dies
+                    del ws, ws_j
                 per_view[i], per_view[j] = (gp, gd), (gp_j, gd_j)
                 k += 2
                 continue

@@ -2231,10 +2231,11 @@ _PAIR_CASES = [
 @pytest.mark.parametrize("B,N,H,W,mix,rots,zooms,with_stereo,render",
                          [c + (False,) for c in _PAIR_CASES] + [c + (True,) for c in _PAIR_CASES if c[3] <= 100 and 2 <= c[1] <= 9])
 def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zooms, with_stereo, render, monkeypatch):
-    """pd_uniform_gather_pair (the second passes of the two novel frames of a step in one kernel: one store per gradient
-    element) against the same node with the views' second passes one after the other (PD_PAIR_GATHER=0: read-modify-write
-    per view).  Same contributions added in the same order -> the same bits in g_logits / g_sigma, unless a list overflows
-    the 12 register slots (then the follow-up kernels add those shares last)."""
+    """pd_uniform_fwd_pair / pd_uniform_bwd_pair (the two novel frames of a step: forwards in one launch, first passes in one
+    launch, second passes in one kernel with one store per gradient element) against the same node with the views one
+    after the other (PD_PAIR_FORWARD=0, PD_PAIR_GATHER=0: read-modify-write per view).  The forward's tensors: the same
+    bits (the same arithmetic per view).  Gradients: same contributions added in the same order -> the same bits in
+    g_logits / g_sigma, unless a list overflows the 12 register slots (then the follow-up kernels add those shares last)."""
     from planedepth_amd import ops
     from planedepth_amd.synthetic import intrinsics
     g = torch.Generator().manual_seed(4200 + W + N)
@@ -2252,6 +2253,7 @@ def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zoo
     res = {}
     for pair in (True, False):
         monkeypatch.setattr(ops, "PAIR_GATHER", pair)
+        monkeypatch.setattr(ops, "PAIR_FORWARD", pair)
         lg, sg = logits.clone().requires_grad_(True), sigma.clone().requires_grad_(True)
         Rts = []
         calls = []
@@ -2272,13 +2274,16 @@ def test_two_plane_uniform_views_gather_in_one_kernel(B, N, H, W, mix, rots, zoo
         loss.backward()
         res[pair] = dict(g_logits=lg.grad.cpu(), g_sigma=sg.grad.cpu() if mix else torch.zeros(1),
                          g_Rt0=Rts[0].grad.cpu(), g_Rt1=Rts[1].grad.cpu())
+        for i, o in enumerate(outs):
+            res[pair].update({"rgb_rec%d" % i: o[0].detach().cpu(), "ph_map%d" % i: o[1].detach().cpu(),
+                              "ph_mean%d" % i: o[2].detach().cpu()})
     a, b = res[True], res[False]
     assert float(b["g_logits"].abs().max()) > 0
     exact = max(zooms) == 1.0
     for k in a:
-        if exact and not k.startswith("g_Rt"):    # (the pose gradients pass through torch's own reductions)
+        if k.startswith(("rgb_rec", "ph_map")) or (exact and k.startswith(("g_logits", "g_sigma"))):
             assert torch.equal(a[k], b[k]), (k, rel_err(a[k], b[k]))
-        else:
+        else:    # the pose gradients pass through torch's own reductions; ph_mean is a sum of atomics in arrival order
             assert rel_err(a[k], b[k]) < 2e-6, (k, rel_err(a[k], b[k]))
 
 
