@@ -169,8 +169,7 @@ def build_step(args, c, device):
         if dists is not None:
             dists.grad = None
         if dense_disp is not None:
-            dense_disp.grad = None
-            disp_layered = dense_disp
+            disp_layered = _DecoderSide.apply(dense_disp)
         else:
             disp_layered = disp_pp.expand(-1, -1, H, W)
         outputs = {"probability": shape_probe, "logits": logits, "sigma": sigma,
@@ -190,6 +189,22 @@ def build_step(args, c, device):
         return heads[0]
 
     return step, (logits, sigma, disp_pp, distance)
+
+
+class _DecoderSide(torch.autograd.Function):
+    """The decoder's side of ``outputs["disp_layered"]`` in the --xz_levels configuration: hands the dense map over as the
+    non-leaf tensor it is in the trainer (depth_decoder.py:182, a cat) and takes the path's gradient without doing anything
+    with it — the decoder's backward is not part of the path, just as no backward of the networks runs behind
+    logits.grad / sigma.grad.  (As a LEAF the map would make autograd's AccumulateGrad clone the path's stride-0 gradient
+    into 248 MB of memory per step, which no trainer does.)"""
+
+    @staticmethod
+    def forward(ctx, dense):
+        return dense.view_as(dense)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
 
 
 def algorithmic_bytes(args):

@@ -482,6 +482,25 @@ def _per_plane_view(disp_layered):
     return disp_layered[:, :, 0, 0]
 
 
+class _FirstColumn(torch.autograd.Function):
+    """``dense[..., 0]`` of a [B,N,H,W] map that is constant along x by the caller's promise (``row_uniform``: xy and xz
+    planes, networks/depth_decoder.py:153-181) -> contiguous [B,N,H].
+
+    Backward: the row's gradient goes back as ``g / W`` on EVERY column, as an expanded (stride-0) view — whatever built
+    the map from x-independent quantities (the decoder's ``expand`` / its y-grid formula) sums over x and receives exactly
+    ``g``.  A plain ``dense[..., 0]`` hands autograd a SelectBackward that zero-fills a [B,N,H,W] tensor per step to carry one
+    column (248 MB at 8x63x192x640: 0.037 ms next to a 0.38 ms path) and makes that expand-backward read it all."""
+
+    @staticmethod
+    def forward(ctx, dense):
+        ctx.W = dense.shape[-1]
+        return dense[..., 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * (1.0 / ctx.W)).unsqueeze(-1).expand(*g.shape, ctx.W)
+
+
 def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *, target_side="r",
                      use_mixture_loss=True, automask=False, render_probability=False, dists=None, row_uniform=False,
                      return_mean=False, defer=False, _rows=None):
@@ -518,7 +537,7 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     elif row_uniform:
         probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS, 1.0, SWEEP_IMPL)
         rows = bool(C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)))
-        plane = disp_layered[..., 0] if rows else disp_layered
+        plane = _FirstColumn.apply(disp_layered) if rows else disp_layered
     else:
         plane = disp_layered
     if padding_mask is not None and padding_mask.dtype != torch.float32:

@@ -137,3 +137,31 @@ def test_lazy_layers_is_safe_to_copy_and_reports_metadata_without_materialising(
         pass
     else:
         raise AssertionError("private names must not be forwarded")
+
+
+def test_first_column_hands_the_decoder_the_row_gradient_without_a_dense_zero_fill():
+    """ops._FirstColumn (the [B,N,H] rows of a map that is constant along x by the caller's promise): same values as
+    ``dense[..., 0]``, and the same gradient for whatever built the map from x-independent quantities (the decoder's
+    expand of per-plane scalars, its y-grid formula for the xz planes), but carried by a stride-0 view instead of a
+    zero-filled [B,N,H,W] tensor."""
+    import torch
+    from planedepth_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, N, H, W = 2, 5, 7, 12
+    gain = 1.0 + torch.rand(1, N, H, 1, generator=g)
+    weight = torch.randn(B, N, H, generator=g)
+    grads = {}
+    for name in ("select", "first_column"):
+        p = torch.rand(B, N, 1, 1, generator=torch.Generator().manual_seed(6)).requires_grad_(True)   # per-plane scalars
+        q = torch.rand(B, N, H, 1, generator=torch.Generator().manual_seed(7)).requires_grad_(True)   # a y-dependent term
+        dense = p.expand(B, N, H, W) * gain + q.expand(B, N, H, W)
+        rows = dense[..., 0] if name == "select" else ops._FirstColumn.apply(dense)
+        assert tuple(rows.shape) == (B, N, H) and (name == "select" or rows.is_contiguous())
+        (rows * weight).sum().backward()
+        grads[name] = (p.grad.clone(), q.grad.clone(), rows.detach().clone())
+    for a, b in zip(grads["select"], grads["first_column"]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    probe = torch.rand(B, N, H, W, generator=g).requires_grad_(True)
+    out = ops._FirstColumn.apply(probe)
+    gin, = torch.autograd.grad(out.sum(), probe)
+    assert gin.stride(-1) == 0     # nothing [B,N,H,W]-sized was written
