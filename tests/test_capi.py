@@ -78,6 +78,18 @@ def test_argument_validation_needs_no_gpu():
     d.flags |= C.PD_BWD_DEFER_GATHER
     assert lib.pd_uniform_gather_pair(ctypes.byref(d), *([None] * 9)) == 1
     assert b"NULL" in lib.pd_last_error()
+    # round 4: the pair entry points take two pd_sweep_view structs over one src / logits / sigma, plane-uniform views only
+    d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_HOMOGRAPHY, C.PD_MIXTURE | C.PD_HOMO_UNIFORM, 0.0, 0)
+    va, vb = C.sweep_view(), C.sweep_view()
+    assert ctypes.sizeof(C.SweepView) == 16 * ctypes.sizeof(ctypes.c_void_p)
+    assert lib.pd_uniform_fwd_pair(ctypes.byref(d), None, None, None, None, None, None) == 1
+    assert b"NULL" in lib.pd_last_error()
+    assert lib.pd_uniform_fwd_pair(ctypes.byref(d), None, None, None, ctypes.byref(va), ctypes.byref(vb), None) == 1
+    assert b"NULL" in lib.pd_last_error()
+    assert lib.pd_uniform_bwd_pair(ctypes.byref(d), None, None, None, ctypes.byref(va), ctypes.byref(vb), None, None, None) == 1
+    d.flags = C.PD_MIXTURE
+    assert lib.pd_uniform_fwd_pair(ctypes.byref(d), None, None, None, ctypes.byref(va), ctypes.byref(vb), None) == 1
+    assert b"PD_HOMO_UNIFORM" in lib.pd_last_error()
     d = C.SweepDesc(1, 4, 8, 8, C.PD_WARP_HOMOGRAPHY, C.PD_MIXTURE | C.PD_BWD_DEFER_GATHER, 0.0, 0)   # without PD_HOMO_UNIFORM
     assert lib.pd_plane_sweep_bwd(ctypes.byref(d), *([None] * 20)) == 1
     assert lib.pd_debug_gather_flags(ctypes.byref(d), None, None, None) == 1
