@@ -875,7 +875,13 @@ def main():
                    "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
                    "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
                    "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
-                   if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask"},
+                   if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask",
+                   # what the timed step contains changed between rounds for the non-default configurations: compare like with like
+                   "workload_version": 4,
+                   "workload_changes": {"3": "homography_warp: outputs['distance'] is handed over as the decoder's leaf tensor instead of "
+                                             "being re-derived from the disparities inside the timed step (was 10-15 % of such a step)",
+                                        "4": "--xz_levels: outputs['disp_layered'] is handed over as the decoder's non-leaf dense map; the path "
+                                             "returns its gradient as a stride-0 view (no [B,N,H,W] zero fill / clone inside the step)"}},
     }
     if world > 1:
         import torch.distributed as dist
