@@ -404,7 +404,7 @@ def next_rows_times(args, device, iters=100):
     t_f, t_fb, t_s, t_p = timed(tail_fwd), timed(tail_fwd_bwd), timed(smooth_fwd_bwd), timed(post)
     t_pl = timed(plade_fwd_bwd)
     t_r = timed(reproj_fwd_bwd)
-    g_s, g_r = timed_graph(smooth_fwd_bwd), timed_graph(reproj_fwd_bwd)
+    g_s, g_r, g_pl = timed_graph(smooth_fwd_bwd), timed_graph(reproj_fwd_bwd), timed_graph(plade_fwd_bwd)
     hw4 = H * W * 4
     tail_f_bytes, tail_b_bytes = (3 * N + 4) * hw4 * B, (6 * N + 4) * hw4 * B
     post_bytes = (2 * (2 * N) + 2 * N + N + 3) * hw4 * Bp   # 2 warp-softmax (read N, write N) + 3 warp-sums (read N)
@@ -414,16 +414,18 @@ def next_rows_times(args, device, iters=100):
                          "fwd_bwd_GBs": round((tail_f_bytes + tail_b_bytes) / (t_fb * 1e-3) / 1e9, 1),
                          "shape": [B, N, H, W]},
         # fwd reads 2N-1, writes 3N-1 (+3) planes; bwd reads 2N-1 + 3N-1 (+5), writes 2N-1
-        "plade_tail_render": {"fwd_bwd_ms": round(t_pl, 4),
-                              "fwd_bwd_GBs": round((12 * N - 4 + 8) * hw4 * B / (t_pl * 1e-3) / 1e9, 1), "shape": [B, N, H, W]},
+        "plade_tail_render": {"fwd_bwd_ms": round(t_pl, 4), "fwd_bwd_device_ms": g_pl,
+                              "fwd_bwd_GBs": round((12 * N - 4 + 8) * hw4 * B / ((g_pl if isinstance(g_pl, float) else t_pl) * 1e-3) / 1e9, 1),
+                              "shape": [B, N, H, W]},
         "smooth_loss": {"fwd_bwd_ms": round(t_s, 4), "fwd_bwd_device_ms": g_s, "shape": [B, 1, H, W - x0]},
         "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "fwd_bwd_device_ms": g_r, "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
                          "shape": [2 * Bp, N, H, W]},
         "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot (host-paced "
-                "where the Python / autograd overhead exceeds the kernels' time: fwd_bwd_ms of the two small operators is the "
-                "box's CPU speed, 0.05-0.16 ms across boxes; fwd_bwd_device_ms is the same call replayed from a HIP graph, "
-                "i.e. the device's share)" % iters,
+                "where the Python / autograd overhead exceeds the kernels' time: fwd_bwd_ms of the two small operators and of "
+                "the PladeNet tail (ten small torch launches for its per-plane disparities around the two kernels) is the "
+                "box's CPU speed; fwd_bwd_device_ms is the same call replayed from a HIP graph, i.e. the device's share, and "
+                "what plade_tail_render's GB/s is computed from)" % iters,
     }
 
 
