@@ -933,10 +933,25 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
     if not args.no_ddp_step and args.warp_type == "disp_warp" and not args.xz_levels:
+        # The headline line must not die with the secondary block — neither by an exception nor by a collective that never
+        # returns (a rank that failed while the others wait in an all-reduce: RCCL's watchdog would abort the process before
+        # anything is printed).  A timer thread prints the line without the block and ends the process if it overruns.
+        import threading
+
+        def bail():
+            if rank == 0:
+                result["ddp_step"] = {"error": "timed out after %d s (PD_DDP_STEP_TIMEOUT_S)" % limit}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        limit = int(os.environ.get("PD_DDP_STEP_TIMEOUT_S", "150"))
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
         try:   # every rank takes part (DDP's collectives); rank 0 reports
             blk = ddp_step_block(args, device, rank, world)
-        except Exception as e:  # the headline line must not die with the secondary block
+        except Exception as e:
             blk = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        timer.cancel()
         if rank == 0:
             result["ddp_step"] = blk
     if rank == 0:
