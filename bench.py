@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--xz_levels", type=int, default=0,
                     help="reference option: 0 (BASELINE's '49 planes') lets the path skip the decoder's all-ones padding "
                          "mask; >0 feeds it as a dense [B,N,H,W] tensor like the decoder with ground planes does")
+    ap.add_argument("--yz_levels", type=int, default=0,
+                    help="append K yz (vertical-wall) planes: disparities that vary along x and half-image masks "
+                         "(depth_decoder.py:209-252) — a genuinely dense [B,N,H,W] map: the general forward + the row-dense backward")
     ap.add_argument("--no_padding_mask", action="store_true", help="never pass a padding mask (diagnostics)")
     ap.add_argument("--no_plane_grad", action="store_true", help="diagnostics: disparities do not require grad")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -89,8 +92,8 @@ def parse():
 def make_batch(args, device, seed):
     from planedepth_amd.synthetic import survey_fullsize_case
     torch.manual_seed(seed)
-    c = survey_fullsize_case(B=args.batch, N=args.planes + args.xz_levels, H=args.height, W=args.width,
-                             seed=1234 + seed, n_xz=args.xz_levels)
+    c = survey_fullsize_case(B=args.batch, N=args.planes + args.xz_levels + args.yz_levels, H=args.height, W=args.width,
+                             seed=1234 + seed, n_xz=args.xz_levels + args.yz_levels)
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in c.items()}
 
 
@@ -122,7 +125,7 @@ def build_step(args, c, device):
     opt = types.SimpleNamespace(warp_type=args.warp_type, match_aug=False, use_mixture_loss=mix, automask=args.automask,
                                 render_probability=bool(args.render_probability), alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
                                 gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, materialize_layers=False,
-                                xz_levels=args.xz_levels, yz_levels=0)
+                                xz_levels=args.xz_levels, yz_levels=args.yz_levels)
     zero = torch.zeros((), device=device)
     # --mono_pose: the target is a novel frame (-1), whose pose predict_poses builds without translation -> the
     # plane-uniform kernels; --colmap_pose: a novel frame with a translation (opt.use_colmap) -> the general kernels
@@ -159,10 +162,18 @@ def build_step(args, c, device):
     if args.render_probability:
         dists = (torch.rand(B, N - 1, H, W, generator=torch.Generator().manual_seed(5)) * 2.0).to(device).requires_grad_(True)
     dense_disp = None
-    if args.xz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182): that is
+    if args.xz_levels or args.yz_levels:  # the decoder cat()s xy and xz planes into a dense [B,N,H,W] map (depth_decoder.py:182): that is
         # decoder work, so it is built ONCE here and handed to the path as the decoder would hand it over (a dense
         # tensor that wants a gradient), not re-materialised inside the timed step
-        dense_disp = (disp_pp.detach().expand(-1, -1, H, W) * c["row_gain"]).contiguous().requires_grad_(not args.no_plane_grad)
+        dense_disp = (disp_pp.detach().expand(-1, -1, H, W) * c["row_gain"]).contiguous()
+        if args.yz_levels:   # the last K planes as vertical walls: disparity linear in x, visible on one half of the image each
+            K = args.yz_levels
+            xr = torch.linspace(-1.0, 1.0, W, device=device)[None, None, None, :]
+            dense_disp[:, N - K:] = dense_disp[:, N - K:, :1, :1] * (0.05 + xr.abs())
+            pm_arg = pm_arg.clone() if torch.is_tensor(pm_arg) else torch.ones(B, N, H, W, device=device)
+            pm_arg[:, N - K:N - K // 2] = (xr >= 1e-7).float()
+            pm_arg[:, N - K // 2:] = (xr <= -1e-7).float()
+        dense_disp.requires_grad_(not args.no_plane_grad)
 
     def step():
         logits.grad = sigma.grad = disp_pp.grad = None
@@ -210,7 +221,7 @@ class _DecoderSide(torch.autograd.Function):
 def algorithmic_bytes(args):
     """per image per target side, fp32.  mixture: fwd (2N+9) HW 4, bwd (4N+9) HW 4."""
     HW = args.height * args.width
-    N = args.planes + args.xz_levels
+    N = args.planes + args.xz_levels + args.yz_levels
     k = 2 if not args.no_mixture else 1
     fwd = (k * N + 9) * HW * 4
     bwd = (2 * k * N + 9) * HW * 4
@@ -223,7 +234,7 @@ def kernel_times(args, c, device, iters):
     lib = C.load()
     B, N, H, W = c["logits"].shape
     mix = not args.no_mixture
-    if args.xz_levels or args.render_probability:
+    if args.xz_levels or args.yz_levels or args.render_probability:
         return None  # direct-launch timing is wired for the xy-plane softmax configurations only
     if args.warp_type == "homography_warp" and (args.mono_sides or not (args.mono_pose or args.colmap_pose or args.general_stereo)):
         return None  # stereo target: runs as per-row shifts on the row-shift kernels; the in-step events time those
@@ -674,7 +685,7 @@ def measured_traffic(args, kernel):
             t = json.load(f)
         w = t["workload"]
         same = (w["batch"] == args.batch and w["planes"] == args.planes and w["height"] == args.height and
-                w["width"] == args.width and w["mixture"] == (not args.no_mixture) and args.xz_levels == 0 and
+                w["width"] == args.width and w["mixture"] == (not args.no_mixture) and args.xz_levels == 0 and args.yz_levels == 0 and
                 not args.automask and args.warp_type == "disp_warp")
         if not same:
             return None, "no PMC pass committed for this workload"
@@ -873,11 +884,11 @@ def main():
                                % (args.warp_type, "target_sides ['r', -1, 1]: stereo + two pose_net frames, 3 sweeps per image" if args.mono_sides else "mono pose (pose_net: rotation only, F8)" if args.mono_pose
                                   else ("colmap pose (rotation + translation)" if args.colmap_pose else
                                         ("stereo target r" + (" as per-row shifts (row-shift kernels)" if args.warp_type == "homography_warp" and not args.general_stereo else ""))), "L1" if args.no_mixture else "Laplacian-mixture", args.batch,
-                                  args.height, args.width, args.planes + args.xz_levels),
-                   "global_batch": args.batch * world, "planes": args.planes + args.xz_levels, "height": args.height,
-                   "width": args.width, "xz_levels": args.xz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+                                  args.height, args.width, args.planes + args.xz_levels + args.yz_levels),
+                   "global_batch": args.batch * world, "planes": args.planes + args.xz_levels + args.yz_levels, "height": args.height,
+                   "width": args.width, "xz_levels": args.xz_levels, "yz_levels": args.yz_levels, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
                    "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
-                   if (args.no_padding_mask or args.xz_levels == 0) else "decoder's dense [B,N,H,W] float mask",
+                   if (args.no_padding_mask or args.xz_levels + args.yz_levels == 0) else "decoder's dense [B,N,H,W] float mask",
                    # what the timed step contains changed between rounds for the non-default configurations: compare like with like
                    "workload_version": 4,
                    "workload_changes": {"3": "homography_warp: outputs['distance'] is handed over as the decoder's leaf tensor instead of "
@@ -932,7 +943,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
-    if not args.no_ddp_step and args.warp_type == "disp_warp" and not args.xz_levels:
+    if not args.no_ddp_step and args.warp_type == "disp_warp" and not (args.xz_levels or args.yz_levels):
         # The headline line must not die with the secondary block — neither by an exception nor by a collective that never
         # returns (a rank that failed while the others wait in an all-reduce: RCCL's watchdog would abort the process before
         # anything is printed).  A timer thread prints the line without the block and ends the process if it overruns.
