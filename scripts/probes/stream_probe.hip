@@ -53,6 +53,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void stream(const float* __restric
   extern __shared__ v4f lds[];
   const int RS = W + 4;                 // ctx rows with guard cells
   v4f* c0 = lds; v4f* c1 = lds + RS; v4f* col = lds + 2 * RS; v2f* c2 = reinterpret_cast<v2f*>(lds + 3 * RS);
+  // MODE & 8 (VERDICT r3 #1c): a softmax / mixture state of six floats per TARGET cell and wave, kept in LDS and updated
+  // by read-modify-write at the shifted cell while the wave walks plane rows in SOURCE order (merged once per row in a real kernel)
+  v4f* st0 = lds + 4 * RS; v2f* st1 = reinterpret_cast<v2f*>(lds + 4 * RS + WAVES * RS);
+  if (MODE & 8) {
+    for (int x = threadIdx.x; x < WAVES * RS; x += blockDim.x) { st0[x] = v4f{0, 0, 0, 0}; st1[x] = v2f{0, 0}; }
+  }
   const int id = blockIdx.x;            // row-major over images: rows of all images, image fastest
   const int b = id % Bn, y = id / Bn;
   const long HW = (long)H * W;
@@ -124,6 +130,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void stream(const float* __restric
       la = c1v; lb = d1v;
       acc += r;
     }
+    if (MODE & 8) {
+      const int k = __builtin_amdgcn_readfirstlane(kshift[b * N + n]);
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int xt = min(max(xs + i - k, -1), W) + 2 + wave * RS;
+        v4f a0 = st0[xt]; v2f a1 = st1[xt];
+        a0 += v4f{oa[i], ob[i], la, lb}; a1 += v2f{oa[i] * 0.5f, ob[i] * 0.5f};
+        st0[xt] = a0; st1[xt] = a1;
+      }
+    }
     // lane's first slot also receives the previous lane's last right-hand contribution (lane 0: the carried one)
     const float pa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_a), __float_as_int(la), 0x138, 0xF, 0xF, false));
     const float pb = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_b), __float_as_int(lb), 0x138, 0xF, 0xF, false));
@@ -179,13 +195,14 @@ template <class F> static double time_ms(F f, int iters = 20) {
 
 static float *A, *Bt, *GA, *GB, *out, *ctx; static int* ks;
 template <int P, int D, int K, int MODE, int WAVES = 4, int OCC = 4> static void run(int B, int N, int H, int W) {
-  const size_t ldsb = (size_t)(W + 4) * (3 * 16 + 8);
+  const size_t ldsb = (size_t)(W + 4) * (3 * 16 + 8) + ((MODE & 8) ? (size_t)(W + 4) * 8 + (size_t)WAVES * (W + 4) * 24 : 0);
+  if (ldsb > 160 * 1024) { printf("W=%4d P=%d D=%d K=%3d waves=%d: %zu bytes of LDS do not fit a CU — skipped\n", W, P, D, K, WAVES, ldsb); return; }
   CK(hipFuncSetAttribute((const void*)stream<P, D, K, MODE, WAVES, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
   const double ms = time_ms([&] { stream<P, D, K, MODE, WAVES, OCC><<<dim3(H * B), WAVES * 64, ldsb>>>(A, Bt, GA, GB, ctx, ks, out, N, H, W, B); });
   CK(hipGetLastError());
   const double bytes = (double)B * H * W * 4 * (((MODE & 1) ? 2 * N : 0) + ((MODE & 2) ? 2 * N : 0) + 13);
-  printf("W=%4d P=%d D=%d K=%3d waves=%d occ=%d %s%s%s  %7.3f ms  %7.1f GB/s\n", W, P, D, K, WAVES, OCC, (MODE & 1) ? "L" : "-", (MODE & 2) ? "S" : "-",
-         (MODE & 4) ? "C" : "-", ms, bytes / 1e9 / (ms * 1e-3));
+  printf("W=%4d P=%d D=%d K=%3d waves=%d occ=%d %s%s%s%s lds=%zu  %7.3f ms  %7.1f GB/s\n", W, P, D, K, WAVES, OCC, (MODE & 1) ? "L" : "-", (MODE & 2) ? "S" : "-",
+         (MODE & 4) ? "C" : "-", (MODE & 8) ? "R" : "-", ldsb, ms, bytes / 1e9 / (ms * 1e-3));
 }
 
 
@@ -395,6 +412,12 @@ int main(int argc, char** argv) {
     run<2, 4, 0, 1, 8, 4>(B, N, H, W); run<2, 6, 0, 1, 8, 4>(B, N, H, W);
     run<1, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2>(B, N, H, W); run<4, 2, 0, 2>(B, N, H, W); run<2, 2, 0, 2, 8, 4>(B, N, H, W);
     run<2, 2, 0, 3, 8, 4>(B, N, H, W); run<4, 2, 0, 3, 8, 4>(B, N, H, W); run<2, 4, 0, 3, 8, 4>(B, N, H, W);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 's') {   // VERDICT r3 #1c: source-ordered forward with the softmax state in LDS (R) against loads alone
+    run<2, 3, 0, 1, 4, 4>(B, N, H, W); run<2, 3, 0, 9, 4, 4>(B, N, H, W); run<2, 3, 40, 9, 4, 4>(B, N, H, W); run<2, 3, 40, 13, 4, 4>(B, N, H, W);
+    run<2, 3, 0, 1, 8, 4>(B, N, H, W); run<2, 3, 0, 9, 8, 4>(B, N, H, W); run<2, 3, 40, 9, 8, 4>(B, N, H, W); run<2, 3, 40, 13, 8, 4>(B, N, H, W);
+    run<4, 2, 40, 9, 4, 4>(B, N, H, W); run<4, 2, 40, 9, 8, 4>(B, N, H, W); run<2, 3, 40, 9, 2, 4>(B, N, H, W); run<1, 4, 40, 9, 4, 4>(B, N, H, W);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'r') {   // forward shape, R rows per wave (five waves = one segment each; W = 640)
