@@ -938,6 +938,33 @@ def main():
                 "bwd_frac_of_peak": round(bwd_b * args.batch / (kt["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if iso:
                 result["kernels"].update(isolated_fwd_ms=round(iso["fwd"], 4), isolated_bwd_ms=round(iso["bwd"], 4))
+        if world == 1 and args.warp_type == "disp_warp" and not args.no_next_rows:
+            # The opt-in approximation next to the reported (exact) number: PD_IMPL_FAST_ROWS drops the second source row of the
+            # rows whose y round trip is inexact (weight eps <= 8e-6) in forward and backward — all the traffic the headline
+            # kernels move above the algorithmic bytes.  Both legs eager, same process, same tensors: like for like.
+            from planedepth_amd import ops as _ops, _capi as _C
+
+            def eager_rate(n=60):
+                for _ in range(10):
+                    eager_step()
+                torch.cuda.synchronize(device)
+                t = time.perf_counter()
+                for _ in range(n):
+                    eager_step()
+                torch.cuda.synchronize(device)
+                return args.batch * n / (time.perf_counter() - t)
+            prev = _ops.SWEEP_IMPL
+            try:
+                r_exact = eager_rate()
+                _ops.SWEEP_IMPL = _C.PD_IMPL_FAST_ROWS
+                r_fast = eager_rate()
+            finally:
+                _ops.SWEEP_IMPL = prev
+            result["fast_rows_option"] = {
+                "images_per_sec": round(r_fast, 1), "exact_images_per_sec_same_leg": round(r_exact, 1),
+                "ratio": round(r_fast / r_exact, 4),
+                "what": "PD_SWEEP_IMPL=2 / pd_sweep_desc.impl = PD_IMPL_FAST_ROWS: an approximation inside the 1e-4 parity bar (samples move by "
+                        "<= 8e-6 of the neighbour row's difference), NOT the default and not `value`; eager launches, 60 steps each"}
         if world == 1 and not args.no_next_rows:
             result["next_rows"] = next_rows_times(args, device)
         if world == 1 and not args.no_cpu_baseline:
