@@ -149,10 +149,25 @@ def build_step(args, c, device):
     # gradient, handed to the path as the decoder hands it over — not re-derived from the disparities inside the timed step
     # (that was ten 2-5 us launches of decoder arithmetic and its autograd per step: 10-15 % of a homography step)
     distance = (0.1 * 0.58 * W / disp_pp.detach()[:, :, 0, 0]).contiguous().requires_grad_(not args.no_plane_grad)
+    decoder_geometry = None
+    if args.warp_type == "homography_warp" and args.xz_levels and not args.yz_levels:
+        # SURVEY.md 8d D-inputs (4): the reference decoder's own plane set — `planes` xy planes + `xz_levels` ground planes with
+        # their normals [0, 1, t] / |.| and distances h / |.| (networks/depth_decoder.py:158-207), the horizon mask from
+        # grid = linspace(-1, 1) (the Resize grid, pair_transforms.py:63-64) multiplied into the logits as the decoder does
+        # (:255-256), level residuals as in C-golden (rand - 0.5)
+        from planedepth_amd.synthetic import crop_grid, decoder_plane_geometry
+        grid = crop_grid(H, W, H, W, 0, 0)[None].expand(B, -1, -1, -1).to(device)
+        res = (torch.rand(B, N, generator=torch.Generator().manual_seed(4242)) - 0.5).to(device)
+        decoder_geometry = decoder_plane_geometry(grid, res, no_levels=args.planes, xz_levels=args.xz_levels, rows=True)
+        norm = decoder_geometry["norm"].contiguous()
+        distance = decoder_geometry["distance"].contiguous().requires_grad_(not args.no_plane_grad)
+        logits = (c["logits"] * decoder_geometry["padding_mask"]).contiguous().requires_grad_(True)
     shape_probe = torch.empty(B, N, H, W, device="meta")
     g_rgb = c["g_rgb_rec"]
     one = torch.ones((), device=device)  # d loss / d ph_loss
     pm = None if args.no_padding_mask else c["padding_mask"]
+    if decoder_geometry is not None and pm is not None:   # (homography_warp computes its own facing mask; the decoder's mask is
+        pm = decoder_geometry["padding_mask"].expand(-1, -1, -1, W)   # still part of `outputs`, constant along x: an expand view)
     if pm is None:
         pm_arg = None
     else:
@@ -849,7 +864,10 @@ def main():
         t_eager, t_graph = min(t_eager, probe(eager_step)), min(t_graph, probe(graph_step))
         # every rank must take the same decision (the ranks meet in the timing barrier): the slowest rank's view decides
         t_eager, t_graph = parallel.max_over_ranks(t_eager, device), parallel.max_over_ranks(t_graph, device)
-        launch_probe = {"eager_ms_per_step": round(t_eager, 4), "graph_ms_per_step": round(t_graph, 4), "steps_each": 2 * 31}
+        # both forms are always in the line (`value` must not switch methodology silently between boxes or rounds)
+        launch_probe = {"eager_ms_per_step": round(t_eager, 4), "graph_ms_per_step": round(t_graph, 4), "steps_each": 2 * 31,
+                        "eager_images_per_sec": round(args.batch * world / (t_eager * 1e-3), 1),
+                        "graph_images_per_sec": round(args.batch * world / (t_graph * 1e-3), 1)}
         step = graph_step if t_graph < t_eager else eager_step
     used_graph = step is not eager_step
     pre_timed["hip_graph_capture_steps"] = 4 if graph_step is not None else 0
@@ -978,17 +996,23 @@ def main():
 
         def bail():
             if rank == 0:
-                result["ddp_step"] = {"error": "timed out after %d s (PD_DDP_STEP_TIMEOUT_S)" % limit}
+                result["ddp_step_timed_out"] = True      # top level: a hang of the secondary block must not hide inside it
+                result["ddp_step"] = {"error": "timed out after %d s (PD_DDP_STEP_TIMEOUT_S): the secondary DDP training-step "
+                                               "block hung (a collective that never returned?); `value` above was measured "
+                                               "before it and is complete" % limit}
                 print(json.dumps(result), flush=True)
             os._exit(0)
         limit = int(os.environ.get("PD_DDP_STEP_TIMEOUT_S", "150"))
         timer = threading.Timer(limit, bail)
         timer.daemon = True
         timer.start()
+        result["ddp_step_timed_out"] = False
+        result["ddp_step_failed"] = False
         try:   # every rank takes part (DDP's collectives); rank 0 reports
             blk = ddp_step_block(args, device, rank, world)
         except Exception as e:
             blk = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            result["ddp_step_failed"] = True
         timer.cancel()
         if rank == 0:
             result["ddp_step"] = blk

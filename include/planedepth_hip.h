@@ -13,7 +13,10 @@
  *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous;
  *   - every function returns PD_OK (0) or a PD_ERR_* code; pd_last_error() returns a
  *     thread-local human-readable message for the last non-zero return on this thread;
- *   - no global mutable state: safe to call from any thread (e.g. the autograd thread).  The few process-environment
+ *   - safe to call from any thread (e.g. the autograd thread) and for any device: the entry points work on the CURRENT
+ *     device (hipSetDevice / torch.cuda.device by the caller) and keep nothing between calls except per-device caches of
+ *     device facts — the LDS a workgroup can be given, the dynamic-LDS limit already granted to a kernel — held in
+ *     atomics indexed by the device ordinal (the rare raise is serialised by a mutex).  The few process-environment
  *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS) are read ONCE, when the library is first
  *     used, never on the launch path; kernel selection per call goes through pd_sweep_desc.impl.
  */
@@ -110,7 +113,16 @@ enum pd_sweep_impl {
   PD_IMPL_UNIFORM_DIRECT = 5 /* as AUTO, but pass 2 of the two-pass homography backwards (plane-uniform and per-plane) gathers
                             directly from the scratch instead of staging it through LDS (the form large boxes fall back
                             to anyway): cross-check */
+  ,
+  PD_IMPL_EXACT_ROWS = 6 /* as AUTO, with every second source row served whatever its weight: the reference's last-ulp row
+                            weights (the y round trip of trainer.py:552 + grid_sample returns y + e, |e| <= 6e-6, on a
+                            quarter of the rows at H = 192).  What AUTO itself does about those rows is stated at
+                            PD_IMPL_AUTO / pd_sweep_auto_fast_rows() */
 };
+
+/* The bilinear weight below which PD_IMPL_AUTO (and the impls documented "as AUTO") drops a second source row: 0 = never
+ * (as PD_IMPL_EXACT_ROWS); PD_IMPL_FAST_ROWS uses 2^-16. */
+float pd_sweep_auto_row_eps(void);
 
 typedef struct pd_sweep_desc {
   int32_t B, N, H, W;

@@ -21,6 +21,7 @@ PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
 PD_HMAT_PLANES, PD_HMAT_UNIFORM, PD_HMAT_STEREO_ROWS = 0, 1, 2
 PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1, PD_IMPL_UNIFORM_DIRECT = 0, 1, 2, 3, 4, 5
+PD_IMPL_EXACT_ROWS = 6
 
 
 class SweepDesc(ctypes.Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_source_hash": (ctypes.c_char_p, []),
     "pd_sweep_uses_rowshift": (_I, [_D]),
+    "pd_sweep_auto_row_eps": (_F, []),
     "pd_sweep_bwd_accumulates": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
     "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "planedepth_hip.h"
 
 namespace pd {
@@ -27,13 +30,21 @@ struct Switches {
 };
 const Switches& switches();
 
-// LDS a workgroup of this device can be given (bytes; queried once per process: hipDeviceAttributeMaxSharedMemoryPerMultiprocessor,
-// 160 KB on gfx950, which is also the answer when there is no device to ask).  The kernels' applicability tests use it instead of a constant, so a device or partition with less falls
-// back to a kernel that fits instead of failing at launch.
+// LDS a workgroup of the CURRENT device can be given (bytes: hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, 160 KB on
+// gfx950, which is also the answer when there is no device to ask).  Queried once per device ordinal and kept in an atomic
+// slot of a per-device table: a process that drives several GPUs (or several threads on one) gets each device's own answer.
+// The kernels' applicability tests use it instead of a constant, so a device or partition with less falls back to a kernel
+// that fits instead of failing at launch.
 size_t device_lds_bytes();
-// Raise a kernel's dynamic-LDS limit to `bytes` if it is above what was granted before (*granted: one static per kernel
-// instantiation, starts at 64 KB); PD_OK, or PD_ERR_UNSUPPORTED with the error text set.  Not on the hot path after the first call.
-int grant_dynamic_lds(const void* kernel, size_t bytes, size_t* granted, const char* what);
+// Dynamic-LDS limit of one kernel instantiation, per device ordinal (0 = the 64 KB every kernel starts with).
+constexpr int kMaxDevices = 64;
+struct LdsGrant {
+  std::atomic<size_t> granted[kMaxDevices];
+  std::mutex slow;   // serialises the rare raise (first launch of a shape that needs more than was granted before)
+};
+// Raise the kernel's dynamic-LDS limit on the current device to `bytes` if that is above what was granted there before;
+// PD_OK, or PD_ERR_UNSUPPORTED with the error text set.  After the first call for a shape: one relaxed atomic load.
+int grant_dynamic_lds(const void* kernel, size_t bytes, LdsGrant* grant, const char* what);
 
 #define PD_REQUIRE(cond, ...)        \
   do {                               \

@@ -29,26 +29,38 @@ const Switches& switches() {
   return sw;
 }
 
-size_t device_lds_bytes() {
-  static const size_t bytes = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || n <= 0)
-      n = 160 * 1024;  // no device to ask (host-side size queries on a box without a GPU): the target's value, gfx950
-    (void)hipGetLastError();
-    return (size_t)n;
-  }();
-  return bytes;
+static int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return (dev >= 0 && dev < kMaxDevices) ? dev : kMaxDevices - 1;   // (ordinals beyond the table share its last slot's limit)
 }
 
-int grant_dynamic_lds(const void* kernel, size_t bytes, size_t* granted, const char* what) {
-  if (bytes <= *granted) return PD_OK;
+size_t device_lds_bytes() {
+  static std::atomic<size_t> bytes[kMaxDevices];   // zero-initialised: 0 = not asked yet
+  const int dev = current_device_slot();
+  size_t have = bytes[dev].load(std::memory_order_relaxed);
+  if (have) return have;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || n <= 0)
+    n = 160 * 1024;  // no device to ask (host-side size queries on a box without a GPU): the target's value, gfx950
+  (void)hipGetLastError();
+  bytes[dev].store((size_t)n, std::memory_order_relaxed);   // (two threads racing here store the same value)
+  return (size_t)n;
+}
+
+int grant_dynamic_lds(const void* kernel, size_t bytes, LdsGrant* grant, const char* what) {
+  constexpr size_t kDefault = 64 * 1024;
+  if (bytes <= kDefault) return PD_OK;
+  const int dev = current_device_slot();
+  if (bytes <= grant->granted[dev].load(std::memory_order_acquire)) return PD_OK;
+  std::lock_guard<std::mutex> lock(grant->slow);
+  if (bytes <= grant->granted[dev].load(std::memory_order_relaxed)) return PD_OK;   // somebody else raised it meanwhile
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
     (void)hipGetLastError();
     set_error("%s: %zu bytes of LDS per workgroup are not available on this device", what, bytes);
     return PD_ERR_UNSUPPORTED;
   }
-  *granted = bytes;
+  grant->granted[dev].store(bytes, std::memory_order_release);   // only ever raised: a concurrent launch with a smaller need stays valid
   return PD_OK;
 }
 

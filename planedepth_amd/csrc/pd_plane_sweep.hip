@@ -417,6 +417,17 @@ static int validate(const pd_sweep_desc* d, const float* src, const float* logit
   return PD_OK;
 }
 
+// What PD_IMPL_AUTO does with a second source row whose weight is fp32 noise of the reference's y round trip
+// (pd_rowshift_common.h: two_row_form): it is dropped when the weight is below PD_AUTO_ROW_EPS (0: never).  Decided by the
+// parity suite run under the modes (tests/test_gpu_parity.py: row_mode; profiles/r05_parity.md).  PD_ROW_EPS in the
+// environment (read once, diagnostics) overrides the compiled-in value.
+#ifndef PD_AUTO_ROW_EPS
+#define PD_AUTO_ROW_EPS 0.0f
+#endif
+static float auto_row_eps() {
+  static const float eps = [] { const char* e = getenv("PD_ROW_EPS"); return e ? (float)atof(e) : (float)(PD_AUTO_ROW_EPS); }();
+  return eps;
+}
 static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
                            const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
                            const float* padding_mask, const float* dists = nullptr) {
@@ -426,7 +437,8 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   a.sign = d->sign;
   a.stash_k = kStashBase + ((d->mode == PD_WARP_DISP) ? (d->N + 31) / 32 : 0);
   const bool mask_rows = (d->flags & PD_MASK_ROWS) != 0;
-  a.fast_rows = (d->impl == PD_IMPL_FAST_ROWS) ? 1 : 0;
+  a.row_eps = (d->impl == PD_IMPL_FAST_ROWS) ? kFastRowWeight : (d->impl == PD_IMPL_EXACT_ROWS) ? 0.0f : auto_row_eps();
+  a.fast_rows = a.row_eps > 0.0f ? 1 : 0;
   // row pairs need one scalar disparity per plane (the sampling column is then the same in both rows) and no per-pixel
   // or per-row mask; PD_NO_ROWPAIR=1 (environment) switches them off for A/B runs
   a.pairs = (d->mode == PD_WARP_DISP && !(d->flags & (PD_DISP_DENSE | PD_DISP_ROWS | PD_MASK_ROWS | PD_RENDER_PROB)) &&
@@ -442,8 +454,11 @@ static SweepArgs make_args(const pd_sweep_desc* d, const float* src, const float
   return a;
 }
 
+extern "C" float pd_sweep_auto_row_eps(void) { return auto_row_eps(); }
+
 static bool wants_rowshift(const pd_sweep_desc* d) {
-  return d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_ROWS1 || d->impl == PD_IMPL_UNIFORM_DIRECT;
+  return d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_ROWS1 || d->impl == PD_IMPL_UNIFORM_DIRECT ||
+         d->impl == PD_IMPL_EXACT_ROWS;
 }
 
 extern "C" int pd_sweep_uses_rowshift(const pd_sweep_desc* d) {
@@ -543,7 +558,7 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
   PD_REQUIRE(!(d->flags & PD_RENDER_PROB) || (dists && d->N >= 2), "PD_RENDER_PROB needs dists [B,N-1,H,W] and N >= 2");
   const bool dense = (d->flags & (PD_DISP_DENSE | PD_DISP_ROWS)) != 0;
   PD_REQUIRE(!g_plane || dense || workspace, "g_plane needs workspace (pd_sweep_bwd_workspace_floats)");
-  PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_UNIFORM_DIRECT, "unknown impl %d", d->impl);
+  PD_REQUIRE(d->impl >= PD_IMPL_AUTO && d->impl <= PD_IMPL_EXACT_ROWS, "unknown impl %d", d->impl);
   hipStream_t stream = (hipStream_t)stream_;
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   const bool accumulate = (d->flags & PD_BWD_ACCUMULATE) != 0;

@@ -48,8 +48,26 @@ namespace pd {
 #define PD_FS_REVERSE 0   // row groups dispatched bottom-up (the backward then walks top-down: PD_BWD_REVERSE 0)
 #endif
 #ifndef PD_FS_ABL
-#define PD_FS_ABL 0
+#define PD_FS_ABL 0   // timing experiments only (wrong results; scripts/gpu_r5_ladder.sh): 1 colour cells at a 16-byte lane stride,
+#endif                // 2 no LDS colour reads, 4 no softmax / mixture arithmetic, 8 no output / stash stores, 16 every row as one
+                      // source row, 32 no coordinate chain, 64 no tap loads, 128 no tap interpolation, 256 no staging loads
+#ifndef PD_FS_SHRING
+#define PD_FS_SHRING 0  // 1: a plane's staged shift is read from LDS ONE iteration before its tap loads are issued and kept in
+#endif                  // scalar registers until the plane is reduced (one LDS read per iteration, off the critical path, instead of
+                        // two round trips at the head of every iteration)
+#ifndef PD_FS_FIXREF
+#define PD_FS_FIXREF 0  // 1: softmax with a FIXED per-pixel reference (the first plane's scaled logit) on the regular planes: no
+#endif                  // lazy-rescale branch per pixel and plane (a compare, an exec-mask branch and the copies of all seven running
+                        // sums at its join: a sixth of the loop's VALU instructions).  The largest exponent a pixel used is tracked
+                        // (one v_max per plane); a wave in which any pixel went beyond 2^kFixRefLimit redoes its planes with the
+                        // rescaling accumulator (per-pixel general path) — exact for any input, never taken for logits within
+                        // +-60 of each other
+#ifndef PD_FS_COLPF
+#define PD_FS_COLPF 0   // 1 (needs PD_FS_SHRING): the three colour cells of plane n + 1 are read from LDS while plane n is reduced
 #endif
+#ifndef PD_FS_TRACE
+#define PD_FS_TRACE 0   // diagnostics build: s_memtime stamps per wave (entry, staged, loop end, exit) + HW_ID / XCC_ID into a device
+#endif                  // array read back through pd_debug_fs_trace (scripts/diag_fwd_trace.py)
 #ifndef PD_FS_LDS_PAD
 #define PD_FS_LDS_PAD 0   // timing experiments: extra LDS bytes per workgroup (caps the workgroups per CU)
 #endif
@@ -57,11 +75,34 @@ namespace pd {
 #define PD_FS_ROWS 3   // consecutive target rows per workgroup where its 16 waves allow (each row: one wave per segment).  Measured
 #endif                 // at 8x49x192x640, isolated / in the step: 1 row 0.114 / 0.128 ms, 2 rows 0.119 / 0.131, 3 rows 0.104 / 0.122
                        // — 15 waves that read three adjacent rows (7.5 KB) of every plane at about the same time
+constexpr float kFixRefLimit = 90.0f;  // PD_FS_FIXREF: largest base-2 exponent of a softmax term before the wave falls back
 constexpr int kFsSeg = 2 * kWave;      // target pixels per wave
 constexpr int kFsGuard = 4;            // zero cells on each side of the colour row
 constexpr int kFsThreadsMax = 1024;    // 16 waves: rows up to 2048 pixels
 
 typedef float v3f __attribute__((ext_vector_type(3)));
+
+#if PD_FS_TRACE
+constexpr int kFsTraceWgs = 4096, kFsTraceWords = 6;   // per wave: 4 stamps, hw ids, (image << 16 | first row)
+__device__ unsigned long long g_fs_trace[kFsTraceWgs * 16 * kFsTraceWords];
+__device__ __forceinline__ void fs_stamp(int slot) {
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (wg < kFsTraceWgs && (threadIdx.x & (kWave - 1)) == 0)
+    g_fs_trace[((long)wg * 16 + (threadIdx.x >> 6)) * kFsTraceWords + slot] = __builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void fs_stamp_ids(int b, int y) {
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (wg < kFsTraceWgs && (threadIdx.x & (kWave - 1)) == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    unsigned long long* p = g_fs_trace + ((long)wg * 16 + (threadIdx.x >> 6)) * kFsTraceWords;
+    p[4] = ((unsigned long long)xcc << 32) | hw;
+    p[5] = ((unsigned long long)b << 32) | (unsigned)y;
+  }
+}
+#else
+__device__ __forceinline__ void fs_stamp(int) {}
+__device__ __forceinline__ void fs_stamp_ids(int, int) {}
+#endif
 
 __device__ __forceinline__ v3f fs_load3(Rsrc r, unsigned byte_off) {
   return __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, (int)byte_off, 0, 0));
@@ -142,12 +183,46 @@ __device__ __forceinline__ void fs_general_plane(const SweepArgs& a, const FsRow
   }
 }
 
-// One target row (b, y): `tix` / `nthr` = this thread's index among the threads that serve the row (nseg waves), `seg` the
-// wave's segment.  Contains one workgroup barrier (after staging): every thread of the workgroup calls it, `active` = false
-// for the waves of a row beyond the image.
+// Stage one target row (b, y) for the waves that serve it (`tix` / `nthr` = this thread's index among them): the source
+// colour row (vertically blended where the row has two live source rows) with zero guard cells, and the per-plane shifts.
+// The number of live rows is a run-time value here: every wave of the workgroup runs this one function and meets at the
+// kernel's ONE barrier, whatever its row's footprint (the bodies below, specialised by footprint, contain no barrier).
+__device__ __forceinline__ void fs_stage_row(const SweepArgs& a, const RowSel& row, int b, int y, int tix, int nthr,
+                                             float4* __restrict__ col, int2* __restrict__ shift) {
+  const int W = a.W, N = a.N, HW = a.H * a.W;
+  const int CW = W + 2 * kFsGuard;
+  const bool two = row.nrows == 2;
+  const float* srcb = a.src + (long)b * 3 * HW;
+  for (int cidx = tix; cidx < CW && y < a.H; cidx += nthr) {
+    const int x = cidx - kFsGuard;
+    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W) {
+      if (PD_FS_ABL & 256) cc = make_float4((float)x, 0.5f, 0.25f, 0.0f);
+      else {
+      const float* p = srcb + (long)row.yA * W + x;
+      cc = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
+      if (two) {   // fl(B*wB + fl(A*wA)): the rounding the row-stream backward stages (its knife-edge note applies here too)
+        const float* q = srcb + (long)row.yB * W + x;
+        cc = make_float4(fmaf(q[0], row.wB, cc.x * row.wA), fmaf(q[HW], row.wB, cc.y * row.wA), fmaf(q[2 * HW], row.wB, cc.z * row.wA), 0.0f);
+      }
+      }
+    }
+    col[cidx] = cc;
+  }
+  const float tol = irregular_tol(W);
+  for (int i = tix; i < N && y < a.H; i += nthr) {
+    const float sd = staged_shift(a, b, i, y);
+    const float fl = floorf(sd), fr = sd - fl;
+    const bool inview = fabsf(sd) < (float)(W + 1);
+    const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
+    shift[i] = make_int2(__float_as_int(sd), (int)fl * 2 + irr);
+  }
+}
+
+// One wave's segment `seg` of the staged target row (b, y), all planes.  No barrier inside.
 template <bool MIX, bool AUTO, int NROWS, bool RENDER>
-__device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel& row, int b, int y, int tix, int nthr, int seg,
-                                                bool active, float4* __restrict__ col, int2* __restrict__ shift,
+__device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel& row, int b, int y, int seg,
+                                                float4* __restrict__ col, int2* __restrict__ shift,
                                                 float* __restrict__ rgb_rec, float* __restrict__ ph_map,
                                                 float* __restrict__ stash) {
   constexpr int D = (NROWS == 1) ? PD_FS_D1 : PD_FS_D2;
@@ -159,35 +234,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
   const bool automask = MIX ? AUTO : (bool)(a.flags & PD_AUTOMASK);
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
-  const int CW = W + 2 * kFsGuard;
-
-  // ---- stage the row: blended source colour row with zero guard cells, per-plane shifts -----------------------------
   const float* srcb = a.src + (long)r.b * 3 * HW;
-  for (int cidx = tix; cidx < CW && y < a.H; cidx += nthr) {
-    const int x = cidx - kFsGuard;
-    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 0 && x < W) {
-      const float* p = srcb + (long)r.yA * W + x;
-      cc = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
-      if (NROWS == 2) {   // fl(B*wB + fl(A*wA)): the rounding the row-stream backward stages (its knife-edge note applies here too)
-        const float* q = srcb + (long)r.yB * W + x;
-        cc = make_float4(fmaf(q[0], r.wB, cc.x * r.wA), fmaf(q[HW], r.wB, cc.y * r.wA), fmaf(q[2 * HW], r.wB, cc.z * r.wA), 0.0f);
-      }
-    }
-    col[cidx] = cc;
-  }
-  {
-    const float tol = irregular_tol(W);
-    for (int i = tix; i < N && y < a.H; i += nthr) {
-      const float sd = staged_shift(a, r.b, i, r.y);
-      const float fl = floorf(sd), fr = sd - fl;
-      const bool inview = fabsf(sd) < (float)(W + 1);
-      const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
-      shift[i] = make_int2(__float_as_int(sd), (int)fl * 2 + irr);
-    }
-  }
-  __syncthreads();
-  if (!active) return 0.0f;
 
   // ---- this wave's segment -----------------------------------------------------------------------------------------
   const int lane = threadIdx.x & (kWave - 1);
@@ -211,11 +258,33 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   }
   FwdAcc acc[2];
   RenderState rs[2];
+  float dmax[2] = {-INFINITY, -INFINITY};   // PD_FS_FIXREF: largest exponent used so far
   FsTaps<NROWS> g[D + 1];
   int pn = 0;
-  auto prefetch = [&](FsTaps<NROWS>& grp) {
+#if PD_FS_SHRING
+  int sh_sd[D + 1], sh_kk[D + 1];          // wave-uniform (SGPRs): the shifts of the planes whose taps are in flight
+  int2 sh_next = shift[0];                 // LDS read in flight: the shift of the next plane to be prefetched
+#endif
+#if PD_FS_COLPF && PD_FS_SHRING
+  float4 cpre[3];                          // LDS reads in flight: the colour cells of the next plane to be reduced
+#endif
+  auto prefetch = [&](FsTaps<NROWS>& grp, int slot) {
     const int n = min(pn, N - 1);   // past the end: re-load the last plane (unused) — unconditional issue keeps the wait counts right
+#if PD_FS_SHRING
+    sh_sd[slot] = __builtin_amdgcn_readfirstlane(sh_next.x);
+    sh_kk[slot] = __builtin_amdgcn_readfirstlane(sh_next.y);
+    sh_next = shift[min(pn + 1, N - 1)];
+    const int k = sh_kk[slot] >> 1;
+#else
     const int k = __builtin_amdgcn_readfirstlane(shift[n].y) >> 1;
+#endif
+    if (PD_FS_ABL & 64) {   // timing only: no tap loads, lane- and plane-dependent stand-ins
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        grp.l[0][q] = grp.l[NROWS - 1][q] = xt0f * 1e-3f + (float)(k + q) * 1e-2f;
+        grp.s[0][q] = grp.s[NROWS - 1][q] = 0.5f + xt0f * 1e-4f + (float)(k - q) * 1e-4f;
+      }
+    } else
     fs_issue<MIX, NROWS>(grp, a, r, n, (unsigned)(xt0 + k) << 2, HW);
     if (RENDER) {   // unshifted, coalesced: read where the pixels are, not where they sample (the last plane has none: alpha = 1)
       const float2 d2 = *reinterpret_cast<const float2*>(a.dists + ((long)r.b * (N - 1) + min(n, N - 2)) * HW + pix);
@@ -223,11 +292,23 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
     }
     ++pn;
   };
-  auto step = [&](const FsTaps<NROWS>& grp, int n) {
+  auto step = [&](const FsTaps<NROWS>& grp, int n, int slot, int next_slot) {
+#if PD_FS_SHRING
+    const float sd = __int_as_float(sh_sd[slot]);
+    const int kk = sh_kk[slot];
+#else
     const int2 sh = shift[n];
     const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
     const int kk = __builtin_amdgcn_readfirstlane(sh.y);
+#endif
     const int k = kk >> 1;
+#if PD_FS_COLPF && PD_FS_SHRING
+    const float4 cq0 = cpre[0], cq1 = cpre[1], cq2 = cpre[2];
+    {   // the next plane's cells (its shift is in the ring already: its taps were issued D - 1 iterations ago)
+      const int cn = min(max(xt0 + (sh_kk[next_slot] >> 1), -kFsGuard), W + 1) + kFsGuard;
+      cpre[0] = col[cn]; cpre[1] = col[cn + 1]; cpre[2] = col[cn + 2];
+    }
+#endif
     const int c0 = seg * kFsSeg + k;   // source column of the segment's first left tap (wave-uniform); lane i loads c0 + 2i ..
     // 12-byte form: regular plane, and no lane's load starts at column -3, -2 or -1: a load that starts left of the row reads
     // as zeros as a whole although its last columns may be inside, and the dword at byte offset -4 passes the 32-bit range
@@ -242,16 +323,29 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
 #else
     const int cell = min(max(xt0 + k, -kFsGuard), W + 1) + kFsGuard;
 #endif
-    const float4 cv0 = col[cell], cv1 = col[cell + 1], cv2 = col[cell + 2];
+    float4 cv0, cv1, cv2;
+#if PD_FS_COLPF && PD_FS_SHRING
+    cv0 = cq0; cv1 = cq1; cv2 = cq2;
+    (void)cell;
+#else
+    if (PD_FS_ABL & 2) {   // timing only: no LDS colour reads
+      cv0 = make_float4(xt0f * 1e-3f, 0.25f, 0.5f, 0.0f); cv1 = make_float4(0.75f, xt0f * 1e-3f, 0.5f, 0.0f); cv2 = make_float4(0.1f, 0.2f, xt0f * 1e-3f, 0.0f);
+    } else {
+      cv0 = col[cell]; cv1 = col[cell + 1]; cv2 = col[cell + 2];
+    }
+#endif
     const float kf = (float)k;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float xtf = xt0f + (float)i;
-      const float ix = stream_ix(xtf, sd, Wm1, rcpWm1);
       const float xsf = xtf + kf;                               // integers below 2^24: exact
+      const float ix = (PD_FS_ABL & 32) ? xsf + (sd - kf) : stream_ix(xtf, sd, Wm1, rcpWm1);
       const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;        // torch's (ix - x0), (x1 - ix) with x0 = xt + k
       float l, s = 0.0f;
-      if (NROWS == 1) {
+      if (PD_FS_ABL & 128) {   // timing only: the loaded values are consumed, not interpolated
+        l = grp.l[0][i] + grp.l[0][i + 1] + grp.l[NROWS - 1][i] * r.wB;
+        if (MIX) s = grp.s[0][i] + grp.s[0][i + 1] + grp.s[NROWS - 1][i + 1] * r.wB;
+      } else if (NROWS == 1) {
         l = grp.l[0][i] * w0 + grp.l[0][i + 1] * w1;
         if (MIX) s = grp.s[0][i] * w0 + grp.s[0][i + 1] * w1;
       } else {
@@ -261,30 +355,75 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
       }
       const float4 ca = (i == 0) ? cv0 : cv1, cb = (i == 0) ? cv1 : cv2;
       const float c0v = ca.x * w0 + cb.x * w1, c1v = ca.y * w0 + cb.y * w1, c2v = ca.z * w0 + cb.z * w1;
+      if (PD_FS_ABL & 4) {   // timing only: no softmax / mixture arithmetic
+        acc[i].Z += l; acc[i].S += s; acc[i].C0 += c0v; acc[i].C1 += c1v; acc[i].C2 += c2v; acc[i].Mx += w0; acc[i].m = 0.0f;
+      } else if (PD_FS_FIXREF && !RENDER) {
+        const float d = l * kLog2e - acc[i].m;   // (m = -inf until a plane set it: d = +inf trips the limit below)
+        dmax[i] = fmaxf(dmax[i], d);
+        mixture_accumulate<MIX>(acc[i], exp2_fast(d), s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask);
+      } else
       fs_accumulate<MIX, RENDER>(acc[i], rs[i], l, s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask, grp.dist[i], n == N - 1);
     }
   };
 #pragma unroll
-  for (int j = 0; j < D; ++j) prefetch(g[j]);
+  for (int j = 0; j < D; ++j) prefetch(g[j], j);
+  if (PD_FS_FIXREF && !RENDER) {   // the reference: plane 0's scaled logit at the lane's two pixels (when plane 0 takes the 12-byte form;
+    const int2 sh0 = shift[0];     // otherwise the general path's rescaling accumulator sets it when it reduces plane 0)
+    const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh0.x));
+    const int kk = __builtin_amdgcn_readfirstlane(sh0.y), k = kk >> 1, c0 = seg * kFsSeg + k;
+    if (!((kk & 1) || (c0 < 0 && c0 + 2 * (kWave - 1) >= -3))) {
+      const float kf = (float)k;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float xtf = xt0f + (float)i, xsf = xtf + kf;
+        const float ix = stream_ix(xtf, sd, Wm1, rcpWm1);
+        const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;
+        float l;
+        if (NROWS == 1) l = g[0].l[0][i] * w0 + g[0].l[0][i + 1] * w1;
+        else {
+          const float a0 = w0 * r.wA, a1 = w1 * r.wA, b0 = w0 * r.wB, b1 = w1 * r.wB;
+          l = g[0].l[0][i] * a0 + g[0].l[0][i + 1] * a1 + g[0].l[NROWS - 1][i] * b0 + g[0].l[NROWS - 1][i + 1] * b1;
+        }
+        acc[i].m = l * kLog2e;
+      }
+    }
+  }
+#if PD_FS_COLPF && PD_FS_SHRING
+  {
+    const int cn = min(max(xt0 + (sh_kk[0] >> 1), -kFsGuard), W + 1) + kFsGuard;
+    cpre[0] = col[cn]; cpre[1] = col[cn + 1]; cpre[2] = col[cn + 2];
+  }
+#endif
   int n = 0;
   for (; n + (D + 1) <= N; n += D + 1) {
 #pragma unroll
     for (int j = 0; j <= D; ++j) {
-      prefetch(g[(j + D) % (D + 1)]);
-      step(g[j], n + j);
+      prefetch(g[(j + D) % (D + 1)], (j + D) % (D + 1));
+      step(g[j], n + j, j, (j + 1) % (D + 1));
     }
   }
 #pragma unroll
   for (int j = 0; j <= D; ++j) {
     if (n + j < N) {
-      prefetch(g[(j + D) % (D + 1)]);
-      step(g[j], n + j);
+      prefetch(g[(j + D) % (D + 1)], (j + D) % (D + 1));
+      step(g[j], n + j, j, (j + 1) % (D + 1));
     }
   }
+  if (PD_FS_FIXREF && !RENDER) {
+    const bool beyond = dmax[0] > kFixRefLimit || dmax[1] > kFixRefLimit;
+    if (__builtin_amdgcn_ballot_w64(beyond) != 0) {   // rare: this wave again, every plane through the rescaling accumulator
+      acc[0] = FwdAcc(); acc[1] = FwdAcc();
+      for (int q = 0; q < N; ++q)
+        fs_general_plane<MIX, NROWS, RENDER>(a, r, col, q, __int_as_float(__builtin_amdgcn_readfirstlane(shift[q].x)), xt0f, HW, Wm1,
+                                             rcpWm1, t, ea, automask, acc, rs, g[0].dist);
+    }
+  }
+  fs_stamp(2);
   if (!live) return 0.0f;
   // ---- finish the two pixels: outputs + the backward's stash, 8-byte stores -------------------------------------------
   const FwdResult r0 = fwd_finish<MIX>(acc[0], t[0], t[2], t[4], ea[0], automask, !RENDER);   // (compositing weights are used as they are)
   const FwdResult r1 = fwd_finish<MIX>(acc[1], t[1], t[3], t[5], ea[1], automask, !RENDER);
+  if ((PD_FS_ABL & 8) && r0.ph != 123.456f) return r0.ph + r1.ph;   // timing only: no output / stash stores
   float* st = stash + (long)r.b * a.stash_k * HW + pix;
   *reinterpret_cast<float2*>(st) = make_float2(r0.lse2, r1.lse2);
   *reinterpret_cast<float2*>(st + HW) = make_float2(r0.Sn, r1.Sn);
@@ -319,11 +458,18 @@ __global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OC
   const int seg = cb * segs + (wave - slot * segs);              // which segment of the row
   const int y = grp * rows + slot, b = wg_image(a.B, groups * cblocks);
   const bool active = y < a.H && seg < nseg;
-  const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.row_eps);
   const int tix = threadIdx.x - slot * segs * kWave, nthr = segs * kWave;
-  float ph_sum;
-  if (row.nrows == 2) ph_sum = fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
-  else                ph_sum = fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, tix, nthr, seg, active, col, shift, rgb_rec, ph_map, stash);
+  fs_stamp(0);
+  fs_stamp_ids(b, y);
+  fs_stage_row(a, row, b, y, tix, nthr, col, shift);
+  __syncthreads();   // the kernel's only barrier before the outputs: every wave reaches it, whatever its row needs
+  fs_stamp(1);
+  float ph_sum = 0.0f;
+  if (!active) {}
+  else if (row.nrows == 2 && !(PD_FS_ABL & 16)) ph_sum = fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
+  else                                          ph_sum = fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
+  fs_stamp(3);
   if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup
     const float v = wave_sum_hi(ph_sum);
     if ((threadIdx.x & (kWave - 1)) == kWave - 1) parts[wave] = v;
@@ -374,7 +520,7 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
   const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
 #define PD_FS_LAUNCH(M, A, R)                                                                                              \
   do {                                                                                                                    \
-    static size_t granted = 64 * 1024;                                                                                    \
+    static LdsGrant granted;                                                                                              \
     if (int rc = grant_dynamic_lds((const void*)fwdstream_kernel<M, A, R>, shmem, &granted, "fwdstream_kernel")) return rc; \
     fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks);            \
   } while (0)
@@ -390,3 +536,12 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
 }
 
 }  // namespace pd
+
+#if PD_FS_TRACE
+// diagnostics build only (not declared in include/planedepth_hip.h): copies the stamps of the last launch to the host
+extern "C" int pd_debug_fs_trace(unsigned long long* host_dst, long words) {
+  const long have = (long)pd::kFsTraceWgs * 16 * pd::kFsTraceWords;
+  if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(pd::g_fs_trace), sizeof(unsigned long long) * (words < have ? words : have)) != hipSuccess) return 1;
+  return 0;
+}
+#endif

@@ -440,7 +440,7 @@ static size_t galign4(size_t floats) { return (floats + 3) & ~(size_t)3; }
 
 bool gather_bwd_applicable(const pd_sweep_desc* d) {
   return d->mode == PD_WARP_HOMOGRAPHY && !(d->flags & PD_HOMO_UNIFORM) &&
-         (d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_UNIFORM_DIRECT);
+         (d->impl == PD_IMPL_AUTO || d->impl == PD_IMPL_UNIFORM_DIRECT || d->impl == PD_IMPL_FAST_ROWS || d->impl == PD_IMPL_EXACT_ROWS);
 }
 
 // workspace: partial sums [B][nblk][N*9] | GatherPrep[B*N] | flags (4 ints) | scratch [B][N][H*W] (x2 with PD_MIXTURE)

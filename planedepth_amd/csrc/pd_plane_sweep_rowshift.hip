@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kRowThreadsMax, HASMASK ? 3 : PD_FWD_OCC) void rows
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * (a.W + 4));
   float* parts = sdisp + a.N;
   const int y = block_row(wg_rowid(a.B, a.H), a.H);
-  const RowSel row = two_row_form(make_row_sel(y, a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(y, a.H), a.row_eps);
   float ph_sum = 0.0f;
   int partner = y;
   // row pairs: per-plane scalar disparities and no per-pixel mask (then the sampling column is shared by the rows)
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kRowThreadsMax, PD_BWD_OCC) void rowshift_bwd_kerne
   bnd.rec = red + a.N;
   bnd.irr = reinterpret_cast<unsigned*>(bnd.rec + 2 * nsn);
   bnd.side = o.side + ((long)wg_image(a.B, a.H) * a.H + bwd_rowid(a.B, a.H)) * (4L * nsn);
-  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
   if (row.nrows == 2) rowshift_bwd_body<MIX, HASMASK, 2, RENDER>(a, o, row, sdisp, kshift, red, bnd, lds4);
   else                rowshift_bwd_body<MIX, HASMASK, 1, RENDER>(a, o, row, sdisp, kshift, red, bnd, lds4);
 }

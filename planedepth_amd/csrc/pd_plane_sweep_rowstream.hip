@@ -61,6 +61,9 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_LOAD_AUX
 #define PD_STREAM_LOAD_AUX 0    // same for the tap loads
 #endif
+#ifndef PD_STREAM_SHPF
+#define PD_STREAM_SHPF 0   // 1: the staged shift of the NEXT (plane, segment) item is read from LDS while the current one is reduced
+#endif                     // (its round trip sat at the head of every iteration)
 #ifndef PD_STREAM_OCC
 #define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 77 = 6 waves per SIMD
 #endif
@@ -349,8 +352,20 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     stream_issue<MIX, NROWS>(grp, a, r, min(pn, N - 1), pseg, lane8, HW);   // past the end: re-load the last plane (unused)
     advance(pn, pseg);
   };
+#if PD_STREAM_SHPF
+  int2 shv = L.shift[min(n, N - 1)];
+#endif
   auto step = [&](const StreamGroup<NROWS>& grp) {
+#if PD_STREAM_SHPF
+    const int2 sh = shv;
+    {
+      int nn = n, ss = seg;
+      advance(nn, ss);
+      shv = L.shift[min(nn, N - 1)];
+    }
+#else
     const int2 sh = L.shift[n];
+#endif
     const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
     const int kk = __builtin_amdgcn_readfirstlane(sh.y);
     const int k = kk >> 1;
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bw
   L.red = reinterpret_cast<float*>(L.shift + a.N);
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
-  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
   if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK>(a, o, row, L);
   else                                     stream_body<MIX, 1, PK>(a, o, row, L);
 }
@@ -502,7 +517,7 @@ size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d
 
 template <bool MIX, bool PK>
 static int rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
-  static size_t granted = 64 * 1024;   // per instantiation: the attribute is set once (and checked), not per launch
+  static LdsGrant granted;   // per instantiation and device: the attribute is set once (and checked), not per launch
   const int rc = grant_dynamic_lds((const void*)rowstream_bwd_kernel<MIX, PK>, shmem, &granted, "rowstream_bwd_kernel");
   if (rc) return rc;
   rowstream_bwd_kernel<MIX, PK><<<grid, block, shmem, stream>>>(a, o);

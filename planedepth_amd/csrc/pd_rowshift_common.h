@@ -106,11 +106,11 @@ __device__ __forceinline__ int block_row(int r, int H) {
 // dropping it moves results by up to e * (range of the logits), measured 4e-5 (rgb_rec) .. 1e-4 (g_sigma) of the
 // tensors' range on random inputs — the whole 1e-4 parity budget.  PD_IMPL_FAST_ROWS opts into dropping a second row
 // whose weight is below 2^-16 (smooth network outputs make the difference far smaller than random test data does).
-constexpr float kTinyRowWeight = 1.52587890625e-05f;  // 2^-16
-__device__ __forceinline__ RowSel two_row_form(RowSel r, bool fast_rows) {
-  if (fast_rows && r.nrows == 2) {
+// row_eps: a second source row whose weight is BELOW it is dropped (0: none is — PD_IMPL_EXACT_ROWS).
+__device__ __forceinline__ RowSel two_row_form(RowSel r, float row_eps) {
+  if (row_eps > 0.0f && r.nrows == 2) {
     const bool a_main = r.wA >= r.wB;
-    if ((a_main ? r.wB : r.wA) < kTinyRowWeight) {
+    if ((a_main ? r.wB : r.wA) < row_eps) {
       r.nrows = 1;
       r.yA = a_main ? r.yA : r.yB;
       r.wA = 1.0f;

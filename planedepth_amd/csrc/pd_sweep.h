@@ -14,6 +14,7 @@ namespace pd {
 constexpr int kAblate = PD_ABLATE;
 
 constexpr int kStashBase = 4;  // lse, S, Mx, flags  (then ceil(N/32) mask words in disp mode)
+constexpr float kFastRowWeight = 1.52587890625e-05f;  // 2^-16: the threshold of PD_IMPL_FAST_ROWS (pd_rowshift_common.h: two_row_form)
 constexpr float kSigmaMin = 0.01f, kSigmaMax = 1.0f, kLogEps = 1e-7f, kZMin = 1e-7f;
 
 struct SweepArgs {
@@ -31,7 +32,8 @@ struct SweepArgs {
   const float* inv_K3;
   const float* padding_mask;
   int pairs;               // forward: inexact rows take their neighbour along (per-plane disparities, no mask)
-  int fast_rows;           // PD_IMPL_FAST_ROWS: the row-shift kernels drop eps-weighted second source rows
+  int fast_rows;           // row_eps > 0
+  float row_eps;           // the row kernels drop a second source row whose weight is below this (pd_rowshift_common.h: two_row_form)
   const float* mask_rows;  // PD_MASK_ROWS: [B,N,H] (row-shift kernels only; padding_mask is NULL then)
   const float* dists;  // PD_RENDER_PROB: [B,N-1,H,W] inter-plane distances at the TARGET pixel (trainer.py:587)
   float* ph_mean;      // forward, optional: one float that receives mean(ph_map) (block sums, one atomic per wave)

@@ -13,6 +13,14 @@ from . import _capi as C
 
 # Kernel selection for the sweep (C.PD_IMPL_AUTO | C.PD_IMPL_GENERAL).  Tests flip it to cross-check the specialised
 # row-shift kernels against the general ones; leave it alone otherwise.
+def _env_int(name):
+    """A numeric environment switch as the library parses it (atoi; unset, empty, non-numeric or <= 0: off)."""
+    try:
+        return max(int(os.environ.get(name, "0") or 0), 0)
+    except ValueError:
+        return 0
+
+
 SWEEP_IMPL = int(os.environ.get("PD_SWEEP_IMPL", C.PD_IMPL_AUTO))  # 0 auto, 1 general kernels, 2 fast rows (A/B runs)
 LAST_SWEEP_FLAGS = None  # flags of the most recent sweep forward (introspection for tests)
 DEBUG_STASH = None       # diagnostics (scripts/diag_w70.py): set to a list to collect the forward's per-pixel stash
@@ -390,7 +398,7 @@ class _MultiPlaneSweep(torch.autograd.Function):
         def pairable(v):   # plane-uniform views with the same kernel configuration gather together (pd_uniform_gather_pair)
             mode, flags, sign = ctx.cfgs[v[0]]
             # (PD_UNI_CHUNK, the library's chunked plane-uniform passes, does not serve the deferred gather: sequential views then)
-            return (PAIR_GATHER and not os.environ.get("PD_UNI_CHUNK") and mode == C.PD_WARP_HOMOGRAPHY and
+            return (PAIR_GATHER and not _env_int("PD_UNI_CHUNK") and mode == C.PD_WARP_HOMOGRAPHY and
                     bool(flags & C.PD_HOMO_UNIFORM) and (need_logits or need_sigma))
         k = 0
         while k < len(views):
@@ -512,6 +520,15 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     dense map is constant along x (true for xy and xz planes: networks/depth_decoder.py:153-181 build them from the
     y-grid only; false once yz planes exist): its first column is then used as ``[B,N,H]`` per-row disparities, which
     keeps the row-shift kernels applicable.
+
+    Gradient of a dense ``row_uniform`` map.  The reference's autograd hands ``disp_layered`` a dense [B,N,H,W] gradient
+    (every column its own share).  Here the row's total ``g[b,n,y]`` comes back SPREAD EVENLY, ``g / W`` on every column, as
+    a stride-0 view (``_FirstColumn``): anything that built the map from x-independent quantities — the decoder's
+    ``expand`` and its y-grid formula, depth_decoder.py:153-181 — sums over x and receives exactly the reference's
+    gradient, and nothing [B,N,H,W]-sized is written.  Per-column values differ from the reference's (their sum over x does
+    not): a hook or a consumer that reads individual columns of ``disp_layered.grad`` must not pass ``row_uniform=True``.  A
+    map that is a LEAF (``disp_layered.is_leaf``: somebody wants ``.grad`` itself) gets the plain select gradient instead —
+    the row totals on column 0, zeros elsewhere.
     """
     B, N, H, W = logits.shape
     if _rows is not None:
@@ -537,7 +554,10 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     elif row_uniform:
         probe = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_DISP_ROWS, 1.0, SWEEP_IMPL)
         rows = bool(C.load().pd_sweep_uses_rowshift(ctypes.byref(probe)))
-        plane = _FirstColumn.apply(disp_layered) if rows else disp_layered
+        if rows:   # a LEAF map keeps the exact select gradient (g on column 0, zeros elsewhere); see the docstring
+            plane = disp_layered[..., 0].contiguous() if disp_layered.is_leaf else _FirstColumn.apply(disp_layered)
+        else:
+            plane = disp_layered
     else:
         plane = disp_layered
     if padding_mask is not None and padding_mask.dtype != torch.float32:
@@ -671,6 +691,9 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     derivatives need h00 as well).
     """
     B, N, H, W = logits.shape
+    if plane_uniform and N * H * W >= (1 << 29):
+        plane_uniform = False   # the plane-uniform kernels address one image's [N,H,W] block with 32-bit byte offsets; beyond
+        # that the per-plane route below (one matrix per plane, 64-bit addressing) serves the same poses
     if stereo_rows and not T.requires_grad and not norm.requires_grad:
         return _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, use_mixture_loss, automask,
                                   return_mean, defer, render_probability, dists)

@@ -105,6 +105,47 @@ def survey_fullsize_case(B=1, N=49, H=192, W=640, seed=1234, sigma_interior=Fals
                 g_rgb_rec=torch.randn(B, 3, H, W, generator=g2) * 1e-5, dense_disp=bool(n_xz))
 
 
+def decoder_plane_geometry(grid, residual, *, no_levels=49, xz_levels=14, disp_min=2.0, disp_max=300.0, xz_min=0.1852,
+                           xz_max=0.3704, rows=False):
+    """The plane set the reference decoder hands to the hot path (networks/depth_decoder.py:146-207, its defaults :28), from
+    ``inputs["grid"]`` [B,2,H,W] and the learnt level residuals [B, no_levels + xz_levels] (``sigmoid(residualconv) - 0.5``,
+    :150; zeros without ``--plane_residual``): ``no_levels`` fronto-parallel (xy) planes at exponentially spaced disparities
+    (:152) and ``xz_levels`` ground (xz) planes at heights ``h`` (:162), whose disparity grows with the image row (:171-181),
+    which exist below the horizon only (``padding_mask = y_grid >= 1e-7``, :166) and whose normal / distance for
+    homography_warp are ``[0, 1, t] / |.|``, ``h / |.|`` with ``t`` the principal point's offset from the crop centre
+    (:197-207).  Returns dict(disp_layered [B,N,H,W] (``rows``: [B,N,H,1] — every plane of this set is constant along x),
+    padding_mask (same shape, float), distance [B,N], norm [B,N,3]).  Benchmark / test input: nothing of the product."""
+    B, _, H, W = grid.shape
+    dt, dev = grid.dtype, grid.device
+    lv = torch.arange(no_levels, dtype=dt, device=dev)[None] + residual[:, :no_levels]
+    disp_xy = disp_max * (disp_min / disp_max) ** (lv / (no_levels - 1))                       # [B, no_levels]
+    distance = 0.1 * 0.58 * W / disp_xy
+    norm = torch.tensor([0.0, 0.0, 1.0], dtype=dt, device=dev)[None, None].expand(B, no_levels, -1)
+    Wd = 1 if rows else W
+    disp_layered = disp_xy[:, :, None, None].expand(-1, -1, H, Wd)
+    padding_mask = torch.ones(B, no_levels, H, Wd, dtype=dt, device=dev)
+    if xz_levels > 0:
+        gl = torch.arange(xz_levels, dtype=dt, device=dev)[None] + residual[:, no_levels:no_levels + xz_levels]
+        h = xz_min + (xz_max - xz_min) * gl / (xz_levels - 1)                                  # [B, xz_levels]
+        y = grid[:, 1:, :, :Wd].clone()                                                        # [B,1,H,Wd]
+        mask_xz = (y >= 1e-7).expand(-1, xz_levels, -1, -1)
+        y[y < 1e-7] = 1e-7
+        ground = h[:, :, None, None].expand(-1, -1, H, Wd) * 1.92 / (y / 2.0)
+        ground = (grid[:, :1, :, -1:] - grid[:, :1, :, :1]) / 2.0 * ground
+        ground = 0.1 * 0.58 * W / ground
+        disp_layered = torch.cat([disp_layered, ground], 1)
+        padding_mask = torch.cat([padding_mask, mask_xz.to(dt)], 1)
+        gyc = (grid[:, 1, -1, 0] + grid[:, 1, 0, 0]) / 2
+        py = (gyc + 1) * H / 2
+        fs = (grid[:, 0, 0, -1] - grid[:, 0, 0, 0]) / 2.0
+        t = (py - H / 2) / (H * 1.92 * fs)
+        inv = 1 / ((1 + t ** 2) ** 0.5)
+        xz_norm = torch.stack([torch.zeros_like(t), torch.ones_like(t), t], 1) * inv[:, None]
+        norm = torch.cat([norm, xz_norm[:, None].expand(-1, xz_levels, -1)], 1)
+        distance = torch.cat([distance, h * inv[:, None]], 1)
+    return dict(disp_layered=disp_layered, padding_mask=padding_mask, distance=distance, norm=norm)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # SURVEY.md §8f rank 4: the reference data pipeline's conventions without the dataset
 # ---------------------------------------------------------------------------------------------------------------------

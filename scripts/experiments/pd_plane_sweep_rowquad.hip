@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kQMaxWaves* kWave, NROWS == 1 ? PD_QFWD_OCC1 : PD_Q
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * kQRowCells(a.W));
   float* wsum = sdisp + a.N;
   const int y = block_row(wg_rowid(a.B, a.H), a.H);
-  const RowSel row = two_row_form(make_row_sel(y, a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(y, a.H), a.row_eps);
   float ph_sum;
   if (NROWS == 0) {   // both bodies in this kernel
     if (row.nrows == 2) ph_sum = rowquad_fwd_body<MIX, AUTO, 2, Q>(a, row, lds4, sdisp, rgb_rec, ph_map, stash);
@@ -784,7 +784,7 @@ template <bool MIX, int NROWS, int Q>
 __global__ __launch_bounds__(kQMaxWaves* kWave, NROWS == 1 ? PD_QBWD_OCC1 : PD_QBWD_OCC2) void rowquad_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   // LDS: colour rows float4[2*(W+8)] | sdisp[N] | kshift[N] | red[N] | rec[nseg][N][2] | irr[] | scratch[nwaves][2][260]
-  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.fast_rows != 0);
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
   if (NROWS != 0 && (row.nrows == 2) != (NROWS == 2)) return;   // workgroup-uniform: this row belongs to the other kernel
   float* sdisp = reinterpret_cast<float*>(lds4 + 2 * kQRowCells(a.W));
   int* kshift = reinterpret_cast<int*>(sdisp + a.N);

@@ -22,6 +22,21 @@ NOT_YET = set()
 ILL_CONDITIONED = {"homo_mix_stereo": {"g_Rt"}}
 
 
+@pytest.fixture(params=["exact", "fast"])
+def row_mode(request):
+    """Both treatments of a second source row whose bilinear weight is fp32 noise of the reference's y round trip (<= 6e-6 at
+    H = 192; pd_rowshift_common.h: two_row_form): PD_IMPL_EXACT_ROWS serves it, PD_IMPL_FAST_ROWS drops it below 2^-16.
+    VERDICT r4 #1a: every oracle / golden parity test of the disp path runs under both, at the same 1e-4 — which of the
+    two PD_IMPL_AUTO means (pd_sweep_auto_row_eps) follows from that, not from taste.  Only the row kernels look at the
+    mode; the other kernels run as under PD_IMPL_AUTO."""
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    prev = ops.SWEEP_IMPL
+    ops.SWEEP_IMPL = C.PD_IMPL_FAST_ROWS if request.param == "fast" else C.PD_IMPL_EXACT_ROWS
+    yield request.param
+    ops.SWEEP_IMPL = prev
+
+
 def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0, caps=True):
     """Three-way bound (cases.three_way) of a product result against the oracle in fp32 (the reference's arithmetic) and
     in fp64 (the same formulas, exact to ~1e-13), plus the absolute caps against fp64 (cases.FWD_CAP / GRAD_CAP)."""
@@ -61,7 +76,7 @@ XY_ONLY = ["disp_mix_r", "disp_mix_l", "disp_mix_automask", "disp_l1", "disp_l1_
 
 @pytest.mark.parametrize("name,opt_extra", [(n, None) for n in SMALL if n not in NOT_YET] +
                          [(n, dict(xz_levels=0, yz_levels=0)) for n in XY_ONLY])
-def test_fixture_vs_reference_golden(name, opt_extra):
+def test_fixture_vs_reference_golden(name, opt_extra, row_mode):
     """The reference-captured vectors (tests/golden/*.npz, written by make_golden.py from the imported reference) through
     the product API — once as the trainer hands them over in general (dense mask: row-shift kernels) and, for the xy-plane
     fixtures, with the options that route the same inputs to the headline kernels."""
@@ -73,7 +88,7 @@ def test_fixture_vs_reference_golden(name, opt_extra):
 
 @pytest.mark.parametrize("name", ["disp_mix_r", "disp_mix_l", "disp_mix_automask", "disp_l1", "disp_mix_integer_d",
                                   "disp_mix_oob"])
-def test_dense_disparity_path_matches_per_plane_path(name):
+def test_dense_disparity_path_matches_per_plane_path(name, row_mode):
     """The same xy-plane case fed as a dense [B,N,H,W] disparity map must give the same answer."""
     from gpu_cases import run_product
     case, want, run = load_fixture(name)
@@ -96,7 +111,7 @@ def test_dense_disparity_path_matches_per_plane_path(name):
     (209, dict(B=1, N=6, H=24, W=80, disp_min=0.5, disp_max=20.0, render_probability=True, stereo_T=False),
      dict(render_probability=True, warp_type="homography_warp")),
 ])
-def test_random_cases_vs_oracle(seed, kw, run):
+def test_random_cases_vs_oracle(seed, kw, run, row_mode):
     """Ragged sizes (W not a multiple of 64, odd H), many planes, against the oracle (fp32, the reference's arithmetic).
 
     homography_warp end to end uses the three-way bound: H_t2s = inverse(K (R + t n^T/d) K^-1) is
@@ -395,7 +410,7 @@ def test_fast_division_is_exact():
 
 
 @pytest.mark.parametrize("opt_extra", [None, dict(xz_levels=0, yz_levels=0)], ids=["dense-mask", "headline-kernels"])
-def test_fullsize_known_answers(opt_extra):
+def test_fullsize_known_answers(opt_extra, row_mode):
     """192x640, 49 planes: scalars captured from the reference (tests/golden/kat_fullsize.json) — with the
     decoder's dense all-ones mask handed over (row-shift kernels) and with the options that tell the trainer mirror the mask
     is all ones by construction (the headline kernels: segment-stream forward, row-stream backward)."""
@@ -430,7 +445,7 @@ def test_fullsize_known_answers(opt_extra):
             assert abs(v - exact[key]) <= 2.0 * abs(ref - exact[key]) + TOL * abs(exact[key]), (name, key, v, ref, exact[key])
 
 
-def test_fullsize_vs_oracle_tensors():
+def test_fullsize_vs_oracle_tensors(row_mode):
     """Every output tensor and gradient at the BASELINE size (B=1) against the oracle run on the host."""
     from gpu_cases import run_product
     from planedepth_amd.synthetic import survey_fullsize_case
@@ -445,11 +460,46 @@ def test_fullsize_vs_oracle_tensors():
         _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=str(run))
 
 
+def _band_limited(shape, gen, cutoff=0.12, lo=0.0, hi=1.0):
+    """White noise low-passed in the Fourier domain (keeps |f| <= cutoff of Nyquist per axis) and rescaled to [lo, hi]:
+    neighbouring rows / columns are strongly correlated, as network outputs and photographs are and white noise is not
+    (SURVEY.md H2's second parity set)."""
+    x = torch.randn(shape, generator=gen)
+    H, W = shape[-2:]
+    fy = torch.fft.fftfreq(H).abs()[:, None] * 2.0
+    fx = torch.fft.rfftfreq(W).abs()[None, :] * 2.0
+    keep = ((fy <= cutoff) & (fx <= cutoff)).to(x.dtype)
+    x = torch.fft.irfft2(torch.fft.rfft2(x) * keep, s=(H, W))
+    flat = x.flatten(-2)
+    mn, mx = flat.min(-1)[0][..., None, None], flat.max(-1)[0][..., None, None]
+    return lo + (hi - lo) * (x - mn) / (mx - mn)
+
+
+@pytest.mark.parametrize("automask", [False, True])
+def test_band_limited_inputs_fullsize_vs_oracle(automask, row_mode):
+    """SURVEY.md H2's second parity set at the BASELINE size: band-limited images, logits and sigma (smooth like network
+    outputs: the difference between neighbouring source rows is not white noise), both row modes, every tensor at 1e-4
+    against the fp32 oracle."""
+    from gpu_cases import run_product
+    from planedepth_amd.synthetic import survey_fullsize_case
+    case = survey_fullsize_case(sigma_interior=True)
+    g = torch.Generator().manual_seed(99)
+    B, N, H, W = case["logits"].shape
+    case["color_l"] = _band_limited((B, 3, H, W), g)
+    case["color_r"] = _band_limited((B, 3, H, W), g)
+    case["logits"] = _band_limited((B, N, H, W), g, lo=-3.0, hi=3.0)
+    case["sigma"] = _band_limited((B, N, H, W), g, lo=0.02, hi=0.9)
+    run = dict(automask=automask)
+    got = run_product(case, run, opt_extra=dict(xz_levels=0, yz_levels=0))
+    want = run_oracle(case, run)
+    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag="band/%s" % row_mode)
+
+
 def test_fast_rows_mode_is_opt_in_and_bounded():
     """PD_IMPL_FAST_ROWS drops a second source row whose bilinear weight is below 2^-16 (fp32 noise of the reference's y
-    round trip, a quarter of the rows at H=192).  The default keeps it (rounding-level agreement with the fp32 oracle);
-    the opt-in mode stays within the parity budget on random data (g_sigma under the three-way bound, see
-    test_fullsize_vs_oracle_tensors)."""
+    round trip, a quarter of the rows at H=192); PD_IMPL_EXACT_ROWS keeps it (rounding-level agreement with the fp32
+    oracle).  Both modes are distinct code paths, both inside the parity budget on random data; PD_IMPL_AUTO is one of the
+    two, or a threshold in between, and the library says which (pd_sweep_auto_row_eps)."""
     from gpu_cases import run_product
     from planedepth_amd import _capi as C
     from planedepth_amd import ops
@@ -457,16 +507,24 @@ def test_fast_rows_mode_is_opt_in_and_bounded():
     case = survey_fullsize_case(sigma_interior=True)
     want = run_oracle(case, dict())
     keys = ("rgb_rec", "ph_map", "g_logits", "g_disp_pp")
-    exact = run_product(case, dict())
-    ops.SWEEP_IMPL = C.PD_IMPL_FAST_ROWS
-    try:
-        fast = run_product(case, dict())
-    finally:
-        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
-    _compare(exact, want, keys=keys, tag="default", tol=1.5e-5)
-    _compare(fast, want, keys=keys, tag="fast_rows", tol=1e-4)
-    _compare3(fast, case, dict(), keys=("g_sigma",), tag="fast_rows")
+    res = {}
+    for impl in (C.PD_IMPL_EXACT_ROWS, C.PD_IMPL_FAST_ROWS, C.PD_IMPL_AUTO):
+        ops.SWEEP_IMPL = impl
+        try:
+            res[impl] = run_product(case, dict())
+        finally:
+            ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    exact, fast, auto = res[C.PD_IMPL_EXACT_ROWS], res[C.PD_IMPL_FAST_ROWS], res[C.PD_IMPL_AUTO]
+    _compare(exact, want, keys=keys, tag="exact_rows", tol=1.5e-5)
+    _compare(fast, want, keys=keys + ("g_sigma",), tag="fast_rows", tol=1e-4)
     assert not torch.equal(fast["rgb_rec"], exact["rgb_rec"])  # the two modes really are different code paths
+    eps = C.load().pd_sweep_auto_row_eps()
+    if eps == 0.0 or eps >= 2.0 ** -16:   # AUTO is one of the two pure modes
+        same_as = fast if eps > 0.0 else exact
+        for k in keys + ("g_sigma",):
+            assert torch.equal(auto[k], same_as[k]), k
+    else:
+        _compare(auto, want, keys=keys + ("g_sigma",), tag="auto", tol=1e-4)
 
 
 def test_size_independent_properties_at_benchmark_size():
@@ -1018,10 +1076,15 @@ def test_add_flip_right_inputs_takes_the_dataloaders_cpu_batch():
     assert all(not v.is_cuda for v in inputs.values())     # the caller's batch is left where it was
 
 
-def test_bench_spawns_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (bench.spawn_ranks);
-    on a one-GPU box PD_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 with gloo for the timing collectives.  The JSON
-    line must report two ranks, a comm block and finite numbers — through the HIP path of both ranks."""
+@pytest.mark.parametrize("gpus,ddp_model", [(2, "r18"), (4, "r50")])
+def test_bench_spawns_its_own_ranks(gpus, ddp_model):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (bench.spawn_ranks);
+    on a one-GPU box PD_BENCH_SHARE_GPU=1 puts all ranks on cuda:0 with gloo for the collectives.  The JSON line must report
+    N ranks, a comm block, every rank's shard in `value` and finite numbers — through the HIP path of all ranks — and the
+    DDP training-step block (three more DDP re-wraps for the bucket sizes, under its timer) must FINISH: at world 4 with the
+    ResNet-50 + dense-ASPP-shaped stand-in (BASELINE configs[2]'s 157 MB of gradients) as well as at world 2 with the
+    ResNet-18-shaped one.  A block that hangs or fails says so at the TOP level of the line (`ddp_step_timed_out` /
+    `ddp_step_failed`), which this test requires to be false."""
     import json
     import subprocess
     import sys
@@ -1029,20 +1092,24 @@ def test_bench_spawns_its_own_ranks():
     env = dict(os.environ, PD_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--no_cpu_baseline", "--no_next_rows", "--batch", "2", "--height", "64", "--width", "128", "--planes", "9"],
-                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+                          "--no_cpu_baseline", "--no_next_rows", "--batch", "2", "--height", "64", "--width", "128", "--planes", "9",
+                          "--ddp_model", ddp_model],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["comm"]["world_size"] == 2, res
+    assert res["n_gpus"] == gpus and res["comm"]["world_size"] == gpus, res
     assert res["value"] > 0 and res["ms_per_step"] > 0 and res["value"] == res["value"]
-    assert res["config"]["global_batch"] == 4      # weak scaling: every rank brings its own shard
-    # the DDP training-step block ran on both ranks (gloo carries DDP's all-reduce here): the figures SCALE runs will read
+    assert res["config"]["global_batch"] == gpus * 2      # weak scaling: every rank brings its own shard ...
+    assert abs(res["value"] - gpus * 2 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) <= 1e-3 * res["value"]   # ... and is counted
+    assert res["ddp_step_timed_out"] is False and res["ddp_step_failed"] is False, res.get("ddp_step")
+    # the DDP training-step block ran on all ranks (gloo carries DDP's all-reduce here): the figures SCALE runs will read
     # at 2/4/8 GPUs exist and are finite before an 8-GPU node ever sees this code
     blk = res["ddp_step"]
     assert "error" not in blk and "skipped" not in blk, blk
-    assert blk["world_size"] == 2 and blk["ms_per_step"] > 0 and blk["ms_per_step_without_gradient_sync"] > 0
+    assert blk["world_size"] == gpus and blk["ms_per_step"] > 0 and blk["ms_per_step_without_gradient_sync"] > 0
+    assert ("ResNet-50" in blk["network"]) == (ddp_model == "r50")
     import math
     for key in ("allreduce_alone_ms", "allreduce_exposed_ms"):
         assert math.isfinite(blk[key]) and blk[key] >= 0.0, (key, blk[key])
@@ -1115,7 +1182,7 @@ def test_two_rank_hip_shards_reproduce_the_full_batch():
     # BASELINE configs[2]: batch 12 per GPU — every tensor of all twelve images (the loss mean runs over the whole batch)
     ("batch12", dict(B=12, N=49, H=192, W=640), dict(), dict(yz_levels=0, xz_levels=0)),
 ])
-def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extra):
+def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extra, row_mode):
     """The other full-size configurations of BASELINE.json / SURVEY §8d against the fp32 oracle (B=1)."""
     from gpu_cases import run_product
     from planedepth_amd import _capi as C
@@ -1201,7 +1268,7 @@ def test_pred_self_images_vs_oracle():
     (305, dict(B=1, N=5, H=7, W=63, disp_min=0.5, disp_max=30.0, n_xz=2), dict()),             # one partial segment
     (306, dict(B=1, N=2, H=4, W=3, disp_min=0.1, disp_max=1.5, stereo_T=False), dict(warp_type="homography_warp")),
 ])
-def test_degenerate_shapes_vs_oracle(seed, kw, run):
+def test_degenerate_shapes_vs_oracle(seed, kw, run, row_mode):
     """Images narrower than one 64-lane segment, a single plane, disparities larger than the row (every tap out of
     view), the 2x2 minimum: the edge cases the reference's code admits (H, W >= 2: its normalisation divides by
     size - 1)."""
