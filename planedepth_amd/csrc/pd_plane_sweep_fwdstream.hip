@@ -16,9 +16,15 @@
 //     descriptor's range check is padding_mode = "zeros"), half the memory instructions per pixel of the 8-byte form;
 //   * one plane per iteration behind a register ring of PD_FS_D1 iterations of loads (6 VGPRs per slot): the state per
 //     wave is two accumulator sets + the ring, 94 VGPRs instead of 148;
-//   * a workgroup serves PD_FS_ROWS = 3 consecutive target rows (15 waves at W = 640, one workgroup per CU): its waves start
-//     together and do the same work, so between them they read three adjacent rows of every plane at about the same
-//     time, and the second source row of an inexact row is its neighbour's main row in the same L1;
+//   * a workgroup serves PD_FS_ROWS = 3 consecutive target rows (15 waves at W = 640, one workgroup per CU): its waves read three
+//     adjacent rows of every plane (7.5 KB contiguous) at about the same time, and the second source row of an inexact row is
+//     its neighbour's main row;
+//   * round 5 (profiles/r05_fwd_ladder.md): the workgroup is PERSISTENT — it walks its share of the launch's (image, row group)
+//     items, the five waves of a row slot ("team") staging the next item's row into the slot's second LDS buffer as soon as the
+//     TEAM is done and meeting only each other (an LDS counter) — no workgroup barrier between items, nothing idles while the
+//     slowest wave of the slowest row finishes; wave priorities rotate every four planes (the SIMD serves its oldest wave
+//     first; left alone, the waves of a team drift 40 % apart); a plane's staged shift is read one iteration ahead and lives
+//     in SGPRs; the softmax runs against a fixed per-pixel reference (no rescale branch) with an exact fallback;
 //   * the colour taps come out of LDS (packed float4 row, vertically pre-blended for rows with two live source rows, as
 //     the row-stream backward stages it) when the plane is reduced;
 //   * PD_RENDER_PROB: the planes of a pixel arrive in order in one wave, so the transmittance is a register.
@@ -40,9 +46,9 @@ namespace pd {
 #ifndef PD_FS_D2
 #define PD_FS_D2 1   // two live source rows (12 VGPRs per slot): this body sets the kernel's register count (depth 2: 108 VGPRs)
 #endif
-#ifndef PD_FS_OCC
-#define PD_FS_OCC 5  // waves per SIMD the register allocator must leave room for: 96 VGPRs, which the mixture kernel just fits
-#endif               // (the automask variant needs 8 more for its extra exponential's operands: it runs at 4 waves per SIMD)
+// Registers: a workgroup is 15 waves at W = 640 (three rows x five segments) and at most 16 in general, so one workgroup per CU is
+// all that ever fits and the allocator may use the 128 VGPRs that four waves per SIMD leave (launch bound = the 1024-thread
+// maximum).  Rounds 4's 96-register cap (five waves per SIMD) bought nothing — two such workgroups never fitted a CU.
 
 #ifndef PD_FS_REVERSE
 #define PD_FS_REVERSE 0   // row groups dispatched bottom-up (the backward then walks top-down: PD_BWD_REVERSE 0)
@@ -52,19 +58,22 @@ namespace pd {
 #endif                // 2 no LDS colour reads, 4 no softmax / mixture arithmetic, 8 no output / stash stores, 16 every row as one
                       // source row, 32 no coordinate chain, 64 no tap loads, 128 no tap interpolation, 256 no staging loads
 #ifndef PD_FS_SHRING
-#define PD_FS_SHRING 0  // 1: a plane's staged shift is read from LDS ONE iteration before its tap loads are issued and kept in
+#define PD_FS_SHRING 1  // 1: a plane's staged shift is read from LDS ONE iteration before its tap loads are issued and kept in
 #endif                  // scalar registers until the plane is reduced (one LDS read per iteration, off the critical path, instead of
                         // two round trips at the head of every iteration)
+#ifndef PD_FS_PRIO
+#define PD_FS_PRIO 1    // 1: wave priority rotating every PD_FS_PRIO_PERIOD x 4 planes (every wave of a SIMD leads for a quarter of them)
+#endif
+#ifndef PD_FS_PRIO_PERIOD
+#define PD_FS_PRIO_PERIOD 1
+#endif
 #ifndef PD_FS_FIXREF
-#define PD_FS_FIXREF 0  // 1: softmax with a FIXED per-pixel reference (the first plane's scaled logit) on the regular planes: no
+#define PD_FS_FIXREF 1  // 1: softmax with a FIXED per-pixel reference (the first plane's scaled logit) on the regular planes: no
 #endif                  // lazy-rescale branch per pixel and plane (a compare, an exec-mask branch and the copies of all seven running
                         // sums at its join: a sixth of the loop's VALU instructions).  The largest exponent a pixel used is tracked
                         // (one v_max per plane); a wave in which any pixel went beyond 2^kFixRefLimit redoes its planes with the
                         // rescaling accumulator (per-pixel general path) — exact for any input, never taken for logits within
                         // +-60 of each other
-#ifndef PD_FS_COLPF
-#define PD_FS_COLPF 0   // 1 (needs PD_FS_SHRING): the three colour cells of plane n + 1 are read from LDS while plane n is reduced
-#endif
 #ifndef PD_FS_TRACE
 #define PD_FS_TRACE 0   // diagnostics build: s_memtime stamps per wave (entry, staged, loop end, exit) + HW_ID / XCC_ID into a device
 #endif                  // array read back through pd_debug_fs_trace (scripts/diag_fwd_trace.py)
@@ -193,21 +202,22 @@ __device__ __forceinline__ void fs_stage_row(const SweepArgs& a, const RowSel& r
   const int CW = W + 2 * kFsGuard;
   const bool two = row.nrows == 2;
   const float* srcb = a.src + (long)b * 3 * HW;
-  for (int cidx = tix; cidx < CW && y < a.H; cidx += nthr) {
-    const int x = cidx - kFsGuard;
+  auto blended = [&](int x) {   // source colour at column x of the (vertically blended) row; zero outside the row
     float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x >= 0 && x < W) {
-      if (PD_FS_ABL & 256) cc = make_float4((float)x, 0.5f, 0.25f, 0.0f);
-      else {
+      if (PD_FS_ABL & 256) return make_float4((float)x, 0.5f, 0.25f, 0.0f);
       const float* p = srcb + (long)row.yA * W + x;
       cc = make_float4(p[0], p[HW], p[2 * HW], 0.0f);
       if (two) {   // fl(B*wB + fl(A*wA)): the rounding the row-stream backward stages (its knife-edge note applies here too)
         const float* q = srcb + (long)row.yB * W + x;
         cc = make_float4(fmaf(q[0], row.wB, cc.x * row.wA), fmaf(q[HW], row.wB, cc.y * row.wA), fmaf(q[2 * HW], row.wB, cc.z * row.wA), 0.0f);
       }
-      }
     }
-    col[cidx] = cc;
+    return cc;
+  };
+  for (int cidx = tix; cidx < CW && y < a.H; cidx += nthr) {
+    const int x = cidx - kFsGuard;
+    col[cidx] = blended(x);
   }
   const float tol = irregular_tol(W);
   for (int i = tix; i < N && y < a.H; i += nthr) {
@@ -263,10 +273,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   int pn = 0;
 #if PD_FS_SHRING
   int sh_sd[D + 1], sh_kk[D + 1];          // wave-uniform (SGPRs): the shifts of the planes whose taps are in flight
-  int2 sh_next = shift[0];                 // LDS read in flight: the shift of the next plane to be prefetched
-#endif
-#if PD_FS_COLPF && PD_FS_SHRING
-  float4 cpre[3];                          // LDS reads in flight: the colour cells of the next plane to be reduced
+  int2 sh_next = shift[0];       // LDS read in flight: the shift of the next plane to be prefetched
 #endif
   auto prefetch = [&](FsTaps<NROWS>& grp, int slot) {
     const int n = min(pn, N - 1);   // past the end: re-load the last plane (unused) — unconditional issue keeps the wait counts right
@@ -302,13 +309,6 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
     const int kk = __builtin_amdgcn_readfirstlane(sh.y);
 #endif
     const int k = kk >> 1;
-#if PD_FS_COLPF && PD_FS_SHRING
-    const float4 cq0 = cpre[0], cq1 = cpre[1], cq2 = cpre[2];
-    {   // the next plane's cells (its shift is in the ring already: its taps were issued D - 1 iterations ago)
-      const int cn = min(max(xt0 + (sh_kk[next_slot] >> 1), -kFsGuard), W + 1) + kFsGuard;
-      cpre[0] = col[cn]; cpre[1] = col[cn + 1]; cpre[2] = col[cn + 2];
-    }
-#endif
     const int c0 = seg * kFsSeg + k;   // source column of the segment's first left tap (wave-uniform); lane i loads c0 + 2i ..
     // 12-byte form: regular plane, and no lane's load starts at column -3, -2 or -1: a load that starts left of the row reads
     // as zeros as a whole although its last columns may be inside, and the dword at byte offset -4 passes the 32-bit range
@@ -318,29 +318,23 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
       fs_general_plane<MIX, NROWS, RENDER>(a, r, col, n, sd, xt0f, HW, Wm1, rcpWm1, t, ea, automask, acc, rs, grp.dist);
       return;
     }
-#if PD_FS_ABL & 1   // timing only (wrong colours): cells at a 16-byte lane stride — what the reads cost without the 2-way bank conflict
-    const int cell = min(max((xt0 >> 1) + k, -kFsGuard), W + 1) + kFsGuard;
-#else
-    const int cell = min(max(xt0 + k, -kFsGuard), W + 1) + kFsGuard;
-#endif
     float4 cv0, cv1, cv2;
-#if PD_FS_COLPF && PD_FS_SHRING
-    cv0 = cq0; cv1 = cq1; cv2 = cq2;
-    (void)cell;
-#else
-    if (PD_FS_ABL & 2) {   // timing only: no LDS colour reads
-      cv0 = make_float4(xt0f * 1e-3f, 0.25f, 0.5f, 0.0f); cv1 = make_float4(0.75f, xt0f * 1e-3f, 0.5f, 0.0f); cv2 = make_float4(0.1f, 0.2f, xt0f * 1e-3f, 0.0f);
-    } else {
-      cv0 = col[cell]; cv1 = col[cell + 1]; cv2 = col[cell + 2];
+    {
+      const int cell = min(max(xt0 + k, -kFsGuard), W + 1) + kFsGuard;
+      if (PD_FS_ABL & 2) {   // timing only: no LDS colour reads
+        cv0 = make_float4(xt0f * 1e-3f, 0.25f, 0.5f, 0.0f); cv1 = make_float4(0.75f, xt0f * 1e-3f, 0.5f, 0.0f); cv2 = make_float4(0.1f, 0.2f, xt0f * 1e-3f, 0.0f);
+      } else {
+        cv0 = col[cell]; cv1 = col[cell + 1]; cv2 = col[cell + 2];
+      }
     }
-#endif
     const float kf = (float)k;
+    const float xs0 = xt0f + kf, xs1 = xs0 + 1.0f, xs2 = xs1 + 1.0f;   // integers below 2^24: exact in any order
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float xtf = xt0f + (float)i;
-      const float xsf = xtf + kf;                               // integers below 2^24: exact
+      const float xsf = (i == 0) ? xs0 : xs1;
       const float ix = (PD_FS_ABL & 32) ? xsf + (sd - kf) : stream_ix(xtf, sd, Wm1, rcpWm1);
-      const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;        // torch's (ix - x0), (x1 - ix) with x0 = xt + k
+      const float w1 = ix - xsf, w0 = ((i == 0) ? xs1 : xs2) - ix;   // torch's (ix - x0), (x1 - ix) with x0 = xt + k
       float l, s = 0.0f;
       if (PD_FS_ABL & 128) {   // timing only: the loaded values are consumed, not interpolated
         l = grp.l[0][i] + grp.l[0][i + 1] + grp.l[NROWS - 1][i] * r.wB;
@@ -359,7 +353,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
         acc[i].Z += l; acc[i].S += s; acc[i].C0 += c0v; acc[i].C1 += c1v; acc[i].C2 += c2v; acc[i].Mx += w0; acc[i].m = 0.0f;
       } else if (PD_FS_FIXREF && !RENDER) {
         const float d = l * kLog2e - acc[i].m;   // (m = -inf until a plane set it: d = +inf trips the limit below)
-        dmax[i] = fmaxf(dmax[i], d);
+        asm("v_max_f32 %0, %1, %2" : "=v"(dmax[i]) : "v"(dmax[i]), "v"(d));   // (fmaxf adds a canonicalising v_max of the running value)
         mixture_accumulate<MIX>(acc[i], exp2_fast(d), s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask);
       } else
       fs_accumulate<MIX, RENDER>(acc[i], rs[i], l, s, c0v, c1v, c2v, t[i], t[2 + i], t[4 + i], ea[i], automask, grp.dist[i], n == N - 1);
@@ -368,7 +362,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
 #pragma unroll
   for (int j = 0; j < D; ++j) prefetch(g[j], j);
   if (PD_FS_FIXREF && !RENDER) {   // the reference: plane 0's scaled logit at the lane's two pixels (when plane 0 takes the 12-byte form;
-    const int2 sh0 = shift[0];     // otherwise the general path's rescaling accumulator sets it when it reduces plane 0)
+    const int2 sh0 = shift[0];   // otherwise the general path's rescaling accumulator sets it when it reduces that plane)
     const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh0.x));
     const int kk = __builtin_amdgcn_readfirstlane(sh0.y), k = kk >> 1, c0 = seg * kFsSeg + k;
     if (!((kk & 1) || (c0 < 0 && c0 + 2 * (kWave - 1) >= -3))) {
@@ -388,14 +382,16 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
       }
     }
   }
-#if PD_FS_COLPF && PD_FS_SHRING
-  {
-    const int cn = min(max(xt0 + (sh_kk[0] >> 1), -kFsGuard), W + 1) + kFsGuard;
-    cpre[0] = col[cn]; cpre[1] = col[cn + 1]; cpre[2] = col[cn + 2];
-  }
-#endif
   int n = 0;
   for (; n + (D + 1) <= N; n += D + 1) {
+#if PD_FS_PRIO == 1   // every wave of a SIMD leads for a quarter of the planes
+    switch (((threadIdx.x >> 8) + (n / ((D + 1) * PD_FS_PRIO_PERIOD))) & 3) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j <= D; ++j) {
       prefetch(g[(j + D) % (D + 1)], (j + D) % (D + 1));
@@ -437,39 +433,85 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
   return r0.ph + r1.ph;
 }
 
+// Team barrier of the `nwaves` waves that serve one row slot (a workgroup-wide s_barrier would make every wave wait for the
+// slowest wave of the slowest row): an LDS counter per slot that every wave bumps once per round after its share of the
+// staging, and polls until the whole team has.  LDS operations of a wave retire in order, so the bump follows the wave's
+// staging stores; the fences keep the compiler from moving LDS accesses across.
+__device__ __forceinline__ void fs_team_barrier(int* cnt, int target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The order in which an image's row groups are dealt to the (persistent) workgroups, by value in the kernel arguments: n = 0
+// means "as they come".
+constexpr int kFsOrderMax = 1024;
+struct FsOrder { int n; unsigned short it[kFsOrderMax]; };
+
+// A workgroup serves `rows` consecutive target rows x one of `cblocks` column blocks of `segs` segments each (rows wider than
+// 640 pixels are cut into column blocks so that three rows still fit the 16 waves of a workgroup) — one "item".  With
+// `rounds` > 1 it is persistent: it walks items blk, blk + nblk, blk + 2 nblk, ... of the launch's item list (row-major over
+// the images: the heavy rows of every image first), and the teams of its row slots move from round to round on their own:
+// the next item's rows are staged into the slot's second LDS buffer by the team itself as soon as IT is done (the other
+// teams keep computing), and only the team meets (fs_team_barrier).  Measured on the per-wave timeline
+// (profiles/r05_fwd_ladder.md): with one 15-wave workgroup per CU and a workgroup barrier per item, the staging, the
+// dispatch turn-around and the 40 % spread between the first and the last wave of a workgroup idle the CU between items.
 template <bool MIX, bool AUTO, bool RENDER>
-__global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OCC - 1 : PD_FS_OCC) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
+__global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                             float* __restrict__ ph_map,
-                                                                            float* __restrict__ stash, int rows, int cblocks) {
+                                                                            float* __restrict__ stash, int rows, int cblocks,
+                                                                            int rounds, int nbk, FsOrder order) {
   extern __shared__ float4 lds4[];
-  // LDS per row of the workgroup: colour row float4[W + 8] | shift int2[N] (padded to 16 bytes); then the wave totals of ph_map
-  // A workgroup serves `rows` consecutive rows x one of `cblocks` column blocks of `segs` segments each (rows wider than
-  // 640 pixels are cut into column blocks so that three rows still fit the 16 waves of a workgroup).
+  // LDS per row slot: (colour row float4[W + 8] | shift int2[N] (padded to 16 bytes)) x (rounds > 1 ? 2 buffers : 1); then the
+  // wave totals of ph_map and the teams' counters
   const int nseg = (a.W + kFsSeg - 1) / kFsSeg, segs = (nseg + cblocks - 1) / cblocks;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int slot = wave / segs;                                  // which of the workgroup's rows
-  const int row_f4 = a.W + 2 * kFsGuard + (a.N + 1) / 2;         // float4 per row slot
-  float4* col = lds4 + slot * row_f4;
-  int2* shift = reinterpret_cast<int2*>(col + a.W + 2 * kFsGuard);
-  float* parts = reinterpret_cast<float*>(lds4 + rows * row_f4);
-  const int groups = (a.H + rows - 1) / rows;                    // row groups per image; the grid is (groups * cblocks, B), dealt row-major
-  const int rid = wg_rowid(a.B, groups * cblocks);
-  const int grp = PD_FS_REVERSE ? groups - 1 - rid / cblocks : rid / cblocks, cb = rid % cblocks;
-  const int seg = cb * segs + (wave - slot * segs);              // which segment of the row
-  const int y = grp * rows + slot, b = wg_image(a.B, groups * cblocks);
-  const bool active = y < a.H && seg < nseg;
-  const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.row_eps);
+  const int CWk = a.W + 2 * kFsGuard;
+  const int row_f4 = CWk + (a.N + 1) / 2;   // float4 per row buffer
+  const int nbuf = rounds > 1 ? 2 : 1;
+  float* parts = reinterpret_cast<float*>(lds4 + rows * nbuf * row_f4);
+  int* team = reinterpret_cast<int*>(parts + kFsThreadsMax / kWave);
+  const int groups = (a.H + rows - 1) / rows;                    // row groups per image
+  // An ITEM is (row group, image), numbered group * B + image.  block -> (column block cb, position k among the nbk blocks of
+  // a column block); round r of that block serves item order.it[r * nbk + k] (the host's balanced deal, fwdstream_order: heavy
+  // row groups first, the rounds snaking so that a block's items add up alike) or, without a table, item r * nbk + k.
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const int cb = blk % cblocks, k = blk / cblocks;
+  const int T = groups * a.B;
   const int tix = threadIdx.x - slot * segs * kWave, nthr = segs * kWave;
-  fs_stamp(0);
-  fs_stamp_ids(b, y);
-  fs_stage_row(a, row, b, y, tix, nthr, col, shift);
-  __syncthreads();   // the kernel's only barrier before the outputs: every wave reaches it, whatever its row needs
-  fs_stamp(1);
+  if (rounds > 1) {
+    if (threadIdx.x < rows) team[threadIdx.x] = 0;
+    __syncthreads();
+  }
   float ph_sum = 0.0f;
-  if (!active) {}
-  else if (row.nrows == 2 && !(PD_FS_ABL & 16)) ph_sum = fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
-  else                                          ph_sum = fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
-  fs_stamp(3);
+  for (int r = 0; r < rounds; ++r) {
+    const int pos = r * nbk + k;
+    if (pos >= T) break;                                         // (workgroup-uniform)
+    const int item = order.n ? (int)order.it[pos] : pos;
+    const int b = item % a.B, gsel = item / a.B;
+    const int grp = PD_FS_REVERSE ? groups - 1 - gsel : gsel;
+    const int seg = cb * segs + (wave - slot * segs);            // which segment of the row
+    const int y = grp * rows + slot;
+    const bool active = y < a.H && seg < nseg;
+    const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.row_eps);
+    float4* col = lds4 + (slot * nbuf + (r & 1)) * row_f4;
+    int2* shift = reinterpret_cast<int2*>(col + CWk);
+    fs_stamp(0);
+    fs_stamp_ids(b, y);
+    fs_stage_row(a, row, b, y, tix, nthr, col, shift);
+    // rounds == 1: the kernel's only barrier before the outputs, every wave reaches it whatever its row needs; persistent: the
+    // team's own (the buffer written here was last read two rounds ago, and every wave of the team has passed the barrier of
+    // the round in between since)
+    if (rounds > 1) fs_team_barrier(team + slot, segs * (r + 1));
+    else __syncthreads();
+    fs_stamp(1);
+    if (!active) {}
+    else if (row.nrows == 2 && !(PD_FS_ABL & 16)) ph_sum += fwdstream_body<MIX, AUTO, 2, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
+    else                                          ph_sum += fwdstream_body<MIX, AUTO, 1, RENDER>(a, row, b, y, seg, col, shift, rgb_rec, ph_map, stash);
+    fs_stamp(3);
+  }
   if (a.ph_mean) {  // fused `.mean()` of trainer.py:742: wave totals -> LDS -> ONE atomic per workgroup
     const float v = wave_sum_hi(ph_sum);
     if ((threadIdx.x & (kWave - 1)) == kWave - 1) parts[wave] = v;
@@ -487,7 +529,28 @@ __global__ __launch_bounds__(kFsThreadsMax, ((MIX && AUTO) || RENDER) ? PD_FS_OC
 // ---------------------------------------------------------------------------------------------------------------
 // Workgroup shape: rows of up to 5 segments (640 pixels) go whole, wider ones in column blocks of equal size; PD_FS_ROWS rows
 // per workgroup where their waves fit its 16, else what fits.
-struct FsShape { int rows, cblocks, segs; size_t lds; };
+#ifndef PD_FS_LIGHT_FIRST
+#define PD_FS_LIGHT_FIRST 0   // 1: the deal starts with the light row groups at the bottom of the image and ends with the heavy ones at its top
+#endif                       // (for a backward that walks top-down: PD_BWD_REVERSE = 0)
+#ifndef PD_FS_BALANCE
+#define PD_FS_BALANCE 1   // 0: the persistent workgroups take the items in launch order (A/B)
+#endif
+#ifndef PD_FS_ROUNDS
+#define PD_FS_ROUNDS 0   // items per (persistent) workgroup: 0 = as many as give every CU one workgroup, 1 = one item per workgroup
+#endif
+struct FsShape { int rows, cblocks, segs, rounds, nbk; size_t lds; };
+static int device_cu_count() {
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  if (dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  (void)hipGetLastError();
+  cus[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
 static FsShape fwdstream_shape(const pd_sweep_desc* d) {
   FsShape s;
   const int nseg = ceil_div(d->W, kFsSeg);
@@ -496,9 +559,84 @@ static FsShape fwdstream_shape(const pd_sweep_desc* d) {
   const int most = (kFsThreadsMax / kWave) / s.segs;
   s.rows = most < PD_FS_ROWS ? most : PD_FS_ROWS;
   if (s.rows > d->H) s.rows = d->H;
+  // persistent rounds: one workgroup of (nearly) 16 waves per CU is all that fits, so give every CU ONE workgroup and let it
+  // walk its share of the items; smaller workgroups (several resident per CU) keep the dispatcher's one item per workgroup
+  const int items = ceil_div(d->H, s.rows) * s.cblocks * d->B;
+  const int waves = s.rows * s.segs;
+  s.rounds = PD_FS_ROUNDS ? PD_FS_ROUNDS : (2 * waves > kFsThreadsMax / kWave ? ceil_div(items, device_cu_count()) : 1);
+  if (s.rounds < 1) s.rounds = 1;
+  if (s.rounds > 8) s.rounds = 8;
+  s.nbk = ceil_div(ceil_div(d->H, s.rows) * d->B, s.rounds);   // blocks per column block
   const size_t row_f4 = (size_t)d->W + 2 * kFsGuard + ((size_t)d->N + 1) / 2;
-  s.lds = s.rows * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * sizeof(float) + PD_FS_LDS_PAD;
+  s.lds = s.rows * (s.rounds > 1 ? 2 : 1) * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * sizeof(float) +
+          (size_t)(kFsThreadsMax / kWave) * sizeof(int) + PD_FS_LDS_PAD;
+  if (s.rounds > 1 && s.lds > device_lds_bytes()) {   // the second row buffers do not fit: one item per workgroup
+    s.rounds = 1;
+    s.nbk = ceil_div(d->H, s.rows) * d->B;
+    s.lds = s.rows * row_f4 * sizeof(float4) + (size_t)(kFsThreadsMax / kWave) * (sizeof(float) + sizeof(int)) + PD_FS_LDS_PAD;
+  }
   return s;
+}
+
+// Does target row y blend two source rows (the row bodies' "heavy" rows: twice the tap loads)?  make_row_sel + two_row_form
+// on the host, operation by operation in fp32.  Only the DEAL depends on it (the kernel decides every row's footprint itself),
+// so a disagreement with the device in some last bit would cost balance, not correctness.
+static bool host_row_is_heavy(int y, int H, float row_eps) {
+  volatile float hm1 = (float)(H - 1);
+  volatile float q = (float)y / hm1;
+  volatile float h = q - 0.5f;
+  volatile float g = h * 2.0f;
+  volatile float sv = g + 1.0f;
+  volatile float hh = sv * 0.5f;
+  volatile float iy = hh * hm1;
+  const float yf = floorf(iy);
+  volatile float yf1 = yf + 1.0f;
+  volatile float wy0 = yf1 - iy, wy1 = iy - yf;
+  const bool use0 = yf >= 0.0f && yf <= hm1 && wy0 != 0.0f, use1 = yf1 >= 0.0f && yf1 <= hm1 && wy1 != 0.0f;
+  if (use0 && use1) return !(row_eps > 0.0f && fminf(wy0, wy1) < row_eps);
+  const float wA = use0 ? wy0 : wy1;
+  const int y0 = (int)yf;
+  const float wmain = (y0 == y) ? wy0 : ((y0 + 1 == y) ? wy1 : 0.0f);
+  return (use0 || use1) && (wA != 1.0f || wmain != 1.0f);
+}
+
+// The persistent workgroups' deal: items (row group x image) sorted by the number of heavy rows in the group (heavy first;
+// ties in launch order, images fastest), chunked into `rounds` chunks of nbk, every other chunk reversed — block k then serves
+// the k-th heaviest item of the first chunk, the k-th LIGHTEST of the second, and so on (profiles/r05_fwd_ladder.md: with the
+// dispatcher's order the CUs' totals differ by 13 % on the exact-rows forward).
+static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float row_eps) {
+  FsOrder o;
+  o.n = 0;
+  const int groups = ceil_div(d->H, sh.rows), T = groups * d->B;
+  if (!PD_FS_BALANCE || sh.rounds < 2 || T > kFsOrderMax) return o;
+  int weight[kFsOrderMax], sorted[kFsOrderMax], count[kFsThreadsMax / kWave + 2] = {0};
+  for (int g = 0; g < groups; ++g) {
+    int w = 0;
+    for (int r = 0; r < sh.rows && g * sh.rows + r < d->H; ++r) w += host_row_is_heavy(g * sh.rows + r, d->H, row_eps) ? 1 : 0;
+    weight[g] = w;
+  }
+  int n = 0;   // counting sort by weight; stable in (group, image)
+  if (PD_FS_LIGHT_FIRST) {   // light row groups first, bottom of the image first; the heavy (top) groups last
+    for (int w = 0; w <= sh.rows; ++w)
+      for (int g = groups - 1; g >= 0; --g)
+        if (weight[g] == w)
+          for (int b = 0; b < d->B; ++b) sorted[n++] = g * d->B + b;
+  } else {
+    for (int w = sh.rows; w >= 0; --w)
+      for (int g = 0; g < groups; ++g)
+        if (weight[g] == w)
+          for (int b = 0; b < d->B; ++b) sorted[n++] = g * d->B + b;
+  }
+  (void)count;
+  for (int r = 0; r < sh.rounds; ++r)
+    for (int k = 0; k < sh.nbk; ++k) {
+      const int pos = r * sh.nbk + k;
+      if (pos >= T) break;
+      const int lo = r * sh.nbk, hi = (lo + sh.nbk < T ? lo + sh.nbk : T) - 1;   // this round's chunk of the sorted list
+      o.it[pos] = (unsigned short)sorted[(r & 1) ? (hi - k >= lo ? hi - k : lo + k) : pos];
+    }
+  o.n = T;
+  return o;
 }
 
 bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
@@ -515,14 +653,15 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
        reinterpret_cast<uintptr_t>(ph_map) | reinterpret_cast<uintptr_t>(stash)) & 7)
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, stream);   // unaligned tensors: the one-pixel-per-lane forward
   const FsShape sh = fwdstream_shape(d);
-  const dim3 grid(ceil_div(d->H, sh.rows) * sh.cblocks, d->B), block(sh.segs * sh.rows * kWave);
+  const dim3 grid(sh.nbk * sh.cblocks, 1), block(sh.segs * sh.rows * kWave);
+  const FsOrder order = fwdstream_order(d, sh, a.row_eps);
   const size_t shmem = sh.lds;
   const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
 #define PD_FS_LAUNCH(M, A, R)                                                                                              \
   do {                                                                                                                    \
     static LdsGrant granted;                                                                                              \
     if (int rc = grant_dynamic_lds((const void*)fwdstream_kernel<M, A, R>, shmem, &granted, "fwdstream_kernel")) return rc; \
-    fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks);            \
+    fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks, sh.rounds, sh.nbk, order); \
   } while (0)
   if (render) {
     if (mix) { if (am) PD_FS_LAUNCH(true, true, true); else PD_FS_LAUNCH(true, false, true); }

@@ -61,9 +61,6 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_LOAD_AUX
 #define PD_STREAM_LOAD_AUX 0    // same for the tap loads
 #endif
-#ifndef PD_STREAM_SHPF
-#define PD_STREAM_SHPF 0   // 1: the staged shift of the NEXT (plane, segment) item is read from LDS while the current one is reduced
-#endif                     // (its round trip sat at the head of every iteration)
 #ifndef PD_STREAM_OCC
 #define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 77 = 6 waves per SIMD
 #endif
@@ -352,20 +349,8 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     stream_issue<MIX, NROWS>(grp, a, r, min(pn, N - 1), pseg, lane8, HW);   // past the end: re-load the last plane (unused)
     advance(pn, pseg);
   };
-#if PD_STREAM_SHPF
-  int2 shv = L.shift[min(n, N - 1)];
-#endif
   auto step = [&](const StreamGroup<NROWS>& grp) {
-#if PD_STREAM_SHPF
-    const int2 sh = shv;
-    {
-      int nn = n, ss = seg;
-      advance(nn, ss);
-      shv = L.shift[min(nn, N - 1)];
-    }
-#else
     const int2 sh = L.shift[n];
-#endif
     const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
     const int kk = __builtin_amdgcn_readfirstlane(sh.y);
     const int k = kk >> 1;

@@ -37,6 +37,18 @@ def row_mode(request):
     ops.SWEEP_IMPL = prev
 
 
+# Where PD_IMPL_FAST_ROWS is beyond BASELINE's 1e-4 (measured: profiles/r05_parity_rows.md — white-noise inputs at full size;
+# the small fixtures, the KATs and the band-limited set hold 1e-4 in both modes).  This is the test-made decision VERDICT r4 #1a
+# asked for: the mode is red at the contract's tolerance on configs[1]/[2]/[3]/[4]-sized inputs (worst: g_sigma 3.1e-4 at batch 12;
+# g_logits 1.5e-2 of a 7.8e-6 range on the horizon row of the 49 + 14 plane set), so PD_IMPL_AUTO keeps every second source
+# row (pd_sweep_auto_row_eps() == 0) and FAST_ROWS stays an opt-in approximation, held here to 2 x what was measured.
+FAST_ROWS_TOL = {"fullsize": 2e-4, "n63_xz": 3e-2, "hr": 3e-4, "batch12": 6e-4}
+
+
+def _row_tol(row_mode, label):
+    return TOL if row_mode == "exact" else FAST_ROWS_TOL[label]
+
+
 def _compare3(got, case, run, keys=None, tag="", skip=(), factor=2.0, caps=True):
     """Three-way bound (cases.three_way) of a product result against the oracle in fp32 (the reference's arithmetic) and
     in fp64 (the same formulas, exact to ~1e-13), plus the absolute caps against fp64 (cases.FWD_CAP / GRAD_CAP)."""
@@ -356,6 +368,41 @@ def test_segment_stream_forward_equals_the_plane_group_forward(B, N, H, W, sign,
     assert abs(float(old[3]) - float(old[1].mean())) <= 1e-5 * abs(float(old[3]))
 
 
+@pytest.mark.parametrize("kind", ["first_plane_far_below", "one_plane_far_above", "nan_logit"])
+def test_fixed_reference_softmax_falls_back_on_extreme_logits(kind):
+    """The segment-stream forward's softmax runs against a FIXED per-pixel reference (the first plane's scaled logit) and
+    re-does a wave's planes with the rescaling accumulator when a term went beyond 2^90 (pd_plane_sweep_fwdstream.hip:
+    PD_FS_FIXREF).  Logit sets that trip it — the first plane 300 below the rest; one plane 300 above — and a NaN logit
+    (which must propagate like the reference's softmax, not trip anything) against the oracle and the plane-group forward."""
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C
+    from planedepth_amd import ops
+    from planedepth_amd.synthetic import build_case
+    case = build_case(B=1, N=7, H=9, W=256, seed=77, disp_min=0.5, disp_max=30.0, sigma_interior=True)
+    if kind == "first_plane_far_below":
+        case["logits"][:, 0] -= 300.0
+        case["logits"][:, 0, :, :40] -= 1000.0          # (and some of it below exp's range altogether)
+    elif kind == "one_plane_far_above":
+        case["logits"][:, 3, 2:6] += 300.0
+    else:
+        case["logits"][0, 2, 4, 100] = float("nan")
+    extra = dict(xz_levels=0, yz_levels=0)
+    got = run_product(case, {}, opt_extra=extra)
+    ops.SWEEP_IMPL = C.PD_IMPL_ROWS1
+    try:
+        old = run_product(case, {}, opt_extra=extra)
+    finally:
+        ops.SWEEP_IMPL = C.PD_IMPL_AUTO
+    if kind == "nan_logit":
+        for k in ("rgb_rec", "ph_map"):
+            assert torch.equal(torch.isnan(got[k]), torch.isnan(old[k])), k
+            m = ~torch.isnan(old[k])
+            assert rel_err(got[k][m], old[k][m]) < 3e-6, k
+        return
+    _compare(got, {k: old[k] for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma")}, tag=kind + " vs plane-group", tol=3e-6)
+    _compare(got, run_oracle(case, {}), keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=kind)
+
+
 def test_rowstream_backward_at_the_high_resolution_configuration():
     """BASELINE configs[4] (384x1280, 49 planes; one image here): the packed LDS context and 12-wave workgroups of the wide
     rows against the target-ordered row-shift backward on the same forward."""
@@ -457,7 +504,8 @@ def test_fullsize_vs_oracle_tensors(row_mode):
         # arithmetic" is the thing to match, as BASELINE.json's north_star asks.
         # (g_sigma carries 1/sigma^3-type amplification — the fp32 oracle is 2.6e-4 away from the fp64 value — and was
         # held to 2e-4 in round 1; measured 3.4e-6 against the fp32 oracle now: profiles/r02_parity.md)
-        _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=str(run))
+        _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=str(run),
+                 tol=_row_tol(row_mode, "fullsize"))
 
 
 def _band_limited(shape, gen, cutoff=0.12, lo=0.0, hi=1.0):
@@ -516,13 +564,15 @@ def test_fast_rows_mode_is_opt_in_and_bounded():
             ops.SWEEP_IMPL = C.PD_IMPL_AUTO
     exact, fast, auto = res[C.PD_IMPL_EXACT_ROWS], res[C.PD_IMPL_FAST_ROWS], res[C.PD_IMPL_AUTO]
     _compare(exact, want, keys=keys, tag="exact_rows", tol=1.5e-5)
-    _compare(fast, want, keys=keys + ("g_sigma",), tag="fast_rows", tol=1e-4)
+    _compare(fast, want, keys=keys, tag="fast_rows", tol=1e-4)
+    _compare(fast, want, keys=("g_sigma",), tag="fast_rows", tol=FAST_ROWS_TOL["fullsize"])
     assert not torch.equal(fast["rgb_rec"], exact["rgb_rec"])  # the two modes really are different code paths
     eps = C.load().pd_sweep_auto_row_eps()
     if eps == 0.0 or eps >= 2.0 ** -16:   # AUTO is one of the two pure modes
         same_as = fast if eps > 0.0 else exact
-        for k in keys + ("g_sigma",):
+        for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma"):
             assert torch.equal(auto[k], same_as[k]), k
+        assert rel_err(auto["g_disp_pp"], same_as["g_disp_pp"]) < 1e-6   # (summed with LDS float atomics: order-dependent rounding)
     else:
         _compare(auto, want, keys=keys + ("g_sigma",), tag="auto", tol=1e-4)
 
@@ -1193,7 +1243,7 @@ def test_other_baseline_configs_fullsize_vs_oracle(label, case_kw, run, opt_extr
     if label == "n63_xz":
         assert ops.LAST_SWEEP_FLAGS & C.PD_DISP_ROWS and ops.LAST_SWEEP_FLAGS & C.PD_MASK_ROWS
     want = run_oracle(case, run)
-    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=label)
+    _compare(got, want, keys=("rgb_rec", "ph_map", "ph_loss", "g_logits", "g_sigma", "g_disp_pp"), tag=label, tol=_row_tol(row_mode, label))
 
 
 @pytest.mark.parametrize("impl", ["rows", "general"])
@@ -2062,6 +2112,40 @@ def test_uniform_backward_never_reads_shared_memory_it_did_not_write(rot, zoom):
         C.check(C.load().pd_debug_poison_lds(C.stream_handle()), "pd_debug_poison_lds")
         (ph_mean + rgb.sum() * 1e-3).backward()
         assert bool(torch.isfinite(lg.grad).all()) and bool(torch.isfinite(sg.grad).all())
+
+
+def test_two_host_threads_on_one_device_equal_the_serial_result():
+    """The header's threading statement (include/planedepth_hip.h: per-device caches in atomics, the rare dynamic-LDS raise
+    under a mutex): two Python threads drive the path on the SAME device at the same time, each on its own stream, at a shape
+    whose kernels need more than the default 64 KB of LDS per workgroup (384 x 1280: the persistent forward's double row
+    buffers, the packed row-stream backward) — the first call of each thread races the other for the one-time
+    hipFuncSetAttribute.  Results must be bit-identical to the same cases run one after the other (the per-plane disparity gradient, summed with LDS
+    float atomics, to rounding)."""
+    import threading
+    from gpu_cases import run_product
+    from planedepth_amd.synthetic import survey_fullsize_case
+    cases = [survey_fullsize_case(B=1, N=11, H=96, W=1280, seed=500 + i, sigma_interior=True) for i in range(2)]
+    extra = dict(xz_levels=0, yz_levels=0)
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    out[i] = run_product(cases[i], {}, opt_extra=extra)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        serial = run_product(cases[i], {}, opt_extra=extra)
+        for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma"):
+            assert torch.equal(out[i][k], serial[k]), (i, k)
+        assert rel_err(out[i]["g_disp_pp"], serial["g_disp_pp"]) < 1e-6   # (summed with LDS float atomics: order-dependent rounding)
 
 
 def test_launches_follow_torchs_current_stream():
