@@ -529,9 +529,6 @@ __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, f
 // ---------------------------------------------------------------------------------------------------------------
 // Workgroup shape: rows of up to 5 segments (640 pixels) go whole, wider ones in column blocks of equal size; PD_FS_ROWS rows
 // per workgroup where their waves fit its 16, else what fits.
-#ifndef PD_FS_LIGHT_FIRST
-#define PD_FS_LIGHT_FIRST 0   // 1: the deal starts with the light row groups at the bottom of the image and ends with the heavy ones at its top
-#endif                       // (for a backward that walks top-down: PD_BWD_REVERSE = 0)
 #ifndef PD_FS_BALANCE
 #define PD_FS_BALANCE 1   // 0: the persistent workgroups take the items in launch order (A/B)
 #endif
@@ -609,25 +606,19 @@ static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float 
   o.n = 0;
   const int groups = ceil_div(d->H, sh.rows), T = groups * d->B;
   if (!PD_FS_BALANCE || sh.rounds < 2 || T > kFsOrderMax) return o;
-  int weight[kFsOrderMax], sorted[kFsOrderMax], count[kFsThreadsMax / kWave + 2] = {0};
+  int weight[kFsOrderMax], sorted[kFsOrderMax];
   for (int g = 0; g < groups; ++g) {
     int w = 0;
     for (int r = 0; r < sh.rows && g * sh.rows + r < d->H; ++r) w += host_row_is_heavy(g * sh.rows + r, d->H, row_eps) ? 1 : 0;
     weight[g] = w;
   }
-  int n = 0;   // counting sort by weight; stable in (group, image)
-  if (PD_FS_LIGHT_FIRST) {   // light row groups first, bottom of the image first; the heavy (top) groups last
-    for (int w = 0; w <= sh.rows; ++w)
-      for (int g = groups - 1; g >= 0; --g)
-        if (weight[g] == w)
-          for (int b = 0; b < d->B; ++b) sorted[n++] = g * d->B + b;
-  } else {
-    for (int w = sh.rows; w >= 0; --w)
-      for (int g = 0; g < groups; ++g)
-        if (weight[g] == w)
-          for (int b = 0; b < d->B; ++b) sorted[n++] = g * d->B + b;
-  }
-  (void)count;
+  int n = 0;   // counting sort by weight, descending; stable in (group, image).  (Light groups first with a top-down backward,
+               // so that each kernel starts on what the other read last AND the backward starts with its heavy rows: measured
+               // slower, forward 0.0954 / backward 0.1766 against 0.0914 / 0.1752 ms)
+  for (int w = sh.rows; w >= 0; --w)
+    for (int g = 0; g < groups; ++g)
+      if (weight[g] == w)
+        for (int b = 0; b < d->B; ++b) sorted[n++] = g * d->B + b;
   for (int r = 0; r < sh.rounds; ++r)
     for (int k = 0; k < sh.nbk; ++k) {
       const int pos = r * sh.nbk + k;
