@@ -198,6 +198,30 @@ int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tg
                        float* g_sigma, float* g_plane, float* g_dists, float* workspace, pd_stream_t stream);
 
 /*
+ * pd_plane_sweep_bwd with the backward of the fused decoder tail (pd_decoder_tail_fwd, networks/depth_decoder.py:258-291)
+ * riding along — SURVEY.md 8f rank 1's "removes the round-trips": where the decoder's logits / sigma come from
+ * pd_decoder_tail_fwd without a padding mask (xy planes only), the gradients this call writes are those of the decoder's
+ * CONV outputs:
+ *   g_raw_logits = g_logits + t,  g_raw_sigma = (g_sigma - t / sigma) * sigmoid'(raw_sigma) * [clamp passed],
+ *   t = gD (d_n - disp) P_n,  P = softmax(logits) / sigma / sum(pi / sigma),  gD = g_disp - g_depth * 0.1 * 0.58 * W / disp^2,
+ * and g_plane [B,N] carries the sum of the warp's and the tail's (sum_pixels gD P_n) disparity gradients.  The
+ * [B,N,H,W]-sized g_logits / g_sigma are then never re-read by a tail kernel (pd_decoder_tail_bwd reads 4 N + writes 2 N
+ * floats per pixel for what costs this kernel ~20 instructions per element on values it holds anyway).
+ *   logits, sigma   what pd_decoder_tail_fwd returned (logits = its raw_logits input when there is no mask)
+ *   raw_sigma       [B,N,H,W] the sigma conv's output (read only where sigma sits on the clamp's lower bound)
+ *   tail_stash, disp  pd_decoder_tail_fwd's stash [B,2,H,W] and disp [B,1,H,W]
+ *   g_disp, g_depth   [B,1,H,W] upstream gradients of the tail's disp / depth outputs, either may be NULL
+ * Served where pd_sweep_bwd_tail_fuses(d) == 1 (PD_WARP_DISP, PD_MIXTURE, one disparity per plane, sign = +-1, the row-stream
+ * backward's plain LDS layout); PD_ERR_UNSUPPORTED otherwise (the caller then runs pd_plane_sweep_bwd + pd_decoder_tail_bwd).
+ */
+int pd_sweep_bwd_tail_fuses(const pd_sweep_desc* d);
+int pd_plane_sweep_bwd_tail(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                            const float* sigma, const float* plane, const float* rgb_rec, const float* stash,
+                            const float* g_rgb_rec, const float* g_ph_map, const float* g_ph_mean, const float* raw_sigma,
+                            const float* tail_stash, const float* disp, const float* g_disp, const float* g_depth,
+                            float* g_raw_logits, float* g_raw_sigma, float* g_plane, float* workspace, pd_stream_t stream);
+
+/*
  * The per-plane tensors the reference stores in `outputs` and the fused path never needs (trainer.py:582-602):
  * rgb_rec_layered [B,N,3,H,W], logit_rec, probability_rec, sigma_rec, pi_rec [B,N,H,W].  Any output may be NULL.
  * Forward only (values for logging / inspection; gradients flow through pd_plane_sweep_fwd/bwd).

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 14),
     "pd_plane_sweep_bwd": (_I, [_D] + [_P] * 20),
     "pd_plane_sweep_layers": (_I, [_D] + [_P] * 14),
+    "pd_sweep_bwd_tail_fuses": (_I, [_D]),
+    "pd_plane_sweep_bwd_tail": (_I, [_D] + [_P] * 20),
     "pd_uniform_gather_pair": (_I, [_D] + [_P] * 9),
     "pd_uniform_fwd_pair": (_I, [_D] + [_P] * 3 + [ctypes.POINTER(SweepView)] * 2 + [_P]),
     "pd_uniform_bwd_pair": (_I, [_D] + [_P] * 3 + [ctypes.POINTER(SweepView)] * 2 + [_P] * 3),

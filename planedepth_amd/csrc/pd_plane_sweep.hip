@@ -546,12 +546,14 @@ extern "C" int pd_plane_sweep_fwd(const pd_sweep_desc* d, const float* src, cons
   return check_launch("sweep_fwd_kernel");
 }
 
-extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
-                                  const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
-                                  const float* padding_mask, const float* dists, const float* rgb_rec,
-                                  const float* stash, const float* g_rgb_rec, const float* g_ph_map,
-                                  const float* g_ph_mean, float* g_logits, float* g_sigma, float* g_plane,
-                                  float* g_dists, float* workspace, pd_stream_t stream_) {
+struct TailIn { const float* raw_sigma; const float* stash; const float* disp; const float* g_disp; const float* g_depth; };
+
+static int sweep_bwd_impl(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                          const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                          const float* padding_mask, const float* dists, const float* rgb_rec,
+                          const float* stash, const float* g_rgb_rec, const float* g_ph_map,
+                          const float* g_ph_mean, float* g_logits, float* g_sigma, float* g_plane,
+                          float* g_dists, float* workspace, pd_stream_t stream_, const TailIn* tail) {
   int rc = validate(d, src, logits, sigma, plane, plane_aux, inv_K3, padding_mask);
   if (rc) return rc;
   PD_REQUIRE(tgt && rgb_rec && stash, "tgt/rgb_rec/stash must not be NULL");
@@ -576,8 +578,22 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
 #endif
     // default: lanes own aligned source slots, waves stream along plane rows (pd_plane_sweep_rowstream.hip);
     // PD_IMPL_ROWS1 keeps the target-ordered row-shift backward (cross-check, A/B)
+    if (tail) {   // pd_plane_sweep_bwd_tail: the row-stream backward with the decoder tail's backward riding along
+      if (d->impl == PD_IMPL_ROWS1 || !rowstream_bwd_tail_applicable(d, ak)) {
+        set_error("pd_plane_sweep_bwd_tail: not served for this descriptor (pd_sweep_bwd_tail_fuses)");
+        return PD_ERR_UNSUPPORTED;
+      }
+      PD_REQUIRE(g_logits && g_sigma, "pd_plane_sweep_bwd_tail writes both g_raw_logits and g_raw_sigma");
+      o.tail_raw_sigma = tail->raw_sigma; o.tail_stash = tail->stash; o.tail_disp = tail->disp;
+      o.tail_g_disp = tail->g_disp; o.tail_g_depth = tail->g_depth;
+      return rowstream_bwd(d, ak, o, stream);
+    }
     if (d->impl != PD_IMPL_ROWS1 && rowstream_bwd_applicable(d, ak)) return rowstream_bwd(d, ak, o, stream);
     return rowshift_bwd(d, ak, o, stream);
+  }
+  if (tail) {
+    set_error("pd_plane_sweep_bwd_tail: not served for this descriptor (pd_sweep_bwd_tail_fuses)");
+    return PD_ERR_UNSUPPORTED;
   }
   if (d->mode == PD_WARP_HOMOGRAPHY && (d->flags & PD_HOMO_UNIFORM)) {
     PD_REQUIRE(workspace, "the plane-uniform backward needs workspace (pd_sweep_bwd_workspace_floats)");
@@ -629,6 +645,35 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
     rc = check_launch("reduce_partials_kernel");
   }
   return rc;
+}
+
+extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                                  const float* sigma, const float* plane, const float* plane_aux, const float* inv_K3,
+                                  const float* padding_mask, const float* dists, const float* rgb_rec,
+                                  const float* stash, const float* g_rgb_rec, const float* g_ph_map,
+                                  const float* g_ph_mean, float* g_logits, float* g_sigma, float* g_plane,
+                                  float* g_dists, float* workspace, pd_stream_t stream) {
+  return sweep_bwd_impl(d, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, rgb_rec, stash, g_rgb_rec,
+                        g_ph_map, g_ph_mean, g_logits, g_sigma, g_plane, g_dists, workspace, stream, nullptr);
+}
+
+extern "C" int pd_sweep_bwd_tail_fuses(const pd_sweep_desc* d) {
+  if (!d || !(wants_rowshift(d) && rowshift_applicable(d)) || d->impl == PD_IMPL_ROWS1) return 0;
+  SweepArgs probe;
+  probe.has_mask = 0;
+  return rowstream_bwd_tail_applicable(d, probe) ? 1 : 0;
+}
+
+extern "C" int pd_plane_sweep_bwd_tail(const pd_sweep_desc* d, const float* src, const float* tgt, const float* logits,
+                                       const float* sigma, const float* plane, const float* rgb_rec, const float* stash,
+                                       const float* g_rgb_rec, const float* g_ph_map, const float* g_ph_mean,
+                                       const float* raw_sigma, const float* tail_stash, const float* disp,
+                                       const float* g_disp, const float* g_depth, float* g_raw_logits,
+                                       float* g_raw_sigma, float* g_plane, float* workspace, pd_stream_t stream) {
+  PD_REQUIRE(raw_sigma && tail_stash && disp, "raw_sigma / tail_stash / disp must not be NULL");
+  const TailIn t = {raw_sigma, tail_stash, disp, g_disp, g_depth};
+  return sweep_bwd_impl(d, src, tgt, logits, sigma, plane, nullptr, nullptr, nullptr, nullptr, rgb_rec, stash, g_rgb_rec,
+                        g_ph_map, g_ph_mean, g_raw_logits, g_raw_sigma, g_plane, nullptr, workspace, stream, &t);
 }
 
 extern "C" int pd_uniform_gather_pair(const pd_sweep_desc* d, const float* plane_a, const float* inv_K3_a, float* workspace_a,

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include "pd_rowshift_common.h"
+#include "pd_tail_common.h"
 
 namespace pd {
 
@@ -90,8 +91,44 @@ struct StreamLds {
   float* red;     // [N]  disparity-gradient sums of the row
   float* hand;    // [nwaves][2] carries that leave a wave's range in the middle of a row
   int* special;   // [1]  any plane with a negative shift or an irregular one (the epilogue has work)
+  float4* tail;   // TAIL: [CW] per SOURCE pixel (lse of the decoder's logits, 1 / sum pi/sigma, disp, d loss / d disp)
+  float* dpl;     // TAIL: [N]  the planes' disparities (unsigned, unclamped: the decoder's disp_layered)
   int CW;
 };
+
+// The decoder tail's backward at one source element (networks/depth_decoder.py:258-291; pd_decoder_tail.hip: tail_bwd_kernel,
+// no padding mask): with the decoder's own logit l and sigma sg = clamp(sigmoid(raw)) AT that element, P = softmax(l) / sg /
+// sum(pi/sigma) and the upstream gD of disp (+ depth's share), t = gD (d_n - disp) P:
+//   g_raw_logits = g_logits + t;   g_raw_sigma = (g_sigma - t / sg) sigmoid'(raw) where the clamp passed sg through, else 0.
+// sigmoid' = sgu (1 - sgu) with sgu = sg wherever 0.01 < sg < 1; sg == 1 means sgu == 1 (sigmoid never exceeds it): the
+// product is 0 either way; sg == 0.01 is the one case that needs raw_sigma (sgu < 0.01: gate closed; == 0.01: open).
+struct TailTerm {
+  float t;        // added to the logit gradient
+  float fs;       // factor of the sigma gradient: sigmoid'(raw) * gate
+  float tos;      // t / sg
+  float gdl;      // gD * P: this element's share of d loss / d d_n through disp
+};
+__device__ __forceinline__ TailTerm tail_term(const float4 tc, float l, float sg, float dn, const float* __restrict__ raw_sigma_at) {
+  TailTerm o;
+  const float p = __expf(l - tc.x);
+  const float rsg = fast_rcp(sg);
+  const float P = p * rsg * tc.y;
+  o.gdl = tc.w * P;
+  o.t = o.gdl * (dn - tc.z);
+  o.tos = o.t * rsg;
+  o.fs = sg * (1.0f - sg);
+  if (sg == kTailSigmaMin) {   // rare: the clamp's lower bound — the gate needs the unclamped value
+    const float sgu = sigmoid_f(*raw_sigma_at);
+    o.fs = (sgu == sg) ? o.fs : 0.0f;
+  }
+  return o;
+}
+// the sigma factor alone (contributions that reach an element on their own: atomics of the irregular planes, hand-overs)
+__device__ __forceinline__ float tail_fs(float sg, const float* __restrict__ raw_sigma_at) {
+  float fs = sg * (1.0f - sg);
+  if (sg == kTailSigmaMin) fs = (sigmoid_f(*raw_sigma_at) == sg) ? fs : 0.0f;
+  return fs;
+}
 
 __device__ __forceinline__ PixelCtx ctx_at(const StreamLds& L, int cell) {
   const float4 a = L.ctx0[cell], g = L.ctx1[cell], h = L.ctx2[cell];
@@ -147,7 +184,7 @@ __device__ __forceinline__ void stream_issue(StreamGroup<NROWS>& g, const SweepA
 
 // One regular (plane, segment) iteration.  carry_*: right-tap contribution of the previous segment's last slot (wave
 // uniform); returns this segment's in the same variables.
-template <bool MIX, int NROWS, bool PK>
+template <bool MIX, int NROWS, bool PK, bool TAIL>
 __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, const SweepArgs& a, const BwdOut& o,
                                                const StreamRow& r, const StreamLds& L, int n, int seg, int k, float sd,
                                                int lane, unsigned lane8, float lane2f, int HW, float Wm1, float rcpWm1,
@@ -198,15 +235,29 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
   }
   // slot xs receives the left-tap part of its own target and the right-tap part of the target one slot to the left
   const float pl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_l), __float_as_int(cl1[kSlots - 1]), 0x138, 0xF, 0xF, false));
-  const float out_l0 = cl0[0] + pl, out_l1 = cl0[1] + cl1[0];
+  float out_l0 = cl0[0] + pl, out_l1 = cl0[1] + cl1[0];
   carry_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1[kSlots - 1]), kWave - 1));   // (an int builtin)
+  float out_s0 = 0.0f, out_s1 = 0.0f;
+  if (MIX) {
+    const float ps = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_s), __float_as_int(cs1[kSlots - 1]), 0x138, 0xF, 0xF, false));
+    out_s0 = cs0[0] + ps; out_s1 = cs0[1] + cs1[0];
+    carry_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs1[kSlots - 1]), kWave - 1));
+  }
+  if (TAIL) {   // the decoder tail's backward at the lane's two source elements (tail_term): the stores below then carry the
+                // gradients of the decoder's conv outputs.  The element's own logit / sigma are the taps of its own row.
+    const int own = (NROWS == 2 && r.yA != r.y) ? NROWS - 1 : 0;
+    const float dn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(L.dpl[n])));
+    const float* rs = o.tail_raw_sigma + ((long)r.b * a.N + n) * HW + (long)r.y * a.W + xs0;
+    const TailTerm t0 = tail_term(L.tail[xs0 + 2], g.l[own][0], g.s[own][0], dn, rs);
+    const TailTerm t1 = tail_term(L.tail[xs0 + 3], g.l[own][1], g.s[own][1], dn, rs + 1);
+    out_l0 += t0.t; out_l1 += t1.t;
+    out_s0 = (out_s0 - t0.tos) * t0.fs; out_s1 = (out_s1 - t1.tos) * t1.fs;
+    if (want_plane) gacc += a.sign * (t0.gdl + t1.gdl);   // (the row's sum is scaled by d ix / d disp = sign at the end: sign^2 = 1)
+  }
   const unsigned soff = (unsigned)seg * (kSeg * 4);
   if (!(kStreamAbl & 8) || out_l0 == 123.456f)
   buf_store2(row_rsrc_bytes(plane_ptr(o.g_logits + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gl_bytes), lane8, soff, out_l0, out_l1);
   if (MIX) {
-    const float ps = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry_s), __float_as_int(cs1[kSlots - 1]), 0x138, 0xF, 0xF, false));
-    const float out_s0 = cs0[0] + ps, out_s1 = cs0[1] + cs1[0];
-    carry_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs1[kSlots - 1]), kWave - 1));
     if (!(kStreamAbl & 8) || out_s0 == 123.456f)
     buf_store2(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gs_bytes), lane8, soff, out_s0, out_s1);
   }
@@ -215,7 +266,7 @@ __device__ __forceinline__ void stream_compute(const StreamGroup<NROWS>& g, cons
 // General form for one paired slot xs of plane n (n may differ per lane): the target xt = xs - k with its EXACT
 // floor(ix); contributions go to the gradient rows with atomics, the disparity-gradient term is returned.
 // Used for irregular planes (rows zero-filled up front) and for the virtual slots of the epilogue.
-template <bool MIX, int NROWS, bool PK>
+template <bool MIX, int NROWS, bool PK, bool TAIL>
 __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs + scratch — measured, NOTEBOOK.md 3.6.4)
     const SweepArgs& a, const BwdOut& o, const StreamRow& r,
                                                      const StreamLds& L, int n, int xs, int k, float sd, bool on, int HW,
@@ -246,18 +297,25 @@ __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs
   const float wy = (NROWS == 1) ? 1.0f : r.wy;
   float* gl = o.g_logits ? o.g_logits + ((long)r.b * a.N + n) * HW + (long)r.y * W : nullptr;
   float* gs = (MIX && o.g_sigma) ? o.g_sigma + ((long)r.b * a.N + n) * HW + (long)r.y * W : nullptr;
+  float f0 = 1.0f, f1 = 1.0f;   // TAIL: the sigma gradient arrives in the conv output's space (tail_fs of the destination element)
+  if (TAIL && MIX) {
+    const bool ownA = (NROWS == 1) || r.yA == r.y;
+    const float* rs = o.tail_raw_sigma + ((long)r.b * a.N + n) * HW + (long)r.y * W;
+    if (v0) f0 = tail_fs(ownA ? sa0 : sb0, rs + t.x0);
+    if (v1) f1 = tail_fs(ownA ? sa1 : sb1, rs + t.x0 + 1);
+  }
   if (v0) {
     if (gl) unsafeAtomicAdd(gl + t.x0, pg.g_l * (t.w0 * wy));
-    if (gs) unsafeAtomicAdd(gs + t.x0, pg.g_s * (t.w0 * wy));
+    if (gs) unsafeAtomicAdd(gs + t.x0, pg.g_s * (t.w0 * wy) * f0);
   }
   if (v1) {
     if (gl) unsafeAtomicAdd(gl + t.x0 + 1, pg.g_l * (t.w1 * wy));
-    if (gs) unsafeAtomicAdd(gs + t.x0 + 1, pg.g_s * (t.w1 * wy));
+    if (gs) unsafeAtomicAdd(gs + t.x0 + 1, pg.g_s * (t.w1 * wy) * f1);
   }
   return pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * (cb.x - ca.x) + pg.gc1 * (cb.y - ca.y) + pg.gc2 * (cb.z - ca.z);
 }
 
-template <bool MIX, int NROWS, bool PK>
+template <bool MIX, int NROWS, bool PK, bool TAIL>
 __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, const StreamLds& L) {
   constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
   const int W = a.W, N = a.N, HW = a.H * a.W;
@@ -293,6 +351,17 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
         cc = make_float4(fmaf(q[0], r.wB, cc.x * r.wA), fmaf(q[HW], r.wB, cc.y * r.wA), fmaf(q[2 * HW], r.wB, cc.z * r.wA), 0.0f);
       }
     }
+    if (TAIL) {   // per SOURCE pixel of the row: what the decoder tail's backward needs (tail_term); zeros outside the row
+      float4 tc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x >= 0 && x < W) {
+        const long pix = (long)r.b * HW + (long)r.y * W + x;
+        const float dsp = o.tail_disp[pix];
+        float gD = o.tail_g_disp ? o.tail_g_disp[pix] : 0.0f;
+        if (o.tail_g_depth) gD -= o.tail_g_depth[pix] * (0.1f * 0.58f * (float)W) / (dsp * dsp);   // depth = 0.1 * 0.58 * W / disp
+        tc = make_float4(o.tail_stash[(long)r.b * 2 * HW + (long)r.y * W + x], 1.0f / o.tail_stash[((long)r.b * 2 + 1) * HW + (long)r.y * W + x], dsp, gD);
+      }
+      L.tail[cidx] = tc;
+    }
     L.ctx0[cidx] = make_float4(c.t0, c.t1, c.t2, c.lse2);
     L.ctx1[cidx] = make_float4(c.gr0, c.gr1, c.gr2, c.gdotr);
     L.ctx2[cidx] = make_float4(c.invS, c.mx, c.A, PK ? cc.x : 0.0f);
@@ -314,6 +383,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
       const bool inview = fabsf(sd) < (float)(W + 1);
       const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
       L.shift[i] = make_int2(__float_as_int(sd), k * 2 + irr);
+      if (TAIL) L.dpl[i] = a.plane[di];
       L.red[i] = 0.0f;
       if (irr || (k < 0 && inview)) *L.special = 1;
     }
@@ -324,8 +394,15 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     for (int n = 0; n < N; ++n) {
       if (!(L.shift[n].y & 1)) continue;
       for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        if (o.g_logits) o.g_logits[((long)r.b * N + n) * HW + (long)r.y * W + x] = 0.0f;
-        if (MIX && o.g_sigma) o.g_sigma[((long)r.b * N + n) * HW + (long)r.y * W + x] = 0.0f;
+        const long at = ((long)r.b * N + n) * HW + (long)r.y * W + x;
+        float il = 0.0f, is = 0.0f;
+        if (TAIL) {   // the tail's own term goes in first; the atomics then add the sweep's shares (sigma's already scaled)
+          const TailTerm tt = tail_term(L.tail[x + 2], a.logits[at], a.sigma[at], L.dpl[n], o.tail_raw_sigma + at);
+          il = tt.t; is = -tt.tos * tt.fs;
+          if (want_plane) atomicAdd(&L.red[n], a.sign * tt.gdl);
+        }
+        if (o.g_logits) o.g_logits[at] = il;
+        if (MIX && o.g_sigma) o.g_sigma[at] = is;
       }
     }
     __syncthreads();
@@ -358,12 +435,12 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     if (kk & 1) {   // irregular plane (wave-uniform branch): exact per-lane floor, atomics into the zero-filled row
 #pragma unroll
       for (int i = 0; i < kSlots; ++i) {
-        const float gd = stream_general_slot<MIX, NROWS, PK>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
+        const float gd = stream_general_slot<MIX, NROWS, PK, TAIL>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
         if (want_plane) gacc += gd;
       }
       carry_l = carry_s = 0.0f;
     } else {
-      stream_compute<MIX, NROWS, PK>(grp, a, o, r, L, n, seg, k, sd, lane, lane8, lane2f, HW, Wm1, rcpWm1, want_plane, gl_bytes,
+      stream_compute<MIX, NROWS, PK, TAIL>(grp, a, o, r, L, n, seg, k, sd, lane, lane8, lane2f, HW, Wm1, rcpWm1, want_plane, gl_bytes,
                                  gs_bytes, carry_l, carry_s, gacc);
     }
     advance(n, seg);
@@ -408,7 +485,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
       const float hl = L.hand[(wave - 1) * 2], hs = L.hand[(wave - 1) * 2 + 1];
       const long at = ((long)r.b * N + ns) * HW + (long)r.y * W + ss * kSeg;
       if (o.g_logits && hl != 0.0f) unsafeAtomicAdd(o.g_logits + at, hl);
-      if (MIX && o.g_sigma && hs != 0.0f) unsafeAtomicAdd(o.g_sigma + at, hs);
+      if (MIX && o.g_sigma && hs != 0.0f) unsafeAtomicAdd(o.g_sigma + at, TAIL ? hs * tail_fs(a.sigma[at], o.tail_raw_sigma + at) : hs);
     }
   }
   // (2) targets without a slot: x0 = -1 (negative shifts; their right tap is column 0) and, on irregular planes, the
@@ -422,7 +499,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
       const bool irr = kk & 1;
       const int xs = (which == 0) ? -1 : ((which == 1) ? -2 : s_end);
       const bool on = (which == 0) || irr;
-      const float gd = stream_general_slot<MIX, NROWS, PK>(a, o, r, L, pn2, xs, k, __int_as_float(sh.x), on, HW, Wm1, rcpWm1);
+      const float gd = stream_general_slot<MIX, NROWS, PK, TAIL>(a, o, r, L, pn2, xs, k, __int_as_float(sh.x), on, HW, Wm1, rcpWm1);
       if (want_plane && gd != 0.0f) atomicAdd(&L.red[pn2], gd);
     }
     __syncthreads();
@@ -438,7 +515,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   }
 }
 
-template <bool MIX, bool PK>
+template <bool MIX, bool PK, bool TAIL>
 __global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   StreamLds L;
@@ -446,13 +523,16 @@ __global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bw
   L.CW = nseg * kSeg + 4;
   L.ctx0 = lds4; L.ctx1 = lds4 + L.CW; L.ctx2 = lds4 + 2 * L.CW; L.col = lds4 + 3 * L.CW;
   L.colgb = reinterpret_cast<float2*>(lds4 + 3 * L.CW);
-  L.shift = PK ? reinterpret_cast<int2*>(L.colgb + L.CW) : reinterpret_cast<int2*>(lds4 + 4 * L.CW);
+  L.tail = PK ? nullptr : lds4 + 4 * L.CW;                         // (TAIL comes with the plain layout only)
+  float4* after = TAIL ? lds4 + 5 * L.CW : lds4 + 4 * L.CW;
+  L.shift = PK ? reinterpret_cast<int2*>(L.colgb + L.CW) : reinterpret_cast<int2*>(after);
   L.red = reinterpret_cast<float*>(L.shift + a.N);
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
+  L.dpl = reinterpret_cast<float*>(L.special + 4);
   const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
-  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK>(a, o, row, L);
-  else                                     stream_body<MIX, 1, PK>(a, o, row, L);
+  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, row, L);
+  else                                     stream_body<MIX, 1, PK, TAIL>(a, o, row, L);
 }
 
 __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
@@ -471,25 +551,25 @@ __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, fl
 // the colour's r in ctx2's spare float and (g, b) as a float2 (56 B) — two more LDS reads per item, so it is used only where
 // it buys a workgroup per CU (192 x 640: 42 KB, three workgroups either way; 384 x 1280: 83 KB = ONE workgroup plain,
 // 72 KB = two packed).
-static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves, bool packed) {
+static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves, bool packed, bool tail = false) {
   const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
-  return CW * (packed ? 3 * sizeof(float4) + sizeof(float2) : 4 * sizeof(float4)) +
-         (size_t)d->N * (sizeof(float2) + sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 16;
+  return CW * (packed ? 3 * sizeof(float4) + sizeof(float2) : (tail ? 5 : 4) * sizeof(float4)) +
+         (size_t)d->N * (sizeof(float2) + sizeof(float) + (tail ? sizeof(float) : 0)) + (size_t)nwaves * 2 * sizeof(float) + 32;
 }
 struct StreamShape { int nwaves; bool packed; size_t lds; };
-static StreamShape rowstream_shape(const pd_sweep_desc* d) {
+static StreamShape rowstream_shape(const pd_sweep_desc* d, bool tail = false) {
   const size_t kCuLds = device_lds_bytes();
   // workgroups per CU by LDS (at most three: 24 waves per CU at the kernel's 77 VGPRs); waves per workgroup to fill them:
   // three workgroups of 8, two of 12, one of 16
-  const int wg_plain = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, false));
-  const int wg_packed = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, true));
+  const int wg_plain = (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, false, tail));
+  const int wg_packed = tail ? 0 : (int)(kCuLds / rowstream_lds_bytes(d, 2 * PD_STREAM_WAVES, true));
   StreamShape s;
   s.packed = wg_plain < 3 && wg_packed > wg_plain;
   const int wg = s.packed ? wg_packed : wg_plain;
   const int w = wg >= 3 ? PD_STREAM_WAVES : wg == 2 ? (3 * PD_STREAM_WAVES) / 2 : 2 * PD_STREAM_WAVES;
   const int items = d->N * ceil_div(d->W, kSeg);
   s.nwaves = items < w ? items : w;
-  s.lds = rowstream_lds_bytes(d, s.nwaves, s.packed);
+  s.lds = rowstream_lds_bytes(d, s.nwaves, s.packed, tail);
   return s;
 }
 
@@ -500,24 +580,33 @@ bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
 
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
 
-template <bool MIX, bool PK>
+template <bool MIX, bool PK, bool TAIL>
 static int rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
   static LdsGrant granted;   // per instantiation and device: the attribute is set once (and checked), not per launch
-  const int rc = grant_dynamic_lds((const void*)rowstream_bwd_kernel<MIX, PK>, shmem, &granted, "rowstream_bwd_kernel");
+  const int rc = grant_dynamic_lds((const void*)rowstream_bwd_kernel<MIX, PK, TAIL>, shmem, &granted, "rowstream_bwd_kernel");
   if (rc) return rc;
-  rowstream_bwd_kernel<MIX, PK><<<grid, block, shmem, stream>>>(a, o);
+  rowstream_bwd_kernel<MIX, PK, TAIL><<<grid, block, shmem, stream>>>(a, o);
   return PD_OK;
 }
 
+// The fused decoder tail rides along (pd_plane_sweep_bwd_tail) where the plain LDS layout with one more float4 per cell fits:
+// mixture, one disparity per plane, unit sign.
+bool rowstream_bwd_tail_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
+  return rowstream_bwd_applicable(d, a) && (d->flags & PD_MIXTURE) && !(d->flags & (PD_DISP_ROWS | PD_MASK_ROWS)) &&
+         (d->sign == 1.0f || d->sign == -1.0f) && rowstream_shape(d, true).lds <= device_lds_bytes();
+}
+
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
-  const StreamShape sh = rowstream_shape(d);
+  const bool tail = o.tail_stash != nullptr;
+  const StreamShape sh = rowstream_shape(d, tail);
   dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   int rc;
-  if (mix) rc = sh.packed ? rowstream_launch<true, true>(a, o, grid, block, sh.lds, stream)
-                          : rowstream_launch<true, false>(a, o, grid, block, sh.lds, stream);
-  else     rc = sh.packed ? rowstream_launch<false, true>(a, o, grid, block, sh.lds, stream)
-                          : rowstream_launch<false, false>(a, o, grid, block, sh.lds, stream);
+  if (tail)     rc = rowstream_launch<true, false, true>(a, o, grid, block, sh.lds, stream);
+  else if (mix) rc = sh.packed ? rowstream_launch<true, true, false>(a, o, grid, block, sh.lds, stream)
+                               : rowstream_launch<true, false, false>(a, o, grid, block, sh.lds, stream);
+  else          rc = sh.packed ? rowstream_launch<false, true, false>(a, o, grid, block, sh.lds, stream)
+                               : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream);
   if (rc) return rc;
   rc = check_launch("rowstream_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;

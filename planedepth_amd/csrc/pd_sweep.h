@@ -53,6 +53,13 @@ struct BwdOut {
   const float* g_rgb_rec;
   const float* g_ph_map;
   const float* g_ph_mean;  // optional: device scalar, upstream gradient of mean(ph_map)
+  // pd_plane_sweep_bwd_tail (row-stream backward only): the fused decoder tail's backward rides along — g_logits / g_sigma
+  // receive the gradients of the decoder's CONV outputs (networks/depth_decoder.py:258-291 through pd_decoder_tail_fwd)
+  const float* tail_raw_sigma = nullptr;  // [B,N,H,W] sigmaconv output (read only where sigma sits on the lower clamp bound)
+  const float* tail_stash = nullptr;      // [B,2,H,W] pd_decoder_tail_fwd's stash: log-sum-exp of the logits, sum pi/sigma
+  const float* tail_disp = nullptr;       // [B,1,H,W]
+  const float* tail_g_disp = nullptr;     // upstream gradients of the tail's disp / depth outputs (either may be NULL)
+  const float* tail_g_depth = nullptr;
 };
 
 // ---- forward: online softmax / mixture accumulators of ONE target pixel over the planes ---------------------------
@@ -267,6 +274,7 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
 
 // Row-stream backward (pd_plane_sweep_rowstream.hip): lanes own aligned source slots, waves stream along plane rows.
 bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a);
+bool rowstream_bwd_tail_applicable(const pd_sweep_desc* d, const SweepArgs& a);
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream);
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d);
 

@@ -71,13 +71,20 @@ class LazyLayers:
 
 
 def fused_decoder_tail(outputs, dispconv_out, sigmaconv_out=None, *, use_mixture_loss=True, all_ones_mask=False,
-                       materialize_layers=False):
+                       materialize_layers=False, fuse_sweep_backward=False):
     """Fills ``outputs`` with "logits", "sigma", "pi", "probability", "disp", "depth" as depth_decoder.py:258-291 does.
     Reads ``outputs["disp_layered"]`` and ``outputs["padding_mask"]`` (skipped when ``all_ones_mask`` says the decoder
-    built it with ``torch.ones_like``, i.e. xy planes only)."""
+    built it with ``torch.ones_like``, i.e. xy planes only).
+
+    ``fuse_sweep_backward=True`` (xy planes, mixture loss, one target view): the promise that ``outputs["logits"]`` /
+    ``["sigma"]`` are consumed — as far as gradients go — by the trainer's plane sweep alone.  The sweep's backward kernel
+    then applies this tail's backward on the values it holds anyway and writes the conv outputs' gradients directly
+    (``ops.TailLink``, ``pd_plane_sweep_bwd_tail``); the tail's own backward kernel, which re-reads the [B,N,H,W]-sized
+    gradients the sweep has just written, no longer runs."""
     mask = None if all_ones_mask else outputs["padding_mask"]
     logits, sigma, disp, depth, layers = ops.decoder_tail(dispconv_out, sigmaconv_out, mask, outputs["disp_layered"],
-                                                          use_mixture_loss=use_mixture_loss)
+                                                          use_mixture_loss=use_mixture_loss,
+                                                          fuse_sweep_backward=fuse_sweep_backward)
     outputs["logits"] = logits
     if use_mixture_loss:
         outputs["sigma"] = sigma

@@ -280,6 +280,33 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=
     return g_logits, (g_sigma if mix else None), g_plane, g_dists
 
 
+def _sweep_backward_tail(saved, cfg, grads, need, link):
+    """pd_plane_sweep_bwd_tail: the sweep's backward with the linked decoder tail's backward riding along.  Returns
+    (g_raw_logits, g_raw_sigma, g_plane) — handed to autograd as the gradients of logits / sigma; the tail's node passes them
+    through (TailLink)."""
+    lib = C.load()
+    src, tgt, logits, sigma, plane, _, _, _, _, rgb_rec, stash = saved
+    mode, flags, sign = cfg
+    g_rgb_rec, g_ph_map, g_ph_mean = grads
+    B, N, H, W = logits.shape
+    d = _desc(B, N, H, W, mode, flags, sign)
+    g_disp, g_depth = link.seen.get("disp"), link.seen.get("depth")
+    gl, gs = torch.empty_like(logits), torch.empty_like(sigma)
+    g_plane = torch.empty_like(plane) if need[2] else None
+    ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device, dtype=torch.float32)
+    g_rgb_rec, g_ph_map, gd, gz = map(_contig, (g_rgb_rec, g_ph_map, g_disp, g_depth))
+    if g_ph_mean is not None:
+        g_ph_mean = g_ph_mean.reshape(1).to(torch.float32).contiguous()
+    with C.on_device(logits.device), _timed("bwd"):
+        rc = lib.pd_plane_sweep_bwd_tail(ctypes.byref(d), C.ptr(src), C.ptr(tgt), C.ptr(logits), C.ptr(sigma), C.ptr(plane),
+                                         C.ptr(rgb_rec), C.ptr(stash), C.ptr(g_rgb_rec), C.ptr(g_ph_map), C.ptr(g_ph_mean),
+                                         C.ptr(link.raw_sigma), C.ptr(link.stash), C.ptr(link.disp), C.ptr(gd), C.ptr(gz),
+                                         C.ptr(gl), C.ptr(gs), C.ptr(g_plane), C.ptr(ws), C.stream_handle(logits.device))
+    C.check(rc, "pd_plane_sweep_bwd_tail")
+    link.applied = {"disp": g_disp, "depth": g_depth}
+    return gl, gs, g_plane
+
+
 def _gather_pair(view_a, view_b, cfg, g_logits, g_sigma, accumulate):
     """pd_uniform_gather_pair: the second pass of two deferred plane-uniform backward calls (``view_*`` = (saved tensors,
     workspace)) into (or, ``accumulate``: added to) g_logits / g_sigma."""
@@ -297,6 +324,51 @@ def _gather_pair(view_a, view_b, cfg, g_logits, g_sigma, accumulate):
     C.check(rc, "pd_uniform_gather_pair")
 
 
+class TailLink:
+    """What ties a fused decoder tail (``decoder_tail(..., fuse_sweep_backward=True)``) to the ONE plane sweep that consumes
+    its logits / sigma, so that the sweep's backward kernel can apply the tail's backward as well
+    (``pd_plane_sweep_bwd_tail``: the [B,N,H,W]-sized g_logits / g_sigma are never re-read by a tail kernel).
+
+    Autograd runs the sweep's node before the tail's, and the tail's other upstream gradients (d loss / d disp from the
+    smoothness term, d / d depth) reach the tail's node only — so ``pred_novel_images`` routes ``outputs["disp"]`` /
+    ``["depth"]`` through gradient taps created AFTER the sweep's node: nodes created later run earlier, the taps have
+    handed their gradients over by the time the sweep's backward runs.  The tail's own backward then passes g_logits /
+    g_sigma through, and runs its kernel only on whatever upstream gradient of disp / depth the sweep did NOT see (none in
+    the trainer's graph; a consumer that took ``disp`` before the tap existed, for example) — correct in any order."""
+
+    def __init__(self, raw_sigma, stash, disp):
+        self.raw_sigma, self.stash, self.disp = raw_sigma, stash, disp
+        self.consumers = 0        # sweeps that registered as consumers of this tail's logits / sigma
+        self.seen = {}            # "disp" / "depth" -> gradient handed over by its tap
+        self.applied = None       # {"disp": g or None, "depth": g or None} once a sweep's backward has applied the tail's terms
+
+
+class _GradTap(torch.autograd.Function):
+    """Identity whose backward leaves the gradient with the TailLink on its way through."""
+
+    @staticmethod
+    def forward(ctx, x, link, which):
+        ctx.link, ctx.which = link, which
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.link.seen[ctx.which] = g
+        return g, None, None
+
+
+def tail_taps(outputs):
+    """Called by ``pred_novel_images`` right after the sweep's node exists: ``outputs["disp"]`` / ``["depth"]`` of a linked
+    fused decoder tail go through gradient taps (see TailLink).  No-op without a link or with more than one consumer."""
+    link = getattr(outputs.get("logits"), "_pd_tail_link", None)
+    if link is None or link.consumers != 1:
+        return
+    for k in ("disp", "depth"):
+        t = outputs.get(k)
+        if torch.is_tensor(t) and t.requires_grad:
+            outputs[k] = _GradTap.apply(t, link, k)
+
+
 class _PlaneSweep(torch.autograd.Function):
     """(src, tgt, logits, sigma, plane, ...) -> (rgb_rec [B,3,H,W], ph_map [B,1,H,W], ph_mean []).
 
@@ -308,20 +380,26 @@ class _PlaneSweep(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign):
+    def forward(ctx, src, tgt, logits, sigma, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign, link=None):
         (rgb_rec, ph_map, ph_mean), saved = _sweep_forward(src, tgt, logits, sigma, plane, plane_aux, inv_K3,
                                                            padding_mask, dists, mode, flags, sign)
         ctx.save_for_backward(*saved)
         ctx.cfg = (mode, flags, sign)
+        ctx.link = link
         ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward, not as zero tensors
         return rgb_rec, ph_map, ph_mean.reshape(())
 
     @staticmethod
     def backward(ctx, g_rgb_rec, g_ph_map, g_ph_mean):
         need = (ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[8])
+        link = ctx.link
+        if link is not None and link.consumers == 1 and link.applied is None and need[0] and need[1]:
+            g_logits, g_sigma, g_plane = _sweep_backward_tail(ctx.saved_tensors, ctx.cfg, (g_rgb_rec, g_ph_map, g_ph_mean),
+                                                              need, link)
+            return None, None, g_logits, g_sigma, g_plane, None, None, None, None, None, None, None, None
         g_logits, g_sigma, g_plane, g_dists = _sweep_backward(ctx.saved_tensors, ctx.cfg,
                                                               (g_rgb_rec, g_ph_map, g_ph_mean), need)
-        return None, None, g_logits, g_sigma, g_plane, None, None, None, g_dists, None, None, None
+        return None, None, g_logits, g_sigma, g_plane, None, None, None, g_dists, None, None, None, None
 
 
 _PER_SIDE = 9   # tgt, plane, plane_aux, inv_K3, padding_mask, dists, mode, flags, sign
@@ -460,7 +538,7 @@ def plane_sweep_multi(deferred):
     for d in deferred:
         if d[0] is not src or d[2] is not logits or (d[3] is not None and d[3] is not sigma):
             raise ValueError("plane_sweep_multi: every view must sweep the same src / logits / sigma tensors")
-        flat += [d[1]] + list(d[4:])
+        flat += [d[1]] + list(d[4:12])   # (a 13th element, the decoder tail's link, serves single-view nodes only)
     outs = _MultiPlaneSweep.apply(src, logits, sigma, *flat)
     return [tuple(outs[3 * i:3 * i + 3]) for i in range(len(deferred))]
 
@@ -574,6 +652,16 @@ def plane_sweep_disp(src, tgt, logits, sigma, disp_layered, padding_mask=None, *
     sign = _SIGN.get(target_side, 0.0)  # any other key leaves the grid untouched (trainer.py:546-549)
     call = (src, tgt, logits, sigma if use_mixture_loss else None, plane, None, None, padding_mask,
             dists if render_probability else None, C.PD_WARP_DISP, flags, sign)
+    # a fused decoder tail that asked for it (decoder_tail(..., fuse_sweep_backward=True)) gets its backward applied by this
+    # sweep's backward kernel — where the library serves that form for this descriptor
+    link = getattr(logits, "_pd_tail_link", None)
+    if (link is not None and per_plane and use_mixture_loss and padding_mask is None and not render_probability
+            and sigma is not None and getattr(sigma, "_pd_tail_link", None) is link
+            and C.load().pd_sweep_bwd_tail_fuses(ctypes.byref(_desc(B, N, H, W, C.PD_WARP_DISP, flags, sign)))):
+        link.consumers += 1
+        call = call + (link,)
+    elif link is not None:
+        link.consumers += 2   # a consumer the fused form does not serve: nobody fuses
     if defer:      # the argument tuple for plane_sweep_multi (several target views as one autograd node)
         return call
     out = _PlaneSweep.apply(*call)
@@ -1132,10 +1220,11 @@ class _DecoderTail(torch.autograd.Function):
     """(raw_logits, raw_sigma, disp_layered[, padding_mask]) -> (logits, sigma, disp, depth, stash)."""
 
     @staticmethod
-    def forward(ctx, raw_logits, raw_sigma, disp_layered, padding_mask, flags):
+    def forward(ctx, raw_logits, raw_sigma, disp_layered, padding_mask, flags, link=None):
         lib = C.load()
         B, N, H, W = raw_logits.shape
         mix = bool(flags & C.PD_TAIL_MIXTURE)
+        ctx.link = link
         C.require_gpu_tensor("raw_logits", raw_logits)
         if mix:
             C.require_gpu_tensor("raw_sigma", raw_sigma, (B, N, H, W))
@@ -1155,6 +1244,8 @@ class _DecoderTail(torch.autograd.Function):
         ctx.save_for_backward(raw_logits, raw_sigma, disp_layered, padding_mask, stash, disp)
         ctx.flags = flags
         ctx.mark_non_differentiable(stash)
+        if link is not None:
+            link.raw_sigma, link.stash, link.disp = raw_sigma, stash, disp.detach()
         if logits is None:       # no mask: the logits ARE the conv output (reference: logits * ones)
             logits = raw_logits.view_as(raw_logits)
         if sigma is None:
@@ -1171,7 +1262,26 @@ class _DecoderTail(torch.autograd.Function):
         mix = bool(flags & C.PD_TAIL_MIXTURE)
         need_l, need_s, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and mix, ctx.needs_input_grad[2]
         if not (need_l or need_s or need_d):
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        link = ctx.link
+        extra = None
+        if link is not None and link.applied is not None:
+            # the sweep's backward kernel applied this node's backward already (pd_plane_sweep_bwd_tail): g_logits / g_sigma ARE
+            # the conv outputs' gradients, the disparity share went into the sweep's g_plane.  Only an upstream gradient of
+            # disp / depth that the sweep did not see is still owed: the plain kernel on that remainder alone, added on top.
+            def rest(got, used):
+                if got is None:
+                    return None
+                if used is None:
+                    return got
+                if got.data_ptr() == used.data_ptr() and got.shape == used.shape:
+                    return None
+                return got - used
+            r_disp, r_depth = rest(g_disp, link.applied["disp"]), rest(g_depth, link.applied["depth"])
+            if r_disp is None and r_depth is None:
+                return (g_logits if need_l else None), (g_sigma if need_s else None), None, None, None, None
+            extra = (g_logits, g_sigma)
+            g_logits, g_sigma, g_disp, g_depth = None, None, r_disp, r_depth
         g_raw_logits = torch.empty_like(raw_logits) if need_l else None
         g_raw_sigma = torch.empty_like(raw_sigma) if need_s else None
         g_dl = torch.empty_like(disp_layered) if need_d else None
@@ -1186,10 +1296,15 @@ class _DecoderTail(torch.autograd.Function):
                                             C.ptr(g_sigma), C.ptr(g_disp), C.ptr(g_depth), C.ptr(g_raw_logits),
                                             C.ptr(g_raw_sigma), C.ptr(g_dl), C.ptr(ws),
                                             C.stream_handle(raw_logits.device)), "pd_decoder_tail_bwd")
-        return g_raw_logits, g_raw_sigma, g_dl, None, None
+        if extra is not None:
+            if g_raw_logits is not None and extra[0] is not None:
+                g_raw_logits += extra[0]
+            if g_raw_sigma is not None and extra[1] is not None:
+                g_raw_sigma += extra[1]
+        return g_raw_logits, g_raw_sigma, g_dl, None, None, None
 
 
-def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_loss=True):
+def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_loss=True, fuse_sweep_backward=False):
     """Tail of DepthDecoder.forward (networks/depth_decoder.py:256-291, softmax branch) in one fused pass.
 
     Returns (logits, sigma | None, disp, depth, layers) where ``layers()`` materialises ``(pi, probability)`` on demand
@@ -1207,8 +1322,15 @@ def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_
             padding_mask = padding_mask.float()
         if tuple(padding_mask.shape) != (B, N, H, W):
             padding_mask = padding_mask.expand(B, N, H, W)
+    # fuse_sweep_backward: the caller's promise that logits / sigma feed (with gradient) exactly ONE plane sweep — the trainer's
+    # single-view pred_novel_images — whose backward kernel then applies this tail's backward too (TailLink)
+    link = TailLink(None, None, None) if (fuse_sweep_backward and use_mixture_loss and padding_mask is None and per_plane
+                                           and torch.is_grad_enabled()) else None
     logits, sigma, disp, depth, stash = _DecoderTail.apply(raw_logits, raw_sigma if use_mixture_loss else None, plane,
-                                                           padding_mask, flags)
+                                                           padding_mask, flags, link)
+    if link is not None:
+        logits._pd_tail_link = link
+        sigma._pd_tail_link = link
 
     def layers(want_pi=True, want_probability=True):
         lib = C.load()
@@ -1267,7 +1389,26 @@ class _PladeTail(torch.autograd.Function):
         mix = bool(flags & C.PD_TAIL_MIXTURE)
         need_l, need_s, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and mix, ctx.needs_input_grad[2]
         if not (need_l or need_s or need_d):
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        link = ctx.link
+        extra = None
+        if link is not None and link.applied is not None:
+            # the sweep's backward kernel applied this node's backward already (pd_plane_sweep_bwd_tail): g_logits / g_sigma ARE
+            # the conv outputs' gradients, the disparity share went into the sweep's g_plane.  Only an upstream gradient of
+            # disp / depth that the sweep did not see is still owed: the plain kernel on that remainder alone, added on top.
+            def rest(got, used):
+                if got is None:
+                    return None
+                if used is None:
+                    return got
+                if got.data_ptr() == used.data_ptr() and got.shape == used.shape:
+                    return None
+                return got - used
+            r_disp, r_depth = rest(g_disp, link.applied["disp"]), rest(g_depth, link.applied["depth"])
+            if r_disp is None and r_depth is None:
+                return (g_logits if need_l else None), (g_sigma if need_s else None), None, None, None, None
+            extra = (g_logits, g_sigma)
+            g_logits, g_sigma, g_disp, g_depth = None, None, r_disp, r_depth
         g_raw_logits = torch.empty_like(raw_logits) if need_l else None
         g_raw_sigma = torch.empty_like(raw_sigma) if need_s else None
         g_dl = torch.empty_like(disp_layered) if need_d else None

@@ -161,6 +161,8 @@ def pred_novel_images(self, inputs, outputs):
         calls.append(call)
         handles.append(handle)
     results = ops.plane_sweep_multi(calls) if fuse_sides else [ops._PlaneSweep.apply(*c) for c in calls]
+    if not fuse_sides:
+        ops.tail_taps(outputs)   # a linked fused decoder tail: disp / depth go through gradient taps from here on (ops.TailLink)
     for target_side, handle, (rgb_rec, ph_map, ph_mean) in zip(self.target_sides, handles, results):
         outputs[("rgb_rec", target_side)] = rgb_rec
         outputs[("ph_map", target_side)] = ph_map
