@@ -586,13 +586,15 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     base = kitti_like_inputs_on_device(B // 2, H, W, seed=1000 + rank, device=device)
     levels0 = torch.arange(N, device=device, dtype=torch.float32)[None, :, None, None]
 
+    fuse_tail = [True]   # the sweep's backward applies the fused decoder tail's backward (pd_plane_sweep_bwd_tail); [False]: two kernels
+
     def step(sync=True):
         inputs = trainer.add_flip_right_inputs(base)                                    # trainer.py:294-295
         ctx = ddp if sync else ddp.module
         raw_l, raw_s, res = ctx(inputs[("color_aug", "l")])
         disp_layered = (300.0 * (2.0 / 300.0) ** ((levels0 + res) / (N - 1))).expand(-1, -1, H, W)   # depth_decoder.py:148-156
         outputs = {"disp_layered": disp_layered, "padding_mask": None}
-        fused_decoder_tail(outputs, raw_l, raw_s, use_mixture_loss=True, all_ones_mask=True)
+        fused_decoder_tail(outputs, raw_l, raw_s, use_mixture_loss=True, all_ones_mask=True, fuse_sweep_backward=fuse_tail[0])
         trainer.pred_novel_images(inputs, outputs)                                      # :342
         losses = trainer.compute_losses(inputs, outputs)                                # :354
         optim.zero_grad(set_to_none=True)                                               # :299
@@ -614,14 +616,22 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
         step()
     t_step = timed(step, steps)
     t_nosync = timed(lambda: step(False), steps)      # the same step without DDP's hooks: what the all-reduce adds
-    ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
-    try:
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize(device)
-        hot = {k: sum(a.elapsed_time(b) for a, b in v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in ops.KERNEL_EVENTS.items() if v}
-    finally:
-        ops.KERNEL_EVENTS = None
+    def hot_kernels():
+        ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+        try:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(device)
+            return {k: sum(a.elapsed_time(b) for a, b in v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in ops.KERNEL_EVENTS.items() if v}
+        finally:
+            ops.KERNEL_EVENTS = None
+    hot = hot_kernels()
+    fuse_tail[0] = False          # the same step with the tail's backward as its own kernel (round 4's form), for comparison
+    for _ in range(2):
+        step()
+    t_unfused = timed(step, steps)
+    hot_unfused = hot_kernels()
+    fuse_tail[0] = True
     flat = torch.empty(n_params, device=device)
     t_allreduce = timed(lambda: dist.all_reduce(flat), 5) if world > 1 else 0.0
     if world > 1:
@@ -631,7 +641,12 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
              "sweep_fwd_ms": round(hot["fwd"], 4), "sweep_bwd_ms": round(hot["bwd"], 4),
              # the sweep's producer and consumer in a real step: the fused decoder tail writes logits / sigma right before the
              # sweep's forward and reads g_logits / g_sigma right after its backward
-             "tail_fwd_ms": round(hot.get("tail_fwd", float("nan")), 4), "tail_bwd_ms": round(hot.get("tail_bwd", float("nan")), 4),
+             "tail_fwd_ms": round(hot.get("tail_fwd", float("nan")), 4),
+             # 0: the tail's backward rides in the sweep's backward kernel (fused_decoder_tail(..., fuse_sweep_backward=True))
+             "tail_bwd_ms": round(hot.get("tail_bwd", 0.0), 4),
+             "tail_backward_as_its_own_kernel": {"ms_per_step": round((parallel_max(t_unfused, device) if world > 1 else t_unfused) * 1e3, 3),
+                                                 "sweep_bwd_ms": round(hot_unfused["bwd"], 4),
+                                                 "tail_bwd_ms": round(hot_unfused.get("tail_bwd", float("nan")), 4)},
              "hot_path_share_of_step": round((hot["fwd"] + hot["bwd"]) * 1e-3 / t_step, 4),
              "network": "%s-shaped stand-in (stock Conv2d/BatchNorm2d blocks + skip decoder + the decoder's three heads), %d "
                         "parameters = %.1f MB of fp32 gradients (SURVEY C1: 59.6 / 156.6 MB), %s, "

@@ -111,7 +111,7 @@ struct TailTerm {
 __device__ __forceinline__ TailTerm tail_term(const float4 tc, float l, float sg, float dn, const float* __restrict__ raw_sigma_at) {
   TailTerm o;
   const float p = __expf(l - tc.x);
-  const float rsg = fast_rcp(sg);
+  const float rsg = fast_rcp(fmaxf(sg, kTailSigmaMin));   // (sg >= 0.01 inside the row; slots beyond it read 0 and carry tc = 0)
   const float P = p * rsg * tc.y;
   o.gdl = tc.w * P;
   o.t = o.gdl * (dn - tc.z);
@@ -515,8 +515,10 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   }
 }
 
+// (TAIL: the tail's terms take the kernel from 77 to 93 VGPRs, which costs the third resident workgroup; bounded at six waves per
+// SIMD it keeps it for twelve spilled dwords outside the loop: 0.175 against 0.196 ms, next to 0.174 + 0.208 ms for the two kernels)
 template <bool MIX, bool PK, bool TAIL>
-__global__ __launch_bounds__(kStreamThreadsMax, PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
+__global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   StreamLds L;
   const int nseg = (a.W + kSeg - 1) / kSeg;

@@ -1244,6 +1244,7 @@ class _DecoderTail(torch.autograd.Function):
         ctx.save_for_backward(raw_logits, raw_sigma, disp_layered, padding_mask, stash, disp)
         ctx.flags = flags
         ctx.mark_non_differentiable(stash)
+        ctx.set_materialize_grads(False)   # an output nobody differentiates (depth, usually) arrives as None, not as a zero tensor
         if link is not None:
             link.raw_sigma, link.stash, link.disp = raw_sigma, stash, disp.detach()
         if logits is None:       # no mask: the logits ARE the conv output (reference: logits * ones)

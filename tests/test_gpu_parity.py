@@ -983,6 +983,128 @@ def test_decoder_tail_vs_oracle_per_plane_disparities(mix, mask, shape):
         assert rel_err(got[k], want[k]) < TOL, (k, rel_err(got[k], want[k]))
 
 
+@pytest.mark.parametrize("case", ["decoder_tail_npz", "many_planes_left_view", "clamp_bounds_and_integer_shift"])
+def test_sweep_backward_applies_the_fused_decoder_tail(case):
+    """SURVEY 8f rank 1, second half ("removes the round-trips"): with ``fused_decoder_tail(..., fuse_sweep_backward=True)`` the
+    row-stream backward applies the decoder tail's backward on the values it holds (pd_plane_sweep_bwd_tail) and hands autograd
+    the gradients of the decoder's CONV outputs; the tail's own backward kernel does not run.  The objective is the trainer's
+    shape — photometric mean + a gradient on rgb_rec (the sweep) + functions of disp and depth (the smoothness term's place) —
+    and the gradients w.r.t. the conv outputs and the plane levels must agree (a) fused against unfused on the GPU, tightly,
+    and (b) both against autograd through the oracle's decoder tail + warp_and_loss on the CPU.  Inputs: the conv outputs of
+    tests/golden/decoder_tail.npz (captured next to the reference DepthDecoder); 49 planes with target "l" (negative shifts,
+    every segment count); sigmas ON both clamp bounds (sigmoid saturated at 1, pushed below 0.01) plus a plane whose shift is an
+    integer (the irregular path: atomics on rows that start from the tail's own term)."""
+    import types
+    from gpu_cases import make_stub_trainer
+    from oracle import planedepth_oracle as orc
+    from planedepth_amd import ops
+    from planedepth_amd.decoder_tail import fused_decoder_tail
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(321)
+    side = "r"
+    if case == "decoder_tail_npz":
+        z = _tail_group("mix_xy")
+        rl, rs = z["raw_logits"], z["raw_sigma"]
+        lv_disp = z["disp_layered"][:, :, :1, :1].clone()          # the decoder's per-plane disparities
+    else:
+        B, N, H, W = (1, 49, 6, 640) if case == "many_planes_left_view" else (2, 7, 9, 256)
+        rl = torch.randn(B, N, H, W, generator=g) * 2.5
+        rs = torch.randn(B, N, H, W, generator=g) * 3 - 1
+        lv_disp = 0.3 * W * (2.0 / (0.3 * W)) ** ((torch.arange(N, dtype=torch.float32)[None, :, None, None] +
+                                                    torch.rand(B, N, 1, 1, generator=g) - 0.5) / (N - 1))
+        if case == "many_planes_left_view":
+            side = "l"
+        else:
+            rs[:, :, :, :40] = -9.0      # sigmoid = 1.2e-4: clamped to 0.01, gate closed
+            rs[:, :, :, 40:80] = 30.0    # sigmoid = 1.0 exactly: on the upper bound, sigmoid' = 0
+            lv_disp[:, 3] = 17.0         # an integer shift: the irregular path
+    B, N, H, W = rl.shape
+    col_l, col_t = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    gw = [torch.randn(B, 3, H, W, generator=g) * 1e-3, torch.randn(B, 1, H, W, generator=g) * 1e-2,
+          torch.randn(B, 1, H, W, generator=g) * 1e-3]
+    K, inv_K = intrinsics(B, H, W)
+
+    def objective(ph, rgb, disp, depth, dev):
+        return ph + (rgb * gw[0].to(dev)).sum() + (disp * gw[1].to(dev)).sum() + (depth * gw[2].to(dev)).sum()
+
+    def run_gpu(fuse):
+        dev = "cuda"
+        a, s, d = (t.to(dev).clone().requires_grad_(True) for t in (rl, rs, lv_disp))
+        outputs = {"disp_layered": d.expand(-1, -1, H, W), "padding_mask": None}
+        fused_decoder_tail(outputs, a, s, use_mixture_loss=True, all_ones_mask=True, fuse_sweep_backward=fuse)
+        link = getattr(outputs["logits"], "_pd_tail_link", None)
+        inputs = {("color", "l"): col_l.to(dev), "K": K.to(dev), "inv_K": inv_K.to(dev)}
+        if side != "l":
+            inputs[("color", side)] = col_t.to(dev)
+        opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                    render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                    gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, xz_levels=0, yz_levels=0)
+        trainer = make_stub_trainer(opt, [side])
+        ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+        try:
+            trainer.pred_novel_images(inputs, outputs)
+            objective(outputs[("ph_mean", side)], outputs[("rgb_rec", side)], outputs["disp"], outputs["depth"], dev).backward()
+            tail_launches = len(ops.KERNEL_EVENTS.get("tail_bwd", []))
+        finally:
+            ops.KERNEL_EVENTS = None
+        assert (link is not None) == fuse
+        if fuse:
+            assert link.applied is not None and link.applied["disp"] is not None and link.applied["depth"] is not None
+            assert tail_launches == 0, "the tail's own backward kernel ran although the sweep applied it"
+        else:
+            assert tail_launches == 1
+        return {k: v.grad.detach().cpu() for k, v in (("g_raw_logits", a), ("g_raw_sigma", s), ("g_disp", d))}
+
+    def run_cpu():
+        a, s, d = (t.clone().requires_grad_(True) for t in (rl, rs, lv_disp))
+        dl = d.expand(-1, -1, H, W)
+        o = orc.decoder_tail(a, s, torch.ones_like(a), dl, W, use_mixture_loss=True)
+        Rt = torch.eye(4)[None].repeat(B, 1, 1)
+        r = orc.warp_and_loss(col_l, col_l if side == "l" else col_t, o["logits"], o["sigma"], warp_type="disp_warp",
+                              target_side=side, disp_layered=dl, padding_mask=torch.ones_like(a),
+                              distance=0.1 * 0.58 * W / d[:, :, 0, 0], norm=torch.tensor([0.0, 0.0, 1.0])[None, None].expand(B, N, -1),
+                              T=Rt, K=K, inv_K=inv_K, use_mixture_loss=True, automask=False)
+        objective(r["ph_loss"], r["rgb_rec"], o["disp"], o["depth"], "cpu").backward()
+        return {"g_raw_logits": a.grad, "g_raw_sigma": s.grad, "g_disp": d.grad}
+
+    plain, fused, want = run_gpu(False), run_gpu(True), run_cpu()
+    for k in want:
+        assert rel_err(fused[k], plain[k]) < 5e-6, (k, "fused vs unfused", rel_err(fused[k], plain[k]))
+        assert rel_err(plain[k], want[k]) < TOL, (k, "unfused vs oracle", rel_err(plain[k], want[k]))
+        assert rel_err(fused[k], want[k]) < TOL, (k, "fused vs oracle", rel_err(fused[k], want[k]))
+
+
+def test_fused_decoder_tail_stays_correct_when_disp_is_consumed_before_the_taps():
+    """The fused form relies on gradient taps that pred_novel_images puts on outputs["disp"] / ["depth"] AFTER the sweep's node
+    exists.  A consumer that took ``disp`` before that (here: the objective holds the untapped tensor) delivers its gradient to
+    the tail's node only, after the sweep's backward has run: the tail's backward must then add that remainder itself."""
+    import types
+    from gpu_cases import make_stub_trainer
+    from planedepth_amd.decoder_tail import fused_decoder_tail
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(11)
+    B, N, H, W = 1, 6, 8, 128
+    rl, rs = torch.randn(B, N, H, W, generator=g) * 2, torch.randn(B, N, H, W, generator=g) * 2
+    lv = 40.0 * (2.0 / 40.0) ** (torch.arange(N, dtype=torch.float32)[None, :, None, None] / (N - 1))
+    cl, ct, w = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    K, inv_K = intrinsics(B, H, W)
+    res = []
+    for fuse in (False, True):
+        a, s, d = (t.cuda().clone().requires_grad_(True) for t in (rl, rs, lv))
+        outputs = {"disp_layered": d.expand(-1, -1, H, W), "padding_mask": None}
+        fused_decoder_tail(outputs, a, s, use_mixture_loss=True, all_ones_mask=True, fuse_sweep_backward=fuse)
+        early_disp = outputs["disp"]                       # taken BEFORE pred_novel_images installs the taps
+        opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                    render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                    gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, xz_levels=0, yz_levels=0)
+        trainer = make_stub_trainer(opt, ["r"])
+        trainer.pred_novel_images({("color", "l"): cl.cuda(), ("color", "r"): ct.cuda(), "K": K.cuda(), "inv_K": inv_K.cuda()}, outputs)
+        (outputs[("ph_mean", "r")] + (early_disp * w.cuda()).sum() + (outputs["disp"] * 0.5 * w.cuda()).sum()).backward()
+        res.append([t.grad.cpu() for t in (a, s, d)])
+    for x, y in zip(*res):
+        assert rel_err(y, x) < 5e-6, rel_err(y, x)
+
+
 def test_smooth_loss_against_reference_vector_and_oracle():
     """get_smooth_loss_disp as a HIP kernel — the reference's own value (modules.npz), then the
     0.2W crop of trainer.py:768 read in place through its strides, forward and backward, against the oracle."""
