@@ -552,6 +552,10 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     N, H, W, B = args.planes, args.height, args.width, args.batch
     if B % 2:
         return {"skipped": "--flip_right doubling needs an even per-GPU batch"}
+    shared = bool(os.environ.get("PD_BENCH_SHARE_GPU"))   # functional check (all ranks on one GPU, gloo): fewer steps per leg
+    if shared:
+        steps, warmup = 3, 1
+    hot_steps, cap_steps = (4, 2) if shared else (10, 5)
 
     model_kind = args.ddp_model
     torch.manual_seed(100 + rank)
@@ -619,7 +623,7 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
     def hot_kernels():
         ops.KERNEL_EVENTS = {"fwd": [], "bwd": []}
         try:
-            for _ in range(10):
+            for _ in range(hot_steps):
                 step()
             torch.cuda.synchronize(device)
             return {k: sum(a.elapsed_time(b) for a, b in v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in ops.KERNEL_EVENTS.items() if v}
@@ -669,7 +673,7 @@ def ddp_step_block(args, device, rank, world, steps=8, warmup=3):
                                                       bucket_cap_mb=cap)
             for _ in range(2):
                 step()
-            t_cap = parallel_max(timed(step, 5), device)
+            t_cap = parallel_max(timed(step, cap_steps), device)
             by_bucket[str(cap)] = {"ms_per_step": round(t_cap * 1e3, 3),
                                    "allreduce_exposed_ms": round(max(t_cap - t_nosync, 0.0) * 1e3, 3)}
         block["by_bucket_cap_mb"] = by_bucket

@@ -1261,7 +1261,7 @@ def test_bench_spawns_its_own_ranks(gpus, ddp_model):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PD_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, PD_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", PD_DDP_STEP_TIMEOUT_S="600")   # (gloo moves 157 MB per step here)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
