@@ -927,11 +927,14 @@ def main():
                    "padding_mask": "not read (xy planes only: the decoder's mask is all ones by construction)"
                    if (args.no_padding_mask or args.xz_levels + args.yz_levels == 0) else "decoder's dense [B,N,H,W] float mask",
                    # what the timed step contains changed between rounds for the non-default configurations: compare like with like
-                   "workload_version": 4,
+                   "workload_version": 5,
                    "workload_changes": {"3": "homography_warp: outputs['distance'] is handed over as the decoder's leaf tensor instead of "
                                              "being re-derived from the disparities inside the timed step (was 10-15 % of such a step)",
                                         "4": "--xz_levels: outputs['disp_layered'] is handed over as the decoder's non-leaf dense map; the path "
-                                             "returns its gradient as a stride-0 view (no [B,N,H,W] zero fill / clone inside the step)"}},
+                                             "returns its gradient as a stride-0 view (no [B,N,H,W] zero fill / clone inside the step)",
+                                        "5": "homography_warp with --xz_levels: the decoder's own xz-plane normals / distances / horizon mask "
+                                             "(synthetic.decoder_plane_geometry = networks/depth_decoder.py:146-207) instead of frontal normals for "
+                                             "every plane: BASELINE configs[3] as SURVEY 8d (4) specifies it; the default workload is unchanged"}},
     }
     if world > 1:
         import torch.distributed as dist
@@ -978,7 +981,8 @@ def main():
         if world == 1 and args.warp_type == "disp_warp" and not args.no_next_rows:
             # The opt-in approximation next to the reported (exact) number: PD_IMPL_FAST_ROWS drops the second source row of the
             # rows whose y round trip is inexact (weight eps <= 8e-6) in forward and backward — all the traffic the headline
-            # kernels move above the algorithmic bytes.  Both legs eager, same process, same tensors: like for like.
+            # kernels move above the algorithmic bytes; rejected as the default by the parity suite.
+            # Both legs eager, same process, same tensors: like for like.
             from planedepth_amd import ops as _ops, _capi as _C
 
             def eager_rate(n=60):
@@ -1000,8 +1004,10 @@ def main():
             result["fast_rows_option"] = {
                 "images_per_sec": round(r_fast, 1), "exact_images_per_sec_same_leg": round(r_exact, 1),
                 "ratio": round(r_fast / r_exact, 4),
-                "what": "PD_SWEEP_IMPL=2 / pd_sweep_desc.impl = PD_IMPL_FAST_ROWS: an approximation inside the 1e-4 parity bar (samples move by "
-                        "<= 8e-6 of the neighbour row's difference), NOT the default and not `value`; eager launches, 60 steps each"}
+                "what": "PD_SWEEP_IMPL=2 / pd_sweep_desc.impl = PD_IMPL_FAST_ROWS: second source rows whose weight is below 2^-16 dropped in "
+                        "forward and backward.  NOT the default and not `value`: the parity suite, run under both row modes, finds it beyond "
+                        "BASELINE's 1e-4 on white-noise inputs at the benchmark sizes (worst 3.1e-4, profiles/r05_parity.md) and inside it on "
+                        "the golden fixtures, the KATs and band-limited inputs; eager launches, 60 steps each"}
         if world == 1 and not args.no_next_rows:
             result["next_rows"] = next_rows_times(args, device)
         if world == 1 and not args.no_cpu_baseline:
