@@ -81,6 +81,13 @@ enum pd_sweep_flags {
   PD_PH_MEAN_ZEROED = 512 /* pd_plane_sweep_fwd: the caller hands `ph_mean` over holding 0.0f already (e.g. a slot of a buffer it
                          zeroed once for many calls): the kernels add into it, and the entry point then issues no memset
                          launch of its own (4-5 us per call next to a 0.1 ms kernel).  Ignored by the other entry points */
+  ,
+  PD_BWD_PLANE_ZEROED = 1024 /* pd_plane_sweep_bwd / _bwd_tail, PD_WARP_DISP with one disparity per plane: the caller hands `g_plane`
+                         [B,N] over holding zeros (e.g. a slice of a buffer it zeroed once for many calls).  Where
+                         pd_sweep_bwd_plane_adds(d) == 1 (the row-stream backward) every row workgroup then ADDS its share with
+                         atomics and the entry point launches no reduction kernel of its own (4-5 us + a launch gap per call next
+                         to a 0.18 ms kernel; the sum's order, hence its last bits, varies from run to run); elsewhere the kernels
+                         overwrite `g_plane` as always — the promise is harmless there */
 };
 
 enum pd_padding_mode { PD_PAD_ZEROS = 0, PD_PAD_BORDER = 1 };
@@ -142,9 +149,12 @@ const char* pd_source_hash(void);
  * (PD_IMPL_TILE; PD_QUAD_FWD / PD_QUAD_BWD / PD_UNI_FUSED in the environment).  The product library returns 0. */
 int pd_experiments(void);
 
-/* 1 if this descriptor is served by the row-shift kernels (PD_WARP_DISP, scalar or per-row disparities), else 0. */
+/* 1 if pd_plane_sweep_bwd adds into a pre-zeroed g_plane under PD_BWD_PLANE_ZEROED for this descriptor (see the flag; a
+ * per-pixel padding mask sends the call to a kernel that overwrites instead), else 0. */
+int pd_sweep_bwd_plane_adds(const pd_sweep_desc* d);
 /* 1 if pd_plane_sweep_bwd honours PD_BWD_ACCUMULATE for this descriptor (see the flag), else 0. */
 int pd_sweep_bwd_accumulates(const pd_sweep_desc* d);
+/* 1 if this descriptor is served by the row-shift kernels (PD_WARP_DISP, scalar or per-row disparities), else 0. */
 int pd_sweep_uses_rowshift(const pd_sweep_desc* d);
 
 /* Floats per image the forward pass stashes for the backward pass (softmax statistics + mask bits). */

@@ -16,6 +16,7 @@ PD_MIXTURE, PD_AUTOMASK, PD_RENDER_PROB, PD_DISP_DENSE, PD_DISP_ROWS, PD_MASK_RO
 PD_BWD_ACCUMULATE = 128
 PD_BWD_DEFER_GATHER = 256
 PD_PH_MEAN_ZEROED = 512
+PD_BWD_PLANE_ZEROED = 1024
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
 PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
@@ -60,6 +61,7 @@ SIGNATURES = {
     "pd_sweep_uses_rowshift": (_I, [_D]),
     "pd_sweep_auto_row_eps": (_F, []),
     "pd_sweep_bwd_accumulates": (_I, [_D]),
+    "pd_sweep_bwd_plane_adds": (_I, [_D]),
     "pd_sweep_stash_floats": (ctypes.c_size_t, [_D]),
     "pd_sweep_bwd_workspace_floats": (ctypes.c_size_t, [_D]),
     "pd_plane_sweep_fwd": (_I, [_D] + [_P] * 14),

@@ -657,6 +657,13 @@ extern "C" int pd_plane_sweep_bwd(const pd_sweep_desc* d, const float* src, cons
                         g_ph_map, g_ph_mean, g_logits, g_sigma, g_plane, g_dists, workspace, stream, nullptr);
 }
 
+extern "C" int pd_sweep_bwd_plane_adds(const pd_sweep_desc* d) {
+  if (!d || !(wants_rowshift(d) && rowshift_applicable(d)) || d->impl == PD_IMPL_ROWS1 || (d->flags & (PD_DISP_ROWS | PD_DISP_DENSE))) return 0;
+  SweepArgs probe;
+  probe.has_mask = 0;   // (the caller passes no per-pixel mask when it relies on this: pd_plane_sweep_bwd falls back to overwriting otherwise)
+  return rowstream_bwd_applicable(d, probe) ? 1 : 0;
+}
+
 extern "C" int pd_sweep_bwd_tail_fuses(const pd_sweep_desc* d) {
   if (!d || !(wants_rowshift(d) && rowshift_applicable(d)) || d->impl == PD_IMPL_ROWS1) return 0;
   SweepArgs probe;

@@ -235,7 +235,7 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
                                                 float4* __restrict__ col, int2* __restrict__ shift,
                                                 float* __restrict__ rgb_rec, float* __restrict__ ph_map,
                                                 float* __restrict__ stash) {
-  constexpr int D = (NROWS == 1) ? PD_FS_D1 : PD_FS_D2;
+  constexpr int D = (NROWS == 1) ? (RENDER ? PD_FS_D1 - 1 : PD_FS_D1) : PD_FS_D2;   // (compositing: the ring also carries dists — one slot less keeps it out of scratch)
   const int W = a.W, N = a.N, HW = a.H * a.W;
   FsRow r;
   r.y = y;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, f
   const int slot = wave / segs;                                  // which of the workgroup's rows
   const int CWk = a.W + 2 * kFsGuard;
   const int row_f4 = CWk + (a.N + 1) / 2;   // float4 per row buffer
-  const int nbuf = rounds > 1 ? 2 : 1;
+  const int nbuf = (!RENDER && rounds > 1) ? 2 : 1;
   float* parts = reinterpret_cast<float*>(lds4 + rows * nbuf * row_f4);
   int* team = reinterpret_cast<int*>(parts + kFsThreadsMax / kWave);
   const int groups = (a.H + rows - 1) / rows;                    // row groups per image
@@ -481,12 +481,14 @@ __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, f
   const int cb = blk % cblocks, k = blk / cblocks;
   const int T = groups * a.B;
   const int tix = threadIdx.x - slot * segs * kWave, nthr = segs * kWave;
-  if (rounds > 1) {
+  if (!RENDER && rounds > 1) {
     if (threadIdx.x < rows) team[threadIdx.x] = 0;
     __syncthreads();
   }
   float ph_sum = 0.0f;
-  for (int r = 0; r < rounds; ++r) {
+  const int nrounds = RENDER ? 1 : rounds;   // (the compositing kernels keep one item per workgroup: their plane loop holds more state,
+                                             // and the loop around it costs them 40-60 spilled registers)
+  for (int r = 0; r < nrounds; ++r) {
     const int pos = r * nbk + k;
     if (pos >= T) break;                                         // (workgroup-uniform)
     const int item = order.n ? (int)order.it[pos] : pos;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, f
     // rounds == 1: the kernel's only barrier before the outputs, every wave reaches it whatever its row needs; persistent: the
     // team's own (the buffer written here was last read two rounds ago, and every wave of the team has passed the barrier of
     // the round in between since)
-    if (rounds > 1) fs_team_barrier(team + slot, segs * (r + 1));
+    if (!RENDER && rounds > 1) fs_team_barrier(team + slot, segs * (r + 1));
     else __syncthreads();
     fs_stamp(1);
     if (!active) {}
@@ -561,6 +563,7 @@ static FsShape fwdstream_shape(const pd_sweep_desc* d) {
   const int items = ceil_div(d->H, s.rows) * s.cblocks * d->B;
   const int waves = s.rows * s.segs;
   s.rounds = PD_FS_ROUNDS ? PD_FS_ROUNDS : (2 * waves > kFsThreadsMax / kWave ? ceil_div(items, device_cu_count()) : 1);
+  if (d->flags & PD_RENDER_PROB) s.rounds = 1;
   if (s.rounds < 1) s.rounds = 1;
   if (s.rounds > 8) s.rounds = 8;
   s.nbk = ceil_div(ceil_div(d->H, s.rows) * d->B, s.rounds);   // blocks per column block

@@ -508,6 +508,8 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     const float gix_scale = (Wm1 / 2) * 2.0f / Wm1 * a.sign;  // d ix / d disp through un-normalise, *2, /(W-1)
     if (a.flags & PD_DISP_ROWS) {  // one disparity per (plane, row): this workgroup owns the whole sum
       for (int i = threadIdx.x; i < N; i += blockDim.x) o.g_plane[((long)r.b * N + i) * a.H + r.y] = L.red[i] * gix_scale;
+    } else if (a.flags & PD_BWD_PLANE_ZEROED) {   // the caller's g_plane holds zeros: the rows add up there (no partials, no reduction launch)
+      for (int i = threadIdx.x; i < N; i += blockDim.x) unsafeAtomicAdd(o.g_plane + (long)r.b * N + i, L.red[i] * gix_scale);
     } else {
       float* dstp = o.partials + ((long)r.b * a.H + r.y) * N;
       for (int i = threadIdx.x; i < N; i += blockDim.x) dstp[i] = L.red[i] * gix_scale;
@@ -611,7 +613,7 @@ int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, h
                                : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream);
   if (rc) return rc;
   rc = check_launch("rowstream_bwd_kernel");
-  if (rc || !o.g_plane || (d->flags & PD_DISP_ROWS)) return rc;
+  if (rc || !o.g_plane || (d->flags & (PD_DISP_ROWS | PD_BWD_PLANE_ZEROED))) return rc;
   reduce_rows_stream_kernel<<<dim3(d->N, d->B), kWave, 0, stream>>>(o.partials, o.g_plane, d->H, d->N);
   return check_launch("reduce_rows_kernel");
 }

@@ -79,6 +79,7 @@ def _contig(t):
 
 
 ZERO_POOL = os.environ.get("PD_ZERO_POOL", "1") != "0"   # A/B switch: 0 = a memset launch per forward call instead
+PLANE_ADDS = os.environ.get("PD_PLANE_ADDS", "1") != "0"   # A/B switch: 0 = per-row partial sums + a reduction launch per backward
 _ZERO_POOL = {}   # (device, stream) -> [pool tensor, next free slot]
 
 
@@ -97,6 +98,37 @@ def _zero_scalar(device, slots=4096):
     i = st[1]
     st[1] = i + 1
     return st[0][i:i + 1]
+
+
+_ZERO_BLOCKS = {}   # (device, stream) -> [pool tensor, next free float]
+_ZERO_BLOCK_FLOATS = 1 << 18
+
+
+def _zero_block(device, shape):
+    """A fresh float32 tensor of ``shape`` that holds zeros, cut from a 1 MB pool zeroed once (same contract as
+    ``_zero_scalar``: every call gets floats of its own, nothing handed out is ever written by the pool again).  Serves the
+    per-plane disparity gradient under PD_BWD_PLANE_ZEROED — [B, N], 1.5 KB a call at the benchmark's shape."""
+    n = 1
+    for k in shape:
+        n *= int(k)
+    if torch.cuda.is_current_stream_capturing() or not ZERO_POOL or n > _ZERO_BLOCK_FLOATS // 8:
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    st = _ZERO_BLOCKS.get(key)
+    if st is None or st[1] + n > _ZERO_BLOCK_FLOATS:
+        st = _ZERO_BLOCKS[key] = [torch.zeros(_ZERO_BLOCK_FLOATS, device=device, dtype=torch.float32), 0]
+    i = st[1]
+    st[1] = i + ((n + 3) & ~3)   # 16-byte steps
+    return st[0][i:i + n].view(shape)
+
+
+def _plane_grad_buffer(plane, mode, flags):
+    """(g_plane buffer, extra descriptor flags) for a backward call that wants the plane-parameter gradient: one disparity
+    per plane gets a pre-zeroed [B, N] block and PD_BWD_PLANE_ZEROED (the row-stream backward then adds its rows' shares
+    there and launches no reduction kernel; the other kernels overwrite it as ever)."""
+    if PLANE_ADDS and mode == C.PD_WARP_DISP and not flags & (C.PD_DISP_DENSE | C.PD_DISP_ROWS):
+        return _zero_block(plane.device, tuple(plane.shape)), C.PD_BWD_PLANE_ZEROED
+    return torch.empty_like(plane), 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -247,9 +279,10 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=
     mode, flags, sign = cfg
     g_rgb_rec, g_ph_map, g_ph_mean = grads
     B, N, H, W = logits.shape
-    d = _desc(B, N, H, W, mode, flags | (C.PD_BWD_ACCUMULATE if accumulate else 0) | (C.PD_BWD_DEFER_GATHER if defer else 0),
-              sign)
     need_logits, need_sigma, need_plane, need_dists = need
+    g_plane, plane_flag = _plane_grad_buffer(plane, mode, flags) if need_plane else (None, 0)
+    d = _desc(B, N, H, W, mode, flags | plane_flag | (C.PD_BWD_ACCUMULATE if accumulate else 0) |
+              (C.PD_BWD_DEFER_GATHER if defer else 0), sign)
     mix = bool(flags & C.PD_MIXTURE)
     if defer:
         g_logits = g_sigma = None
@@ -258,7 +291,6 @@ def _sweep_backward(saved, cfg, grads, need, into=None, accumulate=False, defer=
     else:
         g_logits = torch.empty_like(logits) if need_logits else None
         g_sigma = torch.empty_like(sigma) if (need_sigma and mix) else None
-    g_plane = torch.empty_like(plane) if need_plane else None
     g_dists = torch.empty_like(dists) if (dists is not None and need_dists) else None
     # scratch: partial sums of the plane-parameter gradient and the row-shift kernels' boundary spill
     ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device,
@@ -289,10 +321,10 @@ def _sweep_backward_tail(saved, cfg, grads, need, link):
     mode, flags, sign = cfg
     g_rgb_rec, g_ph_map, g_ph_mean = grads
     B, N, H, W = logits.shape
-    d = _desc(B, N, H, W, mode, flags, sign)
+    g_plane, plane_flag = _plane_grad_buffer(plane, mode, flags) if need[2] else (None, 0)
+    d = _desc(B, N, H, W, mode, flags | plane_flag, sign)
     g_disp, g_depth = link.seen.get("disp"), link.seen.get("depth")
     gl, gs = torch.empty_like(logits), torch.empty_like(sigma)
-    g_plane = torch.empty_like(plane) if need[2] else None
     ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device, dtype=torch.float32)
     g_rgb_rec, g_ph_map, gd, gz = map(_contig, (g_rgb_rec, g_ph_map, g_disp, g_depth))
     if g_ph_mean is not None:
@@ -1391,25 +1423,6 @@ class _PladeTail(torch.autograd.Function):
         need_l, need_s, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and mix, ctx.needs_input_grad[2]
         if not (need_l or need_s or need_d):
             return None, None, None, None, None, None
-        link = ctx.link
-        extra = None
-        if link is not None and link.applied is not None:
-            # the sweep's backward kernel applied this node's backward already (pd_plane_sweep_bwd_tail): g_logits / g_sigma ARE
-            # the conv outputs' gradients, the disparity share went into the sweep's g_plane.  Only an upstream gradient of
-            # disp / depth that the sweep did not see is still owed: the plain kernel on that remainder alone, added on top.
-            def rest(got, used):
-                if got is None:
-                    return None
-                if used is None:
-                    return got
-                if got.data_ptr() == used.data_ptr() and got.shape == used.shape:
-                    return None
-                return got - used
-            r_disp, r_depth = rest(g_disp, link.applied["disp"]), rest(g_depth, link.applied["depth"])
-            if r_disp is None and r_depth is None:
-                return (g_logits if need_l else None), (g_sigma if need_s else None), None, None, None, None
-            extra = (g_logits, g_sigma)
-            g_logits, g_sigma, g_disp, g_depth = None, None, r_disp, r_depth
         g_raw_logits = torch.empty_like(raw_logits) if need_l else None
         g_raw_sigma = torch.empty_like(raw_sigma) if need_s else None
         g_dl = torch.empty_like(disp_layered) if need_d else None

@@ -2270,6 +2270,33 @@ def test_two_host_threads_on_one_device_equal_the_serial_result():
         assert rel_err(out[i]["g_disp_pp"], serial["g_disp_pp"]) < 1e-6   # (summed with LDS float atomics: order-dependent rounding)
 
 
+def test_plane_gradient_added_into_a_zeroed_block_equals_the_reduced_partials(monkeypatch):
+    """PD_BWD_PLANE_ZEROED (include/planedepth_hip.h): the row-stream backward adds every row's share of the per-plane
+    disparity gradient into the caller's pre-zeroed [B, N] block instead of writing per-row partials for a reduction launch.
+    Both forms against each other (rounding: the order of the float adds differs) and, through the usual parity cases, against
+    the oracle; blocks handed out by the pool are never written twice (an earlier step's gradient keeps its value)."""
+    import ctypes
+    from gpu_cases import run_product
+    from planedepth_amd import _capi as C, ops
+    from planedepth_amd.synthetic import survey_fullsize_case
+    case = survey_fullsize_case(B=3, N=13, H=48, W=320, seed=77, sigma_interior=True)
+    extra = dict(xz_levels=0, yz_levels=0)
+    d = ops._desc(3, 13, 48, 320, C.PD_WARP_DISP, C.PD_MIXTURE | C.PD_AUTOMASK, -1.0)
+    assert C.load().pd_sweep_bwd_plane_adds(ctypes.byref(d)) == 1
+    monkeypatch.setattr(ops, "PLANE_ADDS", True)
+    first = run_product(case, {}, opt_extra=extra)
+    kept = first["g_disp_pp"].clone()
+    again = run_product(case, {}, opt_extra=extra)
+    monkeypatch.setattr(ops, "PLANE_ADDS", False)
+    ref = run_product(case, {}, opt_extra=extra)
+    assert float(ref["g_disp_pp"].abs().max()) > 0
+    assert rel_err(first["g_disp_pp"], ref["g_disp_pp"]) < 2e-6
+    assert rel_err(again["g_disp_pp"], ref["g_disp_pp"]) < 2e-6
+    assert torch.equal(first["g_disp_pp"], kept)   # the second call got a block of its own
+    for k in ("g_logits", "g_sigma"):
+        assert torch.equal(first[k], ref[k]), k
+
+
 def test_launches_follow_torchs_current_stream():
     """The C ABI takes an explicit stream and the Python layer hands it torch's CURRENT one: the whole path run inside a
     side-stream context (inputs produced on that stream right before, no synchronisation in between) gives the result
