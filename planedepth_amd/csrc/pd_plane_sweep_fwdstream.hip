@@ -16,9 +16,9 @@
 //     descriptor's range check is padding_mode = "zeros"), half the memory instructions per pixel of the 8-byte form;
 //   * one plane per iteration behind a register ring of PD_FS_D1 iterations of loads (6 VGPRs per slot): the state per
 //     wave is two accumulator sets + the ring, 94 VGPRs instead of 148;
-//   * a workgroup serves PD_FS_ROWS = 3 consecutive target rows (15 waves at W = 640, one workgroup per CU): its waves read three
-//     adjacent rows of every plane (7.5 KB contiguous) at about the same time, and the second source row of an inexact row is
-//     its neighbour's main row;
+//   * a workgroup serves PD_FS_ROWS = 3 target rows (15 waves at W = 640, one workgroup per CU) — neighbours, grouped so that the
+//     second source row of an inexact row is the main row of a team in the same workgroup wherever three rows allow
+//     (fwdstream_rows; consecutive rows otherwise): the waves read the rows of every plane at about the same time;
 //   * round 5 (profiles/r05_fwd_ladder.md): the workgroup is PERSISTENT — it walks its share of the launch's (image, row group)
 //     items, the five waves of a row slot ("team") staging the next item's row into the slot's second LDS buffer as soon as the
 //     TEAM is done and meeting only each other (an LDS counter) — no workgroup barrier between items, nothing idles while the
@@ -448,6 +448,11 @@ __device__ __forceinline__ void fs_team_barrier(int* cnt, int target) {
 // means "as they come".
 constexpr int kFsOrderMax = 1024;
 struct FsOrder { int n; unsigned short it[kFsOrderMax]; };
+// Which target rows make up a row group, by value in the kernel arguments as well: n = 0 means group g serves rows g * rows ..
+// g * rows + rows - 1; otherwise slot s of group g serves row y[g * rows + s] (>= H: none).  The host's regrouping
+// (fwdstream_rows) puts a row that blends two source rows into the group of the neighbour whose main row that second row is.
+constexpr int kFsRowsMax = 640;
+struct FsRows { int n; unsigned short y[kFsRowsMax]; };
 
 // A workgroup serves `rows` consecutive target rows x one of `cblocks` column blocks of `segs` segments each (rows wider than
 // 640 pixels are cut into column blocks so that three rows still fit the 16 waves of a workgroup) — one "item".  With
@@ -461,7 +466,7 @@ template <bool MIX, bool AUTO, bool RENDER>
 __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, float* __restrict__ rgb_rec,
                                                                             float* __restrict__ ph_map,
                                                                             float* __restrict__ stash, int rows, int cblocks,
-                                                                            int rounds, int nbk, FsOrder order) {
+                                                                            int rounds, int nbk, FsOrder order, FsRows rowtab) {
   extern __shared__ float4 lds4[];
   // LDS per row slot: (colour row float4[W + 8] | shift int2[N] (padded to 16 bytes)) x (rounds > 1 ? 2 buffers : 1); then the
   // wave totals of ph_map and the teams' counters
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kFsThreadsMax) void fwdstream_kernel(SweepArgs a, f
     const int b = item % a.B, gsel = item / a.B;
     const int grp = PD_FS_REVERSE ? groups - 1 - gsel : gsel;
     const int seg = cb * segs + (wave - slot * segs);            // which segment of the row
-    const int y = grp * rows + slot;
+    const int y = rowtab.n ? (int)rowtab.y[grp * rows + slot] : grp * rows + slot;
     const bool active = y < a.H && seg < nseg;
     const RowSel row = two_row_form(make_row_sel(y < a.H ? y : 0, a.H), a.row_eps);
     float4* col = lds4 + (slot * nbuf + (r & 1)) * row_f4;
@@ -581,7 +586,8 @@ static FsShape fwdstream_shape(const pd_sweep_desc* d) {
 // Does target row y blend two source rows (the row bodies' "heavy" rows: twice the tap loads)?  make_row_sel + two_row_form
 // on the host, operation by operation in fp32.  Only the DEAL depends on it (the kernel decides every row's footprint itself),
 // so a disagreement with the device in some last bit would cost balance, not correctness.
-static bool host_row_is_heavy(int y, int H, float row_eps) {
+static bool host_row_is_heavy(int y, int H, float row_eps, int* partner = nullptr) {
+  if (partner) *partner = -1;
   volatile float hm1 = (float)(H - 1);
   volatile float q = (float)y / hm1;
   volatile float h = q - 0.5f;
@@ -593,18 +599,80 @@ static bool host_row_is_heavy(int y, int H, float row_eps) {
   volatile float yf1 = yf + 1.0f;
   volatile float wy0 = yf1 - iy, wy1 = iy - yf;
   const bool use0 = yf >= 0.0f && yf <= hm1 && wy0 != 0.0f, use1 = yf1 >= 0.0f && yf1 <= hm1 && wy1 != 0.0f;
-  if (use0 && use1) return !(row_eps > 0.0f && fminf(wy0, wy1) < row_eps);
-  const float wA = use0 ? wy0 : wy1;
   const int y0 = (int)yf;
+  if (use0 && use1) {
+    const bool two = !(row_eps > 0.0f && fminf(wy0, wy1) < row_eps);
+    if (two && partner) *partner = (y0 == y) ? y0 + 1 : y0;   // the OTHER source row: the main row of that target row
+    return two;
+  }
+  const float wA = use0 ? wy0 : wy1;
   const float wmain = (y0 == y) ? wy0 : ((y0 + 1 == y) ? wy1 : 0.0f);
   return (use0 || use1) && (wA != 1.0f || wmain != 1.0f);
+}
+
+// Row groups that keep a heavy row and the neighbour it blends in together.  A team reads its row's second source row from global
+// memory; where the team of that row sits in the same workgroup the lines are in the CU's L1 / the XCD's L2 (the teams walk the
+// planes within a few planes of each other), where it sits in another workgroup they mostly are not: with consecutive rows
+// 3g .. 3g + 2, 15 of the 48 heavy rows of H = 192 have their partner in the next group (NOTEBOOK 10.7: 30 MB of the forward's
+// 41 MB of excess reads).  Groups need not be consecutive rows — each team has its own row buffer — so: chains of linked rows are
+// cut into pieces of at most `rows`, the pieces go first-fit (longest first) into the G groups, single rows fill the holes in order.
+// H = 192, rows = 3: two links left cut (the chains 24-28 and 30-33) instead of fifteen.
+#ifndef PD_FS_REGROUP
+#define PD_FS_REGROUP 1   // 0: consecutive rows (A/B)
+#endif
+static FsRows fwdstream_rows(int H, int R, float row_eps) {
+  struct Cache { int H = 0, R = 0; float eps = -1.0f; FsRows t; };
+  static thread_local Cache c;   // (the table depends on the height, the rows per group and the threshold only)
+  const int G = ceil_div(H, R);
+  if (c.H == H && c.R == R && c.eps == row_eps) return c.t;
+  c.H = H; c.R = R; c.eps = row_eps;
+  FsRows& t = c.t;
+  t.n = 0;
+  if (!PD_FS_REGROUP || R < 2 || G * R > kFsRowsMax) return t;
+  static thread_local unsigned char link[kFsRowsMax], placed[kFsRowsMax], fill[kFsRowsMax];
+  int nlinks = 0;
+  for (int y = 0; y < H; ++y) link[y] = placed[y] = 0;
+  for (int y = 0; y < H; ++y) {
+    int p;
+    if (host_row_is_heavy(y, H, row_eps, &p) && p >= 0 && p < H && (p == y + 1 || p == y - 1)) { link[p < y ? p : y] = 1; ++nlinks; }
+  }
+  if (!nlinks) return t;
+  for (int g = 0; g < G; ++g) fill[g] = 0;
+  for (int i = 0; i < G * R; ++i) t.y[i] = 0xFFFF;
+  auto cap = [&](int g) { return g == G - 1 ? H - (G - 1) * R : R; };
+  for (int len = R; len >= 2; --len) {          // pieces of a chain, longest first; first fit
+    int y = 0;
+    while (y < H) {
+      int n = 1;
+      while (y + n < H && n < R && link[y + n - 1]) ++n;   // (the chain is cut after R rows)
+      if (n == len && !placed[y]) {
+        for (int g = 0; g < G; ++g)
+          if (fill[g] + n <= cap(g)) {
+            for (int k = 0; k < n; ++k) { t.y[g * R + fill[g] + k] = (unsigned short)(y + k); placed[y + k] = 1; }
+            fill[g] += n;
+            break;
+          }
+        // (no group with room left: the rows stay single and fill holes below)
+      }
+      y += n;
+    }
+  }
+  int g = 0;
+  for (int y = 0; y < H; ++y) {                  // everything else, in order, into the holes
+    if (placed[y]) continue;
+    while (g < G && fill[g] >= cap(g)) ++g;
+    if (g == G) { t.n = 0; return t; }           // (cannot happen: the capacities add up to H)
+    t.y[g * R + fill[g]++] = (unsigned short)y;
+  }
+  t.n = G * R;
+  return t;
 }
 
 // The persistent workgroups' deal: items (row group x image) sorted by the number of heavy rows in the group (heavy first;
 // ties in launch order, images fastest), chunked into `rounds` chunks of nbk, every other chunk reversed — block k then serves
 // the k-th heaviest item of the first chunk, the k-th LIGHTEST of the second, and so on (profiles/r05_fwd_ladder.md: with the
 // dispatcher's order the CUs' totals differ by 13 % on the exact-rows forward).
-static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float row_eps) {
+static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float row_eps, const FsRows& rowtab) {
   FsOrder o;
   o.n = 0;
   const int groups = ceil_div(d->H, sh.rows), T = groups * d->B;
@@ -612,7 +680,10 @@ static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float 
   int weight[kFsOrderMax], sorted[kFsOrderMax];
   for (int g = 0; g < groups; ++g) {
     int w = 0;
-    for (int r = 0; r < sh.rows && g * sh.rows + r < d->H; ++r) w += host_row_is_heavy(g * sh.rows + r, d->H, row_eps) ? 1 : 0;
+    for (int r = 0; r < sh.rows; ++r) {
+      const int y = rowtab.n ? (int)rowtab.y[g * sh.rows + r] : g * sh.rows + r;
+      if (y < d->H) w += host_row_is_heavy(y, d->H, row_eps) ? 1 : 0;
+    }
     weight[g] = w;
   }
   int n = 0;   // counting sort by weight, descending; stable in (group, image).  (Light groups first with a top-down backward,
@@ -648,14 +719,15 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
     return rowshift_fwd(d, a, rgb_rec, ph_map, stash, stream);   // unaligned tensors: the one-pixel-per-lane forward
   const FsShape sh = fwdstream_shape(d);
   const dim3 grid(sh.nbk * sh.cblocks, 1), block(sh.segs * sh.rows * kWave);
-  const FsOrder order = fwdstream_order(d, sh, a.row_eps);
+  const FsRows rowtab = fwdstream_rows(d->H, sh.rows, a.row_eps);
+  const FsOrder order = fwdstream_order(d, sh, a.row_eps, rowtab);
   const size_t shmem = sh.lds;
   const bool mix = (d->flags & PD_MIXTURE) != 0, am = (d->flags & PD_AUTOMASK) != 0, render = (d->flags & PD_RENDER_PROB) != 0;
 #define PD_FS_LAUNCH(M, A, R)                                                                                              \
   do {                                                                                                                    \
     static LdsGrant granted;                                                                                              \
     if (int rc = grant_dynamic_lds((const void*)fwdstream_kernel<M, A, R>, shmem, &granted, "fwdstream_kernel")) return rc; \
-    fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks, sh.rounds, sh.nbk, order); \
+    fwdstream_kernel<M, A, R><<<grid, block, shmem, stream>>>(a, rgb_rec, ph_map, stash, sh.rows, sh.cblocks, sh.rounds, sh.nbk, order, rowtab); \
   } while (0)
   if (render) {
     if (mix) { if (am) PD_FS_LAUNCH(true, true, true); else PD_FS_LAUNCH(true, false, true); }
@@ -669,6 +741,28 @@ int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, fl
 }
 
 }  // namespace pd
+
+// Host-only diagnostics (not declared in include/planedepth_hip.h; tests/test_row_groups.py): the forward's row groups for a
+// height and `rows` rows per group -> out[G * rows] (entries >= H: empty slots), *links / *cut = linked row pairs in all / those
+// whose rows ended up in different groups.  Returns G * rows, 0 where the consecutive grouping is kept, -1 on bad arguments.
+extern "C" int pd_debug_fwd_row_groups(int H, int rows, float row_eps, unsigned short* out, int* links, int* cut) {
+  if (H < 1 || rows < 1 || !out) return -1;
+  const pd::FsRows t = pd::fwdstream_rows(H, rows, row_eps);
+  const int G = (H + rows - 1) / rows;
+  for (int i = 0; i < G * rows && i < pd::kFsRowsMax; ++i) out[i] = t.n ? t.y[i] : (unsigned short)(i < H ? i : 0xFFFF);
+  int nl = 0, nc = 0;
+  for (int y = 0; y < H; ++y) {
+    int p;
+    if (!pd::host_row_is_heavy(y, H, row_eps, &p) || p < 0 || p >= H) continue;
+    ++nl;
+    int gy = -1, gp = -1;
+    for (int i = 0; i < G * rows && i < pd::kFsRowsMax; ++i) { if (out[i] == y) gy = i / rows; if (out[i] == p) gp = i / rows; }
+    if (gy != gp) ++nc;
+  }
+  if (links) *links = nl;
+  if (cut) *cut = nc;
+  return t.n;
+}
 
 #if PD_FS_TRACE
 // diagnostics build only (not declared in include/planedepth_hip.h): copies the stamps of the last launch to the host
