@@ -954,8 +954,9 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_launch,
                      "avg_launch_ms": round(kt[dom], 4),
-                     "timing": "HIP events on the launch stream around the C-ABI call (the sweep kernel plus its 5 us helper "
-                               "launch: ph_mean memset / row reduction), inside the training step, steady state"}
+                     "timing": "HIP events on the launch stream around the C-ABI call (for the default workload the sweep kernel "
+                               "alone: ph_mean and g_plane arrive pre-zeroed, PD_PH_MEAN_ZEROED / PD_BWD_PLANE_ZEROED; other "
+                               "workloads add their 5 us helper launches), inside the training step, steady state"}
             # headline workload -> "roofline"; the general (homography) kernels report the same block under their own key
             result["roofline" if args.warp_type == "disp_warp" else "roofline_general"] = block
             if args.warp_type != "disp_warp":
