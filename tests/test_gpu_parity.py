@@ -308,6 +308,11 @@ _FS_CASES = [
     (2, 49, 48, 1280, 1.0, True, False, False),   # wide rows: two column blocks of five segments, three rows per workgroup
     (1, 9, 7, 2048, -1.0, True, False, False),    # four column blocks of four segments (100 KB of LDS), a ragged row group
     (1, 9, 4, 1416, 1.0, True, True, False),      # twelve segments in three blocks, the last one ragged
+    # regrouped rows (fwdstream_rows: linked rows share a workgroup; tests/test_row_groups.py checks the table on the CPU)
+    (1, 5, 213, 64, 1.0, True, False, False),     # H % 3 != 0: the last group has one row, 71 groups
+    (1, 9, 384, 640, -1.0, True, True, False),    # BASELINE configs[4]'s height: 94 linked rows
+    (1, 3, 640, 64, 1.0, True, False, False),     # the largest height the table holds
+    (1, 3, 643, 64, 1.0, False, False, False),    # beyond it: consecutive rows
 ]
 
 
