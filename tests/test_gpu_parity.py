@@ -2333,6 +2333,19 @@ def test_launches_follow_torchs_current_stream():
         assert rel_err(a_.cpu(), b_.cpu()) < 1e-6
 
 
+def test_step_replayed_from_a_hip_graph_equals_the_eager_step():
+    """bench.py may time the step as a HIP-graph replay (``--launch auto`` takes the faster form) and a trainer may capture it:
+    the whole step — forward, fused mean, backward with the per-plane disparity gradient — recorded once in a torch CUDAGraph
+    and replayed three times gives the eager result every time.  What could break it: the pre-zeroed slots (``ph_mean`` under
+    PD_PH_MEAN_ZEROED, ``g_plane`` under PD_BWD_PLANE_ZEROED) are added INTO by the kernels, so a replay has to zero them in
+    the captured work itself (ops._zero_scalar / _zero_block hand out a captured ``zeros`` while the stream is capturing)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_replay_check.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graph replay equals eager: ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_randomised_shapes_homography_shortcuts_vs_general():
     """Seeded sweep over odd shapes (heights / widths from 2 up, not multiples of the 32 x 8 tiles, fewer planes than a
     staging group, batch 1..3, rotations up to ~15 degrees, zooms, L1 / mixture / automask / compositing, one or two
