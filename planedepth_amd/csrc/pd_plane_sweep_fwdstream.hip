@@ -453,6 +453,8 @@ struct FsOrder { int n; unsigned short it[kFsOrderMax]; };
 // (fwdstream_rows) puts a row that blends two source rows into the group of the neighbour whose main row that second row is.
 constexpr int kFsRowsMax = 640;
 struct FsRows { int n; unsigned short y[kFsRowsMax]; };
+static_assert(sizeof(SweepArgs) + 3 * sizeof(float*) + 4 * sizeof(int) + sizeof(FsOrder) + sizeof(FsRows) <= 4096,
+              "the forward's kernel arguments must fit the 4 KB kernarg segment");
 
 // A workgroup serves `rows` consecutive target rows x one of `cblocks` column blocks of `segs` segments each (rows wider than
 // 640 pixels are cut into column blocks so that three rows still fit the 16 waves of a workgroup) — one "item".  With

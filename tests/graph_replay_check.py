@@ -53,7 +53,7 @@ def main():
     assert float(want["g_d"].abs().max()) > 0 and float(want["ph_mean"]) > 0
     for g_ in got:
         for k, w in want.items():
-            tol = 2e-6 if k in ("g_d", "ph_mean") else 0.0   # (sums by float atomics: the order varies)
+            tol = 1e-5 if k in ("g_d", "ph_mean") else 0.0   # (sums by float atomics: the order varies)
             assert rel_err(g_[k].cpu(), w.cpu()) <= tol, k
     print("graph replay equals eager: ok")
 

@@ -577,7 +577,7 @@ def test_fast_rows_mode_is_opt_in_and_bounded():
         same_as = fast if eps > 0.0 else exact
         for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma"):
             assert torch.equal(auto[k], same_as[k]), k
-        assert rel_err(auto["g_disp_pp"], same_as["g_disp_pp"]) < 1e-6   # (summed with LDS float atomics: order-dependent rounding)
+        assert rel_err(auto["g_disp_pp"], same_as["g_disp_pp"]) < 1e-5   # (summed with float atomics, LDS and global: order-dependent rounding)
     else:
         _compare(auto, want, keys=keys + ("g_sigma",), tag="auto", tol=1e-4)
 
@@ -1347,7 +1347,8 @@ def test_two_rank_hip_shards_reproduce_the_full_batch():
         assert torch.equal(ret[r]["rgb_rec"], full["rgb_rec"][sl]) and torch.equal(ret[r]["ph_map"], full["ph_map"][sl])
         for k in ("g_logits", "g_sigma", "g_disp_pp"):
             assert float(full[k][sl].abs().max()) > 0, k
-            assert rel_err(ret[r][k], full[k][sl]) < 1e-6, (k, rel_err(ret[r][k], full[k][sl]))
+            # (the per-plane disparity gradient is a sum of float atomics over the image's rows: its last bits depend on the order)
+            assert rel_err(ret[r][k], full[k][sl]) < (1e-5 if k == "g_disp_pp" else 1e-6), (k, rel_err(ret[r][k], full[k][sl]))
     assert abs(0.5 * (float(ret[0]["ph_loss"]) + float(ret[1]["ph_loss"])) - float(full["ph_loss"])) < 1e-6
 
 
@@ -2272,7 +2273,7 @@ def test_two_host_threads_on_one_device_equal_the_serial_result():
         serial = run_product(cases[i], {}, opt_extra=extra)
         for k in ("rgb_rec", "ph_map", "g_logits", "g_sigma"):
             assert torch.equal(out[i][k], serial[k]), (i, k)
-        assert rel_err(out[i]["g_disp_pp"], serial["g_disp_pp"]) < 1e-6   # (summed with LDS float atomics: order-dependent rounding)
+        assert rel_err(out[i]["g_disp_pp"], serial["g_disp_pp"]) < 1e-5   # (summed with float atomics: order-dependent rounding)
 
 
 def test_plane_gradient_added_into_a_zeroed_block_equals_the_reduced_partials(monkeypatch):
@@ -2295,8 +2296,8 @@ def test_plane_gradient_added_into_a_zeroed_block_equals_the_reduced_partials(mo
     monkeypatch.setattr(ops, "PLANE_ADDS", False)
     ref = run_product(case, {}, opt_extra=extra)
     assert float(ref["g_disp_pp"].abs().max()) > 0
-    assert rel_err(first["g_disp_pp"], ref["g_disp_pp"]) < 2e-6
-    assert rel_err(again["g_disp_pp"], ref["g_disp_pp"]) < 2e-6
+    assert rel_err(first["g_disp_pp"], ref["g_disp_pp"]) < 1e-5
+    assert rel_err(again["g_disp_pp"], ref["g_disp_pp"]) < 1e-5
     assert torch.equal(first["g_disp_pp"], kept)   # the second call got a block of its own
     for k in ("g_logits", "g_sigma"):
         assert torch.equal(first[k], ref[k]), k
@@ -2329,8 +2330,8 @@ def test_launches_follow_torchs_current_stream():
         for _ in range(3):
             got = run()
     side.synchronize()
-    for a_, b_ in zip(got, want):
-        assert rel_err(a_.cpu(), b_.cpu()) < 1e-6
+    for i_, (a_, b_) in enumerate(zip(got, want)):
+        assert rel_err(a_.cpu(), b_.cpu()) < (1e-5 if i_ == 4 else 1e-6)   # (4: the per-plane disparity gradient, float atomics)
 
 
 def test_step_replayed_from_a_hip_graph_equals_the_eager_step():
