@@ -706,24 +706,6 @@ static FsOrder fwdstream_order(const pd_sweep_desc* d, const FsShape& sh, float 
   return o;
 }
 
-bool fwdstream_last_round_rows(const pd_sweep_desc* d, float row_eps, unsigned char* last) {
-  const FsShape sh = fwdstream_shape(d);
-  if (sh.rounds < 2 || sh.cblocks != 1) return false;
-  const FsRows rowtab = fwdstream_rows(d->H, sh.rows, row_eps);
-  const FsOrder order = fwdstream_order(d, sh, row_eps, rowtab);
-  if (!order.n) return false;
-  const int groups = ceil_div(d->H, sh.rows);
-  int votes[kFsOrderMax] = {0};   // per group: images served in the last round
-  for (int pos = (sh.rounds - 1) * sh.nbk; pos < order.n; ++pos) ++votes[order.it[pos] / d->B];
-  for (int y = 0; y < d->H; ++y) last[y] = 0;
-  for (int g = 0; g < groups; ++g)
-    for (int r = 0; r < sh.rows; ++r) {
-      const int y = rowtab.n ? (int)rowtab.y[g * sh.rows + r] : g * sh.rows + r;
-      if (y < d->H) last[y] = (2 * votes[g] > d->B) ? 1 : 0;
-    }
-  return true;
-}
-
 bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
   if (!rowshift_applicable(d) || a.has_mask || !switches().fwd_stream) return false;
   if ((d->flags & PD_RENDER_PROB) && (((long)d->H * d->W) % 2 != 0 || (reinterpret_cast<uintptr_t>(a.dists) & 7))) return false;

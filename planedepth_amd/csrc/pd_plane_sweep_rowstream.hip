@@ -316,11 +316,11 @@ __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs
 }
 
 template <bool MIX, int NROWS, bool PK, bool TAIL>
-__device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, int yrow, const StreamLds& L) {
+__device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, const StreamLds& L) {
   constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
   const int W = a.W, N = a.N, HW = a.H * a.W;
   StreamRow r;
-  r.y = yrow;
+  r.y = block_row(bwd_rowid(a.B, a.H), a.H);
   r.b = wg_image(a.B, a.H);
   r.yA = row.yA; r.yB = (NROWS == 2) ? row.yB : row.yA;
   r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
@@ -519,14 +519,8 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
 
 // (TAIL: the tail's terms take the kernel from 77 to 93 VGPRs, which costs the third resident workgroup; bounded at six waves per
 // SIMD it keeps it for twelve spilled dwords outside the loop: 0.175 against 0.196 ms, next to 0.174 + 0.208 ms for the two kernels)
-#ifndef PD_BWD_ORDER
-#define PD_BWD_ORDER 1   // rows the forward served in its last round first (bottom-up within each class), table by value; 0: plain bottom-up (A/B)
-#endif
-constexpr int kBwdRowsMax = 1024;
-struct BwdRows { int n; unsigned short row[kBwdRowsMax]; };   // n = 0: the built-in order
-
 template <bool MIX, bool PK, bool TAIL>
-__global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o, BwdRows ord) {
+__global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void rowstream_bwd_kernel(SweepArgs a, BwdOut o) {
   extern __shared__ float4 lds4[];
   StreamLds L;
   const int nseg = (a.W + kSeg - 1) / kSeg;
@@ -540,10 +534,9 @@ __global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void r
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
   L.dpl = reinterpret_cast<float*>(L.special + 4);
-  const int yrow = (PD_BWD_ORDER && ord.n) ? (int)ord.row[wg_rowid(a.B, a.H)] : block_row(bwd_rowid(a.B, a.H), a.H);
-  const RowSel row = two_row_form(make_row_sel(yrow, a.H), a.row_eps);
-  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, row, yrow, L);
-  else                                     stream_body<MIX, 1, PK, TAIL>(a, o, row, yrow, L);
+  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
+  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, row, L);
+  else                                     stream_body<MIX, 1, PK, TAIL>(a, o, row, L);
 }
 
 __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
@@ -592,11 +585,11 @@ bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
 size_t rowstream_bwd_workspace_floats(const pd_sweep_desc* d) { return (size_t)d->B * d->H * d->N; }
 
 template <bool MIX, bool PK, bool TAIL>
-static int rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, const BwdRows& ord) {
+static int rowstream_launch(const SweepArgs& a, const BwdOut& o, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
   static LdsGrant granted;   // per instantiation and device: the attribute is set once (and checked), not per launch
   const int rc = grant_dynamic_lds((const void*)rowstream_bwd_kernel<MIX, PK, TAIL>, shmem, &granted, "rowstream_bwd_kernel");
   if (rc) return rc;
-  rowstream_bwd_kernel<MIX, PK, TAIL><<<grid, block, shmem, stream>>>(a, o, ord);
+  rowstream_bwd_kernel<MIX, PK, TAIL><<<grid, block, shmem, stream>>>(a, o);
   return PD_OK;
 }
 
@@ -607,41 +600,17 @@ bool rowstream_bwd_tail_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
          (d->sign == 1.0f || d->sign == -1.0f) && rowstream_shape(d, true).lds <= device_lds_bytes();
 }
 
-// PD_BWD_ORDER: the rows the forward served in its last round come first (they are what the 256 MB memory-side cache holds when
-// the backward starts: the persistent forward deals its heavy row groups in the first round and the light ones in the last, so
-// "bottom-up" alone starts the backward on a quarter of rows the forward read FIRST), bottom-up within each class as ever; the
-// rest follows, which is also what the next forward starts with.  Headline shape: backward 0.1789 -> 0.1767 ms in the
-// forward / backward loop (NOTEBOOK 10.9).  Only the order of the row workgroups changes; shapes whose forward is not dealt
-// (one round, column blocks) keep the plain order.
-static BwdRows bwd_rows(const pd_sweep_desc* d, float row_eps) {
-  struct Cache { int H = 0, B = 0, W = 0; float eps = -1.0f; BwdRows t; };
-  static thread_local Cache c;
-  if (c.H == d->H && c.B == d->B && c.W == d->W && c.eps == row_eps) return c.t;
-  c.H = d->H; c.B = d->B; c.W = d->W; c.eps = row_eps;
-  BwdRows& t = c.t;
-  t.n = 0;
-  unsigned char last[kBwdRowsMax];
-  if (!PD_BWD_ORDER || d->H > kBwdRowsMax || !fwdstream_last_round_rows(d, row_eps, last)) return t;
-  int n = 0;
-  for (int pass = 1; pass >= 0; --pass)
-    for (int y = d->H - 1; y >= 0; --y)
-      if (last[y] == pass) t.row[n++] = (unsigned short)y;
-  t.n = n;
-  return t;
-}
-
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
-  const BwdRows ord = bwd_rows(d, a.row_eps);
   const bool tail = o.tail_stash != nullptr;
   const StreamShape sh = rowstream_shape(d, tail);
   dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   int rc;
-  if (tail)     rc = rowstream_launch<true, false, true>(a, o, grid, block, sh.lds, stream, ord);
-  else if (mix) rc = sh.packed ? rowstream_launch<true, true, false>(a, o, grid, block, sh.lds, stream, ord)
-                               : rowstream_launch<true, false, false>(a, o, grid, block, sh.lds, stream, ord);
-  else          rc = sh.packed ? rowstream_launch<false, true, false>(a, o, grid, block, sh.lds, stream, ord)
-                               : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream, ord);
+  if (tail)     rc = rowstream_launch<true, false, true>(a, o, grid, block, sh.lds, stream);
+  else if (mix) rc = sh.packed ? rowstream_launch<true, true, false>(a, o, grid, block, sh.lds, stream)
+                               : rowstream_launch<true, false, false>(a, o, grid, block, sh.lds, stream);
+  else          rc = sh.packed ? rowstream_launch<false, true, false>(a, o, grid, block, sh.lds, stream)
+                               : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream);
   if (rc) return rc;
   rc = check_launch("rowstream_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & (PD_DISP_ROWS | PD_BWD_PLANE_ZEROED))) return rc;
@@ -650,13 +619,3 @@ int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, h
 }
 
 }  // namespace pd
-
-// Host-only diagnostics (not declared in include/planedepth_hip.h; tests/test_row_groups.py): the row-stream backward's row
-// order for a shape -> out[H]; returns H, 0 where the built-in order (bottom-up) is kept, -1 on bad arguments.
-extern "C" int pd_debug_bwd_row_order(const pd_sweep_desc* d, float row_eps, unsigned short* out) {
-  if (!d || !out || d->H < 1) return -1;
-  const pd::BwdRows t = pd::bwd_rows(d, row_eps);
-  for (int i = 0; i < t.n; ++i) out[i] = t.row[i];
-  return t.n;
-}
-

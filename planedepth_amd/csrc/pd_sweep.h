@@ -271,9 +271,6 @@ size_t rowshift_bwd_workspace_floats(const pd_sweep_desc* d);
 // lane, one plane per iteration behind a deep register ring of 12-byte tap loads.
 bool fwdstream_applicable(const pd_sweep_desc* d, const SweepArgs& a);
 int fwdstream_fwd(const pd_sweep_desc* d, const SweepArgs& a, float* rgb_rec, float* ph_map, float* stash, hipStream_t stream);
-// Which target rows the segment-stream forward serves in its LAST round (what it read last is what the memory-side cache still
-// holds when the backward starts): last[y] = 1 for those rows.  false: the forward is not persistent / not dealt for this shape.
-bool fwdstream_last_round_rows(const pd_sweep_desc* d, float row_eps, unsigned char* last);
 
 // Row-stream backward (pd_plane_sweep_rowstream.hip): lanes own aligned source slots, waves stream along plane rows.
 bool rowstream_bwd_applicable(const pd_sweep_desc* d, const SweepArgs& a);

@@ -51,36 +51,3 @@ def test_heights_beyond_the_table_keep_consecutive_rows():
     n, out, links, cut = _groups(642, 3)
     assert n == 0
 
-
-def _bwd_order(B, N, H, W, eps=0.0):
-    lib = C.load()
-    fn = lib.pd_debug_bwd_row_order
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
-    d = C.SweepDesc(B, N, H, W, C.PD_WARP_DISP, C.PD_MIXTURE, 1.0, 0)
-    out = np.full(max(H, 1), 0xFFFF, dtype=np.uint16)
-    n = fn(ctypes.addressof(d), eps, out.ctypes.data)
-    return n, out
-
-
-@pytest.mark.parametrize("B,H,W", [(8, 192, 640), (12, 192, 640), (3, 192, 640), (1, 47, 640), (8, 96, 512), (4, 384, 1280), (2, 5, 64)])
-def test_backward_row_order_is_a_permutation(B, H, W):
-    """pd_plane_sweep_rowstream.hip: bwd_rows — the rows of the forward's last round first.  Whatever the shape, every row once;
-    where the forward is not dealt (one round, column blocks) the built-in bottom-up order stays (n = 0)."""
-    n, out = _bwd_order(B, 49, H, W)
-    assert n in (0, H)
-    if n:
-        assert sorted(out[:H].tolist()) == list(range(H))
-
-
-def test_backward_starts_on_the_rows_the_forward_served_last():
-    n, out = _bwd_order(8, 49, 192, 640)
-    assert n == 192
-    _, groups, _, _ = _groups(192, 3)
-    first = set(out[:96].tolist())
-    # the forward's last round at B = 8: the 32 row groups without a two-source-row row that come last in its sorted deal —
-    # none of the heavy rows (1..62, 96..125 hold them all) may be among the first 96 rows of the backward
-    heavy_rows = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 19, 21, 22, 24, 25, 27, 28, 30, 31, 33, 36, 39, 42, 45, 48, 51,
-                  54, 56, 59, 62, 96, 101, 102, 107, 108, 112, 113, 118, 119, 124, 125}
-    assert not (first & heavy_rows)
-    assert out[0] == 191 and list(out[:96]) == sorted(out[:96], reverse=True)   # bottom-up within the class
