@@ -590,26 +590,13 @@ static FsShape fwdstream_shape(const pd_sweep_desc* d) {
 // so a disagreement with the device in some last bit would cost balance, not correctness.
 static bool host_row_is_heavy(int y, int H, float row_eps, int* partner = nullptr) {
   if (partner) *partner = -1;
-  volatile float hm1 = (float)(H - 1);
-  volatile float q = (float)y / hm1;
-  volatile float h = q - 0.5f;
-  volatile float g = h * 2.0f;
-  volatile float sv = g + 1.0f;
-  volatile float hh = sv * 0.5f;
-  volatile float iy = hh * hm1;
-  const float yf = floorf(iy);
-  volatile float yf1 = yf + 1.0f;
-  volatile float wy0 = yf1 - iy, wy1 = iy - yf;
-  const bool use0 = yf >= 0.0f && yf <= hm1 && wy0 != 0.0f, use1 = yf1 >= 0.0f && yf1 <= hm1 && wy1 != 0.0f;
-  const int y0 = (int)yf;
-  if (use0 && use1) {
-    const bool two = !(row_eps > 0.0f && fminf(wy0, wy1) < row_eps);
-    if (two && partner) *partner = (y0 == y) ? y0 + 1 : y0;   // the OTHER source row: the main row of that target row
+  const HostRowSel r = host_row_sel(y, H);   // (pd_rowgeom.h)
+  if (r.nrows == 2) {
+    const bool two = !(row_eps > 0.0f && fminf(r.wA, r.wB) < row_eps);
+    if (two && partner) *partner = (r.yA == y) ? r.yB : r.yA;   // the OTHER source row: the main row of that target row
     return two;
   }
-  const float wA = use0 ? wy0 : wy1;
-  const float wmain = (y0 == y) ? wy0 : ((y0 + 1 == y) ? wy1 : 0.0f);
-  return (use0 || use1) && (wA != 1.0f || wmain != 1.0f);
+  return r.nrows == 1 && (r.wA != 1.0f || r.wy_main != 1.0f);
 }
 
 // Row groups that keep a heavy row and the neighbour it blends in together.  A team reads its row's second source row from global

@@ -315,25 +315,11 @@ __device__ __forceinline__ float stream_general_slot(   // (as a call: 123 VGPRs
   return pg.g_l * dlx + pg.g_s * dsx + pg.gc0 * (cb.x - ca.x) + pg.gc1 * (cb.y - ca.y) + pg.gc2 * (cb.z - ca.z);
 }
 
+// Stage target row r.y of image r.b for its workgroup: per-target-pixel context (cell = pixel + 2, zero-gradient guard cells),
+// the (vertically blended) source colour row and, TAIL, the decoder tail's per-source-pixel terms.
 template <bool MIX, int NROWS, bool PK, bool TAIL>
-__device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, const RowSel& row, const StreamLds& L) {
-  constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
-  const int W = a.W, N = a.N, HW = a.H * a.W;
-  StreamRow r;
-  r.y = block_row(bwd_rowid(a.B, a.H), a.H);
-  r.b = wg_image(a.B, a.H);
-  r.yA = row.yA; r.yB = (NROWS == 2) ? row.yB : row.yA;
-  r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
-  r.wy = row.wy_main;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nseg = (W + kSeg - 1) / kSeg;
-  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
-  const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);   // 0: the stores become no-ops
-  const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
-  const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
-
-  // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
+__device__ __forceinline__ void stream_stage_ctx(const SweepArgs& a, const BwdOut& o, const StreamRow& r, const StreamLds& L, int HW) {
+  const int W = a.W;
   const float* srcb = a.src + (long)r.b * 3 * HW;
   for (int cidx = threadIdx.x; cidx < L.CW; cidx += blockDim.x) {
     const int x = cidx - 2;
@@ -368,6 +354,28 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     if (PK) L.colgb[cidx] = make_float2(cc.y, cc.z);
     else L.col[cidx] = cc;
   }
+}
+
+template <bool MIX, int NROWS, bool PK, bool TAIL>
+__device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, int b, int y, const RowSel& row, const StreamLds& L) {
+  constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
+  const int W = a.W, N = a.N, HW = a.H * a.W;
+  StreamRow r;
+  r.y = y;
+  r.b = b;
+  r.yA = row.yA; r.yB = (NROWS == 2) ? row.yB : row.yA;
+  r.wA = row.wA; r.wB = (NROWS == 2) ? row.wB : 0.0f;
+  r.wy = row.wy_main;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + kSeg - 1) / kSeg;
+  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
+  const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);   // 0: the stores become no-ops
+  const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
+  const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
+
+  // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
+  stream_stage_ctx<MIX, NROWS, PK, TAIL>(a, o, r, L, HW);
   if (threadIdx.x == 0) *L.special = 0;
   __syncthreads();
   {
@@ -517,6 +525,10 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   }
 }
 
+#ifdef PD_EXPERIMENTS   // row pairs in the backward (round 6): measured slower; the kernel lives in scripts/experiments/
+#include "pd_rowstream_pairs.inc"
+#endif
+
 // (TAIL: the tail's terms take the kernel from 77 to 93 VGPRs, which costs the third resident workgroup; bounded at six waves per
 // SIMD it keeps it for twelve spilled dwords outside the loop: 0.175 against 0.196 ms, next to 0.174 + 0.208 ms for the two kernels)
 template <bool MIX, bool PK, bool TAIL>
@@ -534,9 +546,10 @@ __global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void r
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
   L.dpl = reinterpret_cast<float*>(L.special + 4);
-  const RowSel row = two_row_form(make_row_sel(block_row(bwd_rowid(a.B, a.H), a.H), a.H), a.row_eps);
-  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, row, L);
-  else                                     stream_body<MIX, 1, PK, TAIL>(a, o, row, L);
+  const int y = block_row(bwd_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
+  const RowSel row = two_row_form(make_row_sel(y, a.H), a.row_eps);
+  if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, b, y, row, L);
+  else                                     stream_body<MIX, 1, PK, TAIL>(a, o, b, y, row, L);
 }
 
 __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, float* __restrict__ out, int R, int M) {
@@ -600,17 +613,42 @@ bool rowstream_bwd_tail_applicable(const pd_sweep_desc* d, const SweepArgs& a) {
          (d->sign == 1.0f || d->sign == -1.0f) && rowstream_shape(d, true).lds <= device_lds_bytes();
 }
 
+#ifdef PD_EXPERIMENTS
+#include "pd_rowstream_pairs_host.inc"
+#else
+static bool rowstream_pairs(const pd_sweep_desc*, const SweepArgs&, bool) { return false; }
+#endif
+
 int rowstream_bwd(const pd_sweep_desc* d, const SweepArgs& a, const BwdOut& o, hipStream_t stream) {
   const bool tail = o.tail_stash != nullptr;
-  const StreamShape sh = rowstream_shape(d, tail);
-  dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
   const bool mix = (d->flags & PD_MIXTURE) != 0;
   int rc;
-  if (tail)     rc = rowstream_launch<true, false, true>(a, o, grid, block, sh.lds, stream);
-  else if (mix) rc = sh.packed ? rowstream_launch<true, true, false>(a, o, grid, block, sh.lds, stream)
-                               : rowstream_launch<true, false, false>(a, o, grid, block, sh.lds, stream);
-  else          rc = sh.packed ? rowstream_launch<false, true, false>(a, o, grid, block, sh.lds, stream)
-                               : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream);
+#ifdef PD_EXPERIMENTS
+  static const bool pairs_on = getenv("PD_BWD_PAIRS") != nullptr;
+#else
+  constexpr bool pairs_on = false;
+#endif
+  if (pairs_on && rowstream_pairs(d, a, tail)) {
+#ifdef PD_EXPERIMENTS
+    const int items = d->N * ceil_div(d->W, kSeg);
+    const int nwaves = items < PD_STREAM_PAIR_WAVES ? items : PD_STREAM_PAIR_WAVES;
+    const dim3 block(nwaves * kWave);
+    const size_t lds = rowstream_pair_lds_bytes(d, nwaves);
+    const StreamUnits& units = rowstream_units(d->H);
+    rc = mix ? rowstream_pair_launch<true>(a, o, units, d->B, block, lds, stream)
+             : rowstream_pair_launch<false>(a, o, units, d->B, block, lds, stream);
+#else
+    rc = PD_ERR_UNSUPPORTED;
+#endif
+  } else {
+    const StreamShape sh = rowstream_shape(d, tail);
+    dim3 grid(d->H, d->B), block(sh.nwaves * kWave);
+    if (tail)     rc = rowstream_launch<true, false, true>(a, o, grid, block, sh.lds, stream);
+    else if (mix) rc = sh.packed ? rowstream_launch<true, true, false>(a, o, grid, block, sh.lds, stream)
+                                 : rowstream_launch<true, false, false>(a, o, grid, block, sh.lds, stream);
+    else          rc = sh.packed ? rowstream_launch<false, true, false>(a, o, grid, block, sh.lds, stream)
+                                 : rowstream_launch<false, false, false>(a, o, grid, block, sh.lds, stream);
+  }
   if (rc) return rc;
   rc = check_launch("rowstream_bwd_kernel");
   if (rc || !o.g_plane || (d->flags & (PD_DISP_ROWS | PD_BWD_PLANE_ZEROED))) return rc;

@@ -382,55 +382,7 @@ __device__ __forceinline__ float rowshift_fwd_rows(const SweepArgs& a, const Row
 //   * y leans on p, p exact            -> y leads unless p-1 also leans on p and y = p+1 (the upper neighbour wins);
 //   * y leans on p, p leans elsewhere  -> y stays a single two-source-row row (a chain; rare).
 // At H = 192: 48 inexact rows -> 26 pairs, 10 left alone (re-reads 25% -> 5% of the rows); H = 384: 94 -> 60 + 14.
-enum PairRole { kSingle = 0, kLeader = 1, kAbsorbed = 2 };
-
-__device__ __forceinline__ int row_lean(int y, int H) {  // 0: exact; +-1: direction of the second source row
-  if (y < 0 || y >= H) return 0;
-  const RowSel r = make_row_sel(y, H);
-  if (r.nrows != 2) return 0;
-  return (r.yA == y) ? +1 : -1;  // rows (y, y+1) or (y-1, y)
-}
-__device__ __forceinline__ bool leads(int y, int H) {  // y is inexact and takes its partner along
-  const int l = row_lean(y, H);
-  if (l == 0) return false;
-  const int p = y + l;
-  const int lp = row_lean(p, H);
-  if (lp == -l) return y < p;                       // mutual
-  if (lp != 0) return false;                        // chain
-  if (l == -1) return row_lean(p - 1, H) != +1;     // p = y-1 is exact: its lower neighbour has the first call on it
-  return true;
-}
-__device__ __forceinline__ PairRole pair_role(int y, int H, int& partner) {
-  partner = y;
-  const int l = row_lean(y, H);
-  if (l != 0) {
-    partner = y + l;
-    if (leads(y, H)) return kLeader;
-    return (row_lean(partner, H) == -l && leads(partner, H)) ? kAbsorbed : kSingle;  // mutual: the other one leads
-  }
-  if (row_lean(y - 1, H) == +1 && leads(y - 1, H)) { partner = y - 1; return kAbsorbed; }
-  if (row_lean(y + 1, H) == -1 && leads(y + 1, H)) { partner = y + 1; return kAbsorbed; }
-  return kSingle;
-}
-
-// Weights of the pair (leader y, partner p) on the two source rows: target y = a0*R_y + b0*R_p, target p = a1*R_p + b1*R_y
-struct PairW {
-  float a0, b0, a1, b1;
-};
-__device__ __forceinline__ PairW pair_weights(int y, int p, int H) {
-  PairW w;
-  const RowSel ry = make_row_sel(y, H), rp = make_row_sel(p, H);
-  w.a0 = (ry.yA == y) ? ry.wA : ry.wB;
-  w.b0 = (ry.yA == y) ? ry.wB : ry.wA;
-  if (rp.nrows == 2) {  // mutual lean
-    w.a1 = (rp.yA == p) ? rp.wA : rp.wB;
-    w.b1 = (rp.yA == p) ? rp.wB : rp.wA;
-  } else {
-    w.a1 = rp.wA;  // exact row: 1
-    w.b1 = 0.0f;
-  }
-  return w;
-}
+// (PairRole, row_lean, leads, pair_role, PairW, pair_weights: pd_rowgeom.h — shared with the row-stream backward)
 
 struct PairPx { float t0, t1, t2, ea; FwdAcc acc; };
 

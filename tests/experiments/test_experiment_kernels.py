@@ -125,3 +125,30 @@ def test_one_kernel_plane_uniform_backward_equals_the_general_kernels(B, N, H, W
     _need_experiments()
     monkeypatch.setenv("PD_UNI_FUSED", "1")
     _uniform_body(B, N, H, W, mix, automask, rot, zoom, "fused", monkeypatch)
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 48, 200), (8, 49, 192, 640), (3, 5, 97, 130), (1, 7, 384, 256)])
+def test_row_pair_backward_equals_the_row_per_workgroup_backward(shape):
+    """Round 6 (NOTEBOOK.md 11.1): the row-stream backward with row pairs (scripts/experiments/pd_rowstream_pairs.inc,
+    PD_BWD_PAIRS=1 on the experiments library) against the product's one-row-per-workgroup kernel, both in one process
+    (scripts/diag_kernel_ab.py --check): the same expressions on the same operands — gradients equal up to the hand-over
+    atomics' order (the waves per workgroup differ), the per-plane disparity gradient up to its summation order."""
+    import os
+    import re
+    import subprocess
+    import sys
+    _need_experiments()
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    exp = os.environ.get("PD_LIB") or os.path.join(root, "planedepth_amd", "lib", "libpd_experiments.so")
+    B, N, H, W = shape
+    env = dict(os.environ, PD_BWD_PAIRS="1")
+    env.pop("PD_LIB", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_kernel_ab.py"), "--check", "--rounds", "1", "--iters", "4",
+                          "--batch", str(B), "--planes", str(N), "--height", str(H), "--width", str(W), "product", "pairs=" + exp],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = next(l for l in out.stdout.splitlines() if l.startswith("check pairs"))
+    got = {k: (float(d), float(r)) for k, d, r in re.findall(r"(\w+) ([0-9.e+-]+) \(of ([0-9.e+-]+)\)", line)}
+    assert got["rgb_rec"][0] == 0 and got["ph_map"][0] == 0, line
+    for k, tol in (("g_logits", 1e-6), ("g_sigma", 1e-6), ("g_plane", 1e-5)):
+        assert got[k][1] > 0 and got[k][0] <= tol * got[k][1], line
