@@ -86,6 +86,7 @@ def parse():
                     help="stand-in depth network of the ddp_step block: ResNet-18-shaped (59.6 MB of gradients, BASELINE configs[1]) "
                          "or ResNet-50 + dense-ASPP-shaped (156.6 MB, configs[2])")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--windows", type=int, default=7, help="further timed windows of --steps steps after the one `value` reports (spread)")
     return ap.parse_args()
 
 
@@ -742,34 +743,50 @@ def cpu_baseline(args, budget_s):
     case = survey_fullsize_case(B=1, N=args.planes, H=args.height, W=args.width)
     run = dict(warp_type=args.warp_type, use_mixture_loss=not args.no_mixture, automask=args.automask)
     torch_sampler = lambda f, g, pm: F.grid_sample(f, g, mode="bilinear", padding_mode=pm, align_corners=True)  # noqa: E731
-    # torch's intra-op pool degrades badly when oversubscribed (256 threads: 36 s / image); pick the better of two
-    # sane thread counts with one probe iteration each, then time the sample at that setting.
-    best = None
-    for th in sorted({min(8, ncpu), min(32, ncpu)}):
+
+    def one(sampler=torch_sampler):
+        tm = {}
+        run_oracle(case, run, sampler=sampler, timing=tm)
+        return tm["fwd_s"], tm["fwd_bwd_s"]
+
+    # Thread count.  SURVEY 8d asks for os.cpu_count() threads; torch's intra-op pool degrades badly when oversubscribed on the
+    # pool's shared hosts (256 threads: 36 s / image), so the sample runs at the best of {8, 32, every core when there are at
+    # most 64} — one warm-up + one probe each — and the line states the host's core count AND the threads used.
+    probes = {}
+    for th in sorted({min(8, ncpu), min(32, ncpu)} | ({ncpu} if ncpu <= 64 else set())):
         torch.set_num_threads(th)
-        run_oracle(case, run, sampler=torch_sampler)  # warm-up at this setting
-        t0 = time.perf_counter()
-        run_oracle(case, run, sampler=torch_sampler)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (th, dt)
-    cores = best[0]
-    torch.set_num_threads(cores)
-    times = []
+        one()   # warm-up at this setting
+        probes[th] = one()[1]
+    threads = min(probes, key=probes.get)
+    torch.set_num_threads(threads)
+    fwd, both = [], []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 9 and (time.perf_counter() < t_end or len(times) < 2):
-        t0 = time.perf_counter()
-        run_oracle(case, run, sampler=torch_sampler)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+    while len(both) < 9 and (time.perf_counter() < t_end or len(both) < 5):
+        f, fb = one()
+        fwd.append(f); both.append(fb)
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
     t0 = time.perf_counter()
     run_oracle(case, run)   # the restated sampler, once (warm pool): the second figure
     restated = time.perf_counter() - t0
-    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    # one thread: one warm-up + up to three runs inside a budget of its own
+    torch.set_num_threads(1)
+    one()
+    f1, fb1 = [], []
+    t_end = time.perf_counter() + max(6.0, budget_s / 2)
+    while len(fb1) < 3 and (time.perf_counter() < t_end or not fb1):
+        f, fb = one()
+        f1.append(f); fb1.append(fb)
+    torch.set_num_threads(threads)
+    return {"value": round(1.0 / med(both), 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "host_cores": ncpu, "threads": threads,
+            "thread_probe_ms": {str(k): round(v * 1e3, 1) for k, v in sorted(probes.items())},
             "sample": "oracle (torch CPU restatement of trainer.py:523-603,717-742, sampling through F.grid_sample as the "
-                      "reference does) fwd+bwd, B=1, N=%d, %dx%d, median of %d" % (args.planes, args.height, args.width, len(times)),
-            "ms_per_image": round(med * 1e3, 2),
+                      "reference does) B=1, N=%d, %dx%d, one warm-up + median of %d at %d threads of %d host cores; value = fwd+bwd"
+                      % (args.planes, args.height, args.width, len(both), threads, ncpu),
+            "fwd_ms": round(med(fwd) * 1e3, 2), "fwd_bwd_ms": round(med(both) * 1e3, 2),
+            "ms_per_image": round(med(both) * 1e3, 2),
+            "one_thread": {"value": round(1.0 / med(fb1), 4), "fwd_ms": round(med(f1) * 1e3, 1), "fwd_bwd_ms": round(med(fb1) * 1e3, 1),
+                           "runs": len(fb1)},
             "restated_sampler": {"value": round(1.0 / restated, 4), "ms_per_image": round(restated * 1e3, 2),
                                  "what": "same pass with the oracle's gather-based bilinear_sample instead of F.grid_sample, one run"}}
 
@@ -816,6 +833,11 @@ def main():
     import __graft_entry__ as entry
     entry.build()
 
+    from planedepth_amd import _capi as _C0
+    build_flags = int(_C0.load().pd_build_flags())
+    if build_flags & 2:
+        raise SystemExit("bench.py: the library was built with -DPD_DIAGNOSTICS (timing ablations: wrong results by design); "
+                         "its timings are not a benchmark")
     c = make_batch(args, device, seed=rank)  # every rank draws its own shard: no data-path collective
     step, _ = build_step(args, c, device)
     eager_step = step
@@ -903,6 +925,18 @@ def main():
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
 
     value = parallel.throughput(args.batch, args.steps, world, elapsed)   # images (not image-views) per second
+    # Spread: `value` above is the contract's window; the same K steps are timed again --windows times, each
+    # window bracketed the same way (barrier + synchronize, max over ranks), so the line shows how far one 5 ms window is from
+    # the next on THIS box.  The device-to-device copy rate is taken before and after as the box's own yardstick.
+    window_rates = []
+    for _ in range(max(0, args.windows)):
+        parallel.barrier(device)
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        parallel.barrier(device)
+        window_rates.append(parallel.throughput(args.batch, args.steps, world, parallel.max_over_ranks(time.perf_counter() - tw, device)))
+    hbm_copy_after = measured_copy_rate(device) if "copy" not in args.skip_context else None
     result = {
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -910,7 +944,11 @@ def main():
         "launch": "HIP graph replay of one captured step" if used_graph else "eager (one host launch per kernel)",
         "launch_policy": args.launch, "launch_probe": launch_probe,
         "pre_timed_steps": pre_timed,
-        "library": dict(entry.BUILD_INFO),   # "built" here from source, or "reused" (the travelling .so matches this source hash)
+        "windows": ({"n": len(window_rates), "steps_each": args.steps, "median": round(sorted(window_rates)[len(window_rates) // 2], 1),
+                     "min": round(min(window_rates), 1), "max": round(max(window_rates), 1),
+                     "what": "further timed windows of the same length, run right after the window `value` reports (images/sec; "
+                             "not part of `value`)"} if window_rates else None),
+        "library": dict(entry.BUILD_INFO, build_flags=build_flags),   # "built" here from source, or "reused" (the travelling .so matches this source hash); build_flags 0 = no experiments, no timing ablations compiled in
         "known_deviation": "row kernels' backward (row-stream by default, row-shift under PD_IMPL_ROWS1): the adjoint drops the "
                            "eps-weighted (eps <= 8e-6) term of the neighbouring source row on rows whose y round trip is "
                            "inexact; bounded at 3e-5 of the gradients' range against the general kernels (tests: "
@@ -944,6 +982,7 @@ def main():
     if rank == 0:
         if "copy" not in args.skip_context:
             result["hbm_copy_measured"] = hbm_copy
+            result["hbm_copy_measured_after"] = hbm_copy_after
         if kt:
             fwd_b, bwd_b = algorithmic_bytes(args)
             dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"

@@ -17,8 +17,8 @@
  *     device (hipSetDevice / torch.cuda.device by the caller) and keep nothing between calls except per-device caches of
  *     device facts — the LDS a workgroup can be given, the dynamic-LDS limit already granted to a kernel — held in
  *     atomics indexed by the device ordinal (the rare raise is serialised by a mutex).  The few process-environment
- *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS) are read ONCE, when the library is first
- *     used, never on the launch path; kernel selection per call goes through pd_sweep_desc.impl.
+ *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS, PD_FWD_STREAM, PD_ROW_EPS) are read ONCE, when
+ *     the library is first used, never on the launch path; kernel selection per call goes through pd_sweep_desc.impl.
  */
 #ifndef PLANEDEPTH_HIP_H
 #define PLANEDEPTH_HIP_H
@@ -148,6 +148,11 @@ const char* pd_source_hash(void);
  * row kernels, owned-tile backward, one-kernel plane-uniform backward; NOTEBOOK.md 3.5) are then compiled in and selectable
  * (PD_IMPL_TILE; PD_QUAD_FWD / PD_QUAD_BWD / PD_UNI_FUSED in the environment).  The product library returns 0. */
 int pd_experiments(void);
+/* What else this binary was compiled with, as bits: 1 = -DPD_EXPERIMENTS (as pd_experiments()); 2 = -DPD_DIAGNOSTICS — a
+ * timing-ablation or trace build of the headline kernels (PD_FS_ABL, PD_STREAM_ABL, PD_ABLATE, PD_FS_TRACE, ...: parts of the
+ * arithmetic or of the memory traffic compiled OUT, results WRONG by design; those switches refuse to compile without
+ * -DPD_DIAGNOSTICS).  The product library returns 0; tests/test_capi.py and bench.py's `library` block check it. */
+int pd_build_flags(void);
 
 /* 1 if pd_plane_sweep_bwd adds into a pre-zeroed g_plane under PD_BWD_PLANE_ZEROED for this descriptor (see the flag; a
  * per-pixel padding mask sends the call to a kernel that overwrites instead), else 0. */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
     "pd_selftest_division": (_I, [_F, _I, _F, _F, _P, _P]),
     "pd_experiments": (_I, []),
+    "pd_build_flags": (_I, []),
     "pd_debug_gather_flags": (_I, [_D, _P, _P, _P]),
     "pd_debug_poison_lds": (_I, [_P]),
     "pd_debug_count_lds_nans": (_I, [_P, _P]),

@@ -84,6 +84,11 @@ namespace pd {
 #define PD_FS_ROWS 3   // consecutive target rows per workgroup where its 16 waves allow (each row: one wave per segment).  Measured
 #endif                 // at 8x49x192x640, isolated / in the step: 1 row 0.114 / 0.128 ms, 2 rows 0.119 / 0.131, 3 rows 0.104 / 0.122
                        // — 15 waves that read three adjacent rows (7.5 KB) of every plane at about the same time
+#ifndef PD_DIAGNOSTICS   // timing-ablation / trace code (results wrong by design) compiles only into a library that says so: pd_build_flags()
+#if PD_FS_ABL || PD_FS_TRACE || PD_FS_LDS_PAD
+#error "timing-ablation / trace switches need -DPD_DIAGNOSTICS as well (pd_build_flags() then reports the build)"
+#endif
+#endif
 constexpr float kFixRefLimit = 90.0f;  // PD_FS_FIXREF: largest base-2 exponent of a softmax term before the wave falls back
 constexpr int kFsSeg = 2 * kWave;      // target pixels per wave
 constexpr int kFsGuard = 4;            // zero cells on each side of the colour row

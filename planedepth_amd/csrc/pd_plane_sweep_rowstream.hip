@@ -50,6 +50,11 @@ namespace pd {
 #ifndef PD_STREAM_ABL
 #define PD_STREAM_ABL 0  // timing experiments only (wrong results): 1 no context reads, 2 no per-plane gradient math,
 #endif                   // 4 every row as one source row, 8 no gradient stores, 16 no coordinate chain
+#ifndef PD_DIAGNOSTICS   // timing-ablation / trace code (results wrong by design) compiles only into a library that says so: pd_build_flags()
+#if PD_STREAM_ABL
+#error "timing-ablation / trace switches need -DPD_DIAGNOSTICS as well (pd_build_flags() then reports the build)"
+#endif
+#endif
 constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_STORE_AUX
 #define PD_STREAM_STORE_AUX 2   // cache-policy bits of the gradient stores (1 = sc0, 2 = nt, 16 = sc1; 0 = write-back).  nt: the

@@ -11,6 +11,11 @@ namespace pd {
 #ifndef PD_ABLATE
 #define PD_ABLATE 0
 #endif
+#ifndef PD_DIAGNOSTICS   // timing-ablation / trace code (results wrong by design) compiles only into a library that says so: pd_build_flags()
+#if PD_ABLATE
+#error "timing-ablation / trace switches need -DPD_DIAGNOSTICS as well (pd_build_flags() then reports the build)"
+#endif
+#endif
 constexpr int kAblate = PD_ABLATE;
 
 constexpr int kStashBase = 4;  // lse, S, Mx, flags  (then ceil(N/32) mask words in disp mode)

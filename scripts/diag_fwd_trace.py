@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of the segment-stream forward (VERDICT r4 #1b): a -DPD_FS_TRACE=1 build stamps s_memtime per wave
+"""Per-workgroup timeline of the segment-stream forward (VERDICT r4 #1b): a -DPD_DIAGNOSTICS -DPD_FS_TRACE=1 build stamps s_memtime per wave
 at entry / after the staging barrier / after the plane loop / at exit, plus HW_ID and XCC_ID; this script launches the
 forward at the headline shape, reads the stamps back and reports
   * the histogram of workgroup durations (exit of the last wave - entry of the first), split by how many of the

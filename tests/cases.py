@@ -21,8 +21,11 @@ def load_fixture(name):
     return inp, out, meta["run"]
 
 
-def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
-    """Mirror of make_golden.run_reference, but through the oracle.  Returns the same keys."""
+def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample, timing=None):
+    """Mirror of make_golden.run_reference, but through the oracle.  Returns the same keys.  `timing` (a dict) receives
+    `fwd_s` (inputs -> loss, autograd recording as in training) and `fwd_bwd_s` (.. -> gradients): bench.py's cpu_baseline."""
+    import time
+    t_start = time.perf_counter()
     c = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in case.items()}
     B, N, H, W = c["logits"].shape
     leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
@@ -40,7 +43,12 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample):
                           T=Rt, K=c["K"], inv_K=c["inv_K"], use_mixture_loss=mix, automask=run.get("automask", False),
                           mask_novel=c.get("mask_novel"), render_probability=run.get("render_probability", False),
                           dists=dists, sampler=sampler)
-    (r["ph_loss"] + (r["rgb_rec"] * c["g_rgb_rec"]).sum()).backward()
+    objective = r["ph_loss"] + (r["rgb_rec"] * c["g_rgb_rec"]).sum()
+    if timing is not None:
+        timing["fwd_s"] = time.perf_counter() - t_start
+    objective.backward()
+    if timing is not None:
+        timing["fwd_bwd_s"] = time.perf_counter() - t_start
     z = torch.zeros_like
     res = dict(rgb_rec=r["rgb_rec"], ph_loss=r["ph_loss"], ph_map=r["ph_map"],
                rgb_rec_layered=r["sweep"]["rgb_rec_layered"], logit_rec=r["sweep"]["logit_rec"],

@@ -31,6 +31,13 @@ def test_library_exports_every_declared_symbol():
     major, minor, patch = (int(v) for v in planedepth_amd.__version__.split("."))
     assert lib.pd_version() == major * 1000 + minor * 100 + patch * 10, (lib.pd_version(), planedepth_amd.__version__)
     assert lib.pd_experiments() in (0, 1)
+    # the library the suite runs against carries no timing-ablation / trace code (built with -DPD_DIAGNOSTICS: parts of the
+    # kernels compiled out, results wrong by design) and, unless PD_LIB points at the experiments library, no experiments
+    flags = lib.pd_build_flags()
+    assert not flags & 2, "this library was built with -DPD_DIAGNOSTICS (timing ablations / traces): not a product build"
+    assert (flags & 1) == lib.pd_experiments()
+    if not os.environ.get("PD_LIB"):
+        assert flags == 0, flags
 
 
 def test_desc_layout_and_host_queries():
@@ -177,3 +184,21 @@ def test_first_column_hands_the_decoder_the_row_gradient_without_a_dense_zero_fi
     out = ops._FirstColumn.apply(probe)
     gin, = torch.autograd.grad(out.sum(), probe)
     assert gin.stride(-1) == 0     # nothing [B,N,H,W]-sized was written
+
+
+@pytest.mark.parametrize("src,flag", [("pd_plane_sweep_rowstream.hip", "-DPD_STREAM_ABL=8"), ("pd_plane_sweep_fwdstream.hip", "-DPD_FS_ABL=64"),
+                                      ("pd_plane_sweep_fwdstream.hip", "-DPD_FS_TRACE=1"), ("pd_plane_sweep_rowshift.hip", "-DPD_ABLATE=1")])
+def test_timing_ablation_switches_refuse_to_compile_without_the_diagnostics_flag(src, flag):
+    """the timing ablations of the headline kernels (parts of the arithmetic or traffic compiled out: wrong results
+    by design) can only be built into a library that reports it (pd_build_flags() & 2, which this suite and bench.py reject)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    cmd = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "planedepth_amd", "csrc"),
+           "--cuda-host-only", "-fsyntax-only", flag, os.path.join(ROOT, "planedepth_amd", "csrc", src)]
+    bad = subprocess.run(cmd, capture_output=True, text=True)
+    assert bad.returncode != 0 and "need -DPD_DIAGNOSTICS" in bad.stderr, bad.stderr[-500:]
+    good = subprocess.run(cmd + ["-DPD_DIAGNOSTICS"], capture_output=True, text=True)
+    assert good.returncode == 0, good.stderr[-500:]
