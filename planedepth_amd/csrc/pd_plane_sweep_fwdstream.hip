@@ -419,6 +419,9 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
                                              rcpWm1, t, ea, automask, acc, rs, g[0].dist);
     }
   }
+#if PD_FS_PRIO == 1
+  __builtin_amdgcn_s_setprio(0);   // (the rotating priority of the plane loop ends with it)
+#endif
   fs_stamp(2);
   if (!live) return 0.0f;
   // ---- finish the two pixels: outputs + the backward's stash, 8-byte stores -------------------------------------------
@@ -442,6 +445,10 @@ __device__ __forceinline__ float fwdstream_body(const SweepArgs& a, const RowSel
 // slowest wave of the slowest row): an LDS counter per slot that every wave bumps once per round after its share of the
 // staging, and polls until the whole team has.  LDS operations of a wave retire in order, so the bump follows the wave's
 // staging stores; the fences keep the compiler from moving LDS accesses across.
+// INVARIANT: every wave of a team runs the round loop of fwdstream_kernel the same number of times and reaches this barrier
+// in every round — the loop's only exits (`pos >= T`) are workgroup-uniform.  A per-wave early exit or `continue` before the
+// barrier would leave the team's other waves polling for ever, with no diagnostic (PD_FS_ROUNDS=1 builds, one item per
+// workgroup and a plain __syncthreads, are the fallback).
 __device__ __forceinline__ void fs_team_barrier(int* cnt, int target) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

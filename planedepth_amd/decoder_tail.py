@@ -80,7 +80,8 @@ def fused_decoder_tail(outputs, dispconv_out, sigmaconv_out=None, *, use_mixture
     ``["sigma"]`` are consumed — as far as gradients go — by the trainer's plane sweep alone.  The sweep's backward kernel
     then applies this tail's backward on the values it holds anyway and writes the conv outputs' gradients directly
     (``ops.TailLink``, ``pd_plane_sweep_bwd_tail``); the tail's own backward kernel, which re-reads the [B,N,H,W]-sized
-    gradients the sweep has just written, no longer runs."""
+    gradients the sweep has just written, no longer runs.  NOT detected: another differentiable consumer of ``outputs["sigma"]``
+    (a regulariser) — its gradient would be added, in sigma space, to one already in conv-output space; keep the flag off then."""
     mask = None if all_ones_mask else outputs["padding_mask"]
     logits, sigma, disp, depth, layers = ops.decoder_tail(dispconv_out, sigmaconv_out, mask, outputs["disp_layered"],
                                                           use_mixture_loss=use_mixture_loss,

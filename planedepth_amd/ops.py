@@ -126,7 +126,10 @@ def _plane_grad_buffer(plane, mode, flags):
     """(g_plane buffer, extra descriptor flags) for a backward call that wants the plane-parameter gradient: one disparity
     per plane gets a pre-zeroed [B, N] block and PD_BWD_PLANE_ZEROED (the row-stream backward then adds its rows' shares
     there and launches no reduction kernel; the other kernels overwrite it as ever)."""
-    if PLANE_ADDS and mode == C.PD_WARP_DISP and not flags & (C.PD_DISP_DENSE | C.PD_DISP_ROWS):
+    # (float atomics: the sum's last bits depend on the order of the adds — under torch.use_deterministic_algorithms(True) the
+    # deterministic partial sums + reduction launch are used instead)
+    if (PLANE_ADDS and not torch.are_deterministic_algorithms_enabled() and mode == C.PD_WARP_DISP
+            and not flags & (C.PD_DISP_DENSE | C.PD_DISP_ROWS)):
         return _zero_block(plane.device, tuple(plane.shape)), C.PD_BWD_PLANE_ZEROED
     return torch.empty_like(plane), 0
 
@@ -323,7 +326,7 @@ def _sweep_backward_tail(saved, cfg, grads, need, link):
     B, N, H, W = logits.shape
     g_plane, plane_flag = _plane_grad_buffer(plane, mode, flags) if need[2] else (None, 0)
     d = _desc(B, N, H, W, mode, flags | plane_flag, sign)
-    g_disp, g_depth = link.seen.get("disp"), link.seen.get("depth")
+    g_disp, g_depth = link.seen.pop("disp", None), link.seen.pop("depth", None)   # (taken: state of THIS backward pass only)
     gl, gs = torch.empty_like(logits), torch.empty_like(sigma)
     ws = torch.empty(max(int(lib.pd_sweep_bwd_workspace_floats(ctypes.byref(d))), 1), device=logits.device, dtype=torch.float32)
     g_rgb_rec, g_ph_map, gd, gz = map(_contig, (g_rgb_rec, g_ph_map, g_disp, g_depth))
@@ -335,7 +338,8 @@ def _sweep_backward_tail(saved, cfg, grads, need, link):
                                          C.ptr(link.raw_sigma), C.ptr(link.stash), C.ptr(link.disp), C.ptr(gd), C.ptr(gz),
                                          C.ptr(gl), C.ptr(gs), C.ptr(g_plane), C.ptr(ws), C.stream_handle(logits.device))
     C.check(rc, "pd_plane_sweep_bwd_tail")
-    link.applied = {"disp": g_disp, "depth": g_depth}
+    link.applied = {"disp": g_disp, "depth": g_depth}   # until the tail's node of this pass has consumed it
+    link.fused_passes += 1
     return gl, gs, g_plane
 
 
@@ -371,8 +375,11 @@ class TailLink:
     def __init__(self, raw_sigma, stash, disp):
         self.raw_sigma, self.stash, self.disp = raw_sigma, stash, disp
         self.consumers = 0        # sweeps that registered as consumers of this tail's logits / sigma
-        self.seen = {}            # "disp" / "depth" -> gradient handed over by its tap
-        self.applied = None       # {"disp": g or None, "depth": g or None} once a sweep's backward has applied the tail's terms
+        self.seen = {}            # "disp" / "depth" -> gradient handed over by its tap (taken by the sweep's backward of the pass)
+        self.applied = None       # {"disp": g or None, "depth": g or None}: a sweep's backward has applied the tail's terms in THIS
+                                  # backward pass; the tail's node consumes it and resets it — a second pass over a retained graph
+                                  # (retain_graph=True, a second torch.autograd.grad) starts clean
+        self.fused_passes = 0     # backward passes in which the sweep's kernel applied the tail's backward (diagnostics / tests)
 
 
 class _GradTap(torch.autograd.Function):
@@ -425,7 +432,7 @@ class _PlaneSweep(torch.autograd.Function):
     def backward(ctx, g_rgb_rec, g_ph_map, g_ph_mean):
         need = (ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[8])
         link = ctx.link
-        if link is not None and link.consumers == 1 and link.applied is None and need[0] and need[1]:
+        if link is not None and link.consumers == 1 and need[0] and need[1]:
             g_logits, g_sigma, g_plane = _sweep_backward_tail(ctx.saved_tensors, ctx.cfg, (g_rgb_rec, g_ph_map, g_ph_mean),
                                                               need, link)
             return None, None, g_logits, g_sigma, g_plane, None, None, None, None, None, None, None, None
@@ -1298,7 +1305,11 @@ class _DecoderTail(torch.autograd.Function):
             return None, None, None, None, None, None
         link = ctx.link
         extra = None
-        if link is not None and link.applied is not None:
+        applied = None
+        if link is not None:
+            applied, link.applied = link.applied, None   # per-pass state: consumed here (a second backward over the graph)
+            link.seen.clear()
+        if applied is not None:
             # the sweep's backward kernel applied this node's backward already (pd_plane_sweep_bwd_tail): g_logits / g_sigma ARE
             # the conv outputs' gradients, the disparity share went into the sweep's g_plane.  Only an upstream gradient of
             # disp / depth that the sweep did not see is still owed: the plain kernel on that remainder alone, added on top.
@@ -1310,7 +1321,7 @@ class _DecoderTail(torch.autograd.Function):
                 if got.data_ptr() == used.data_ptr() and got.shape == used.shape:
                     return None
                 return got - used
-            r_disp, r_depth = rest(g_disp, link.applied["disp"]), rest(g_depth, link.applied["depth"])
+            r_disp, r_depth = rest(g_disp, applied["disp"]), rest(g_depth, applied["depth"])
             if r_disp is None and r_depth is None:
                 return (g_logits if need_l else None), (g_sigma if need_s else None), None, None, None, None
             extra = (g_logits, g_sigma)
@@ -1356,7 +1367,11 @@ def decoder_tail(raw_logits, raw_sigma, padding_mask, disp_layered, use_mixture_
         if tuple(padding_mask.shape) != (B, N, H, W):
             padding_mask = padding_mask.expand(B, N, H, W)
     # fuse_sweep_backward: the caller's promise that logits / sigma feed (with gradient) exactly ONE plane sweep — the trainer's
-    # single-view pred_novel_images — whose backward kernel then applies this tail's backward too (TailLink)
+    # single-view pred_novel_images — whose backward kernel then applies this tail's backward too (TailLink).  Sweeps are
+    # counted (a second one, or one the fused form does not serve, switches the fusion off); any OTHER differentiable consumer
+    # of ``sigma`` (a regulariser on outputs["sigma"]) is NOT detected: its gradient would arrive in sigma space on top of one
+    # the sweep already wrote in conv-output space, without the sigmoid' factor and the clamp gate.  (``logits`` are safe:
+    # d logits / d raw_logits is the identity here.)  Leave the flag off for such a graph.
     link = TailLink(None, None, None) if (fuse_sweep_backward and use_mixture_loss and padding_mask is None and per_plane
                                            and torch.is_grad_enabled()) else None
     logits, sigma, disp, depth, stash = _DecoderTail.apply(raw_logits, raw_sigma if use_mixture_loss else None, plane,

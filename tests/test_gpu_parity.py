@@ -1054,7 +1054,7 @@ def test_sweep_backward_applies_the_fused_decoder_tail(case):
             ops.KERNEL_EVENTS = None
         assert (link is not None) == fuse
         if fuse:
-            assert link.applied is not None and link.applied["disp"] is not None and link.applied["depth"] is not None
+            assert link.fused_passes == 1 and link.applied is None and not link.seen   # applied by the sweep, consumed by the tail's node
             assert tail_launches == 0, "the tail's own backward kernel ran although the sweep applied it"
         else:
             assert tail_launches == 1
@@ -1108,6 +1108,48 @@ def test_fused_decoder_tail_stays_correct_when_disp_is_consumed_before_the_taps(
         res.append([t.grad.cpu() for t in (a, s, d)])
     for x, y in zip(*res):
         assert rel_err(y, x) < 5e-6, rel_err(y, x)
+
+
+def test_fused_decoder_tail_survives_a_second_backward_over_the_same_graph():
+    """what the sweep's backward leaves with the TailLink (the taps' gradients, "the tail's terms are applied") is
+    state of ONE backward pass.  With retain_graph=True the graph is walked again — both passes must give the unfused graph's
+    gradients (accumulated: twice the single pass), and a torch.autograd.grad over the retained graph likewise."""
+    import types
+    from gpu_cases import make_stub_trainer
+    from planedepth_amd.decoder_tail import fused_decoder_tail
+    from planedepth_amd.synthetic import intrinsics
+    g = torch.Generator().manual_seed(12)
+    B, N, H, W = 2, 5, 8, 128
+    rl, rs = torch.randn(B, N, H, W, generator=g) * 2, torch.randn(B, N, H, W, generator=g) * 2
+    lv = 40.0 * (2.0 / 40.0) ** (torch.arange(N, dtype=torch.float32)[None, :, None, None] / (N - 1)).repeat(B, 1, 1, 1)
+    cl, ct, w = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    K, inv_K = intrinsics(B, H, W)
+    res = {}
+    for fuse in (False, True):
+        a, s, d = (t.cuda().clone().requires_grad_(True) for t in (rl, rs, lv))
+        outputs = {"disp_layered": d.expand(-1, -1, H, W), "padding_mask": None}
+        fused_decoder_tail(outputs, a, s, use_mixture_loss=True, all_ones_mask=True, fuse_sweep_backward=fuse)
+        opt = types.SimpleNamespace(warp_type="disp_warp", match_aug=False, use_mixture_loss=True, automask=False,
+                                    render_probability=False, alpha_pc=0.0, alpha_self=0.0, self_distillation=0.0,
+                                    gamma_smooth=2.0, alpha_smooth=0.0, use_ssim=False, xz_levels=0, yz_levels=0)
+        trainer = make_stub_trainer(opt, ["r"])
+        trainer.pred_novel_images({("color", "l"): cl.cuda(), ("color", "r"): ct.cuda(), "K": K.cuda(), "inv_K": inv_K.cuda()}, outputs)
+        obj = outputs[("ph_mean", "r")] + (outputs["disp"] * w.cuda()).sum() + (outputs["depth"] * 1e-2 * w.cuda()).sum()
+        obj.backward(retain_graph=True)
+        first = [t.grad.clone() for t in (a, s, d)]
+        again = torch.autograd.grad(obj, (a, s, d), retain_graph=True)
+        obj.backward()
+        res[fuse] = dict(first=[t.cpu() for t in first], again=[t.cpu() for t in again], accumulated=[t.grad.cpu() for t in (a, s, d)])
+        link = getattr(outputs["logits"], "_pd_tail_link", None)
+        if fuse:
+            assert link.fused_passes == 3 and link.applied is None and not link.seen
+    for k in ("first", "again", "accumulated"):
+        for x, y in zip(res[False][k], res[True][k]):
+            assert rel_err(y, x) < 5e-6, (k, rel_err(y, x))
+    for x, y in zip(res[True]["first"], res[True]["again"]):
+        assert rel_err(y, x) < 2e-6, rel_err(y, x)       # (the per-plane disparity gradient is a float-atomic sum)
+    for x, y in zip(res[True]["first"], res[True]["accumulated"]):
+        assert rel_err(y, 2 * x) < 2e-6, rel_err(y, 2 * x)
 
 
 def test_smooth_loss_against_reference_vector_and_oracle():
