@@ -21,9 +21,11 @@ def load_fixture(name):
     return inp, out, meta["run"]
 
 
-def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample, timing=None):
+def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample, timing=None, H_t2s=None):
     """Mirror of make_golden.run_reference, but through the oracle.  Returns the same keys.  `timing` (a dict) receives
-    `fwd_s` (inputs -> loss, autograd recording as in training) and `fwd_bwd_s` (.. -> gradients): bench.py's cpu_baseline."""
+    `fwd_s` (inputs -> loss, autograd recording as in training) and `fwd_bwd_s` (.. -> gradients): bench.py's cpu_baseline.
+    `H_t2s` [B*N,3,3] pins homography_warp's matrices (the reference-captured ones of the fixtures: no gradient to distance / Rt
+    then)."""
     import time
     t_start = time.perf_counter()
     c = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in case.items()}
@@ -42,7 +44,7 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample, timi
                           disp_layered=disp_layered, padding_mask=c["padding_mask"], distance=distance, norm=norm,
                           T=Rt, K=c["K"], inv_K=c["inv_K"], use_mixture_loss=mix, automask=run.get("automask", False),
                           mask_novel=c.get("mask_novel"), render_probability=run.get("render_probability", False),
-                          dists=dists, sampler=sampler)
+                          dists=dists, sampler=sampler, H_t2s=None if H_t2s is None else H_t2s.to(dtype))
     objective = r["ph_loss"] + (r["rgb_rec"] * c["g_rgb_rec"]).sum()
     if timing is not None:
         timing["fwd_s"] = time.perf_counter() - t_start
@@ -58,6 +60,9 @@ def run_oracle(case, run, dtype=torch.float32, sampler=orc.bilinear_sample, timi
                g_Rt=Rt.grad if Rt.grad is not None else z(Rt))
     if dists is not None:
         res["g_dists"] = dists.grad if dists.grad is not None else z(dists)
+    if run.get("warp_type", "disp_warp") == "homography_warp":   # the matrices this evaluation formed itself (layers.py:206-219)
+        ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
+        res["H_t2s"] = orc.homography_matrices(distance, norm, ex(Rt), ex(c["K"]), ex(c["inv_K"]))[0]
     if mix:
         res["sigma_rec"] = r["sweep"]["sigma_rec"]
         res["pi_rec"] = r["sweep"]["pi_rec"]
@@ -118,7 +123,7 @@ def side_key(s):
     return s if isinstance(s, str) else int(s)
 
 
-def run_oracle_trainer(z, meta, dtype=torch.float32):
+def run_oracle_trainer(z, meta, dtype=torch.float32, pin_matrices=False):
     """pred_novel_images + compute_losses over every target side, restated with the oracle's building blocks
     (trainer.py:532, 717, 765-771: the loss dict is divided by len(target_sides) BEFORE the smoothness term)."""
     c = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in z.items()}
@@ -135,7 +140,8 @@ def run_oracle_trainer(z, meta, dtype=torch.float32):
         r = orc.warp_and_loss(c["color_l"], c["color_%s" % s], logits, sigma,
                               warp_type=meta["warp_type"], target_side=s, disp_layered=disp_layered,
                               padding_mask=c["padding_mask"], distance=distance, norm=c["norm"], T=Rts[s], K=c["K"],
-                              inv_K=c["inv_K"], use_mixture_loss=mix, automask=meta["automask"])
+                              inv_K=c["inv_K"], use_mixture_loss=mix, automask=meta["automask"],
+                              H_t2s=c["H_t2s_%s" % s] if (pin_matrices and homo) else None)   # the reference's own matrices
         res["rgb_rec_%s" % s] = r["rgb_rec"]
         ph_total = ph_total + r["ph_loss"]
         total = total + r["ph_loss"] + (r["rgb_rec"] * c["gw_%s" % s]).sum() * len(sides)  # the test objective adds it undivided

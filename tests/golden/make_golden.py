@@ -28,6 +28,28 @@ from ref_import import load_reference, make_trainer_namespace  # noqa: E402
 from planedepth_amd.synthetic import build_case, intrinsics, small_pose, survey_fullsize_case  # noqa: E402,F401
 
 
+class record_inverse:
+    """Context manager: every matrix ``torch.inverse`` returns while it is active, in call order.  The reference forms
+    ``H_t2s = torch.inverse(H_s2t)`` inside ``HomographyWarp.forward`` (layers.py:219) and nowhere else on the path, so what
+    is recorded around ``Trainer.pred_novel_images`` is the H_t2s THE REFERENCE COMPUTED, one [B*N,3,3] block per target side —
+    stored in the fixtures so that the HIP kernels can be held to 1e-4 against the reference's outputs on the reference's own
+    matrices (an fp32 inverse at cond 1e3-1e4 differs between LAPACK, rocSOLVER and a hand-written adjugate by more than that)."""
+
+    def __enter__(self):
+        self.got, self._orig = [], torch.inverse
+
+        def spy(x, *a, **k):
+            r = self._orig(x, *a, **k)
+            self.got.append(r.detach().clone())
+            return r
+        torch.inverse = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.inverse = self._orig
+        return False
+
+
 def run_reference(ref, case, *, warp_type="disp_warp", target_side="r", use_mixture_loss=True, automask=False,
                   render_probability=False):
     B, N, H, W = case["logits"].shape
@@ -52,7 +74,8 @@ def run_reference(ref, case, *, warp_type="disp_warp", target_side="r", use_mixt
     ns = make_trainer_namespace(ref, H, W, warp_type=warp_type, use_mixture_loss=use_mixture_loss, automask=automask,
                                 render_probability=render_probability, target_sides=[target_side])
     Trainer = ref.trainer.Trainer
-    Trainer.pred_novel_images(ns, inputs, outputs)
+    with record_inverse() as rec:
+        Trainer.pred_novel_images(ns, inputs, outputs)
     losses = Trainer.compute_losses(ns, inputs, outputs)
     rgb_rec = outputs[("rgb_rec", target_side)]
     objective = losses["loss/ph_loss"] + (rgb_rec * case["g_rgb_rec"]).sum()
@@ -69,6 +92,9 @@ def run_reference(ref, case, *, warp_type="disp_warp", target_side="r", use_mixt
     if use_mixture_loss:
         res["sigma_rec"] = outputs[("sigma_rec", target_side)]
         res["pi_rec"] = outputs[("pi_rec", target_side)]
+    if warp_type == "homography_warp":
+        assert len(rec.got) == 1 and tuple(rec.got[0].shape) == (B * N, 3, 3)
+        res["H_t2s"] = rec.got[0]                       # the reference's own fp32 torch.inverse (layers.py:219)
     return {k: v.detach() for k, v in res.items()}
 
 
@@ -349,7 +375,8 @@ def trainer_mono_vectors(ref):
         outputs.update(Trainer.predict_poses(ns, inputs))
         for f in novel:
             outputs[("Rt", f)].retain_grad()
-        Trainer.pred_novel_images(ns, inputs, outputs)
+        with record_inverse() as rec:
+            Trainer.pred_novel_images(ns, inputs, outputs)
         losses = Trainer.compute_losses(ns, inputs, outputs)
         gw = {s: torch.randn(B, 3, H, W, generator=g) * 1e-3 for s in cfg["target_sides"]}
         obj = losses["loss/total_loss"] + sum((outputs[("rgb_rec", s)] * gw[s]).sum() for s in cfg["target_sides"])
@@ -373,6 +400,11 @@ def trainer_mono_vectors(ref):
             blob["g_Rt_%s" % s] = gR
             blob["gw_%s" % s] = gw[s]
             blob["rgb_rec_%s" % s] = outputs[("rgb_rec", s)]
+        if cfg["warp_type"] == "homography_warp":   # the reference's own H_t2s, one block per target side in loop order (trainer.py:532)
+            assert len(rec.got) == len(cfg["target_sides"])
+            for s, Hm in zip(cfg["target_sides"], rec.got):
+                assert tuple(Hm.shape) == (B * N, 3, 3)
+                blob["H_t2s_%s" % s] = Hm
         out.update({"%s/%s" % (tag, k): v.detach().numpy() for k, v in blob.items()})
         out["%s/meta" % tag] = np.frombuffer(json.dumps(dict(cfg, no_levels=no_levels, xz_levels=xz_levels)).encode(),
                                              dtype=np.uint8)
@@ -411,6 +443,25 @@ def pipeline_vectors(ref):
     return out
 
 
+def fullsize_pinned_homography(ref):
+    """192 x 640 x 63 planes, a pose with rotation AND translation (one homography per plane), mixture + automask: the
+    reference's own H_t2s [63,3,3] plus what the reference computed from them — scalars, rgb_rec in full, the gradients on a
+    stride-8 lattice — so that the per-plane homography kernels are pinned at the benchmark size to the reference's outputs
+    on the reference's matrices.  Inputs are regenerated from the seed by whoever reads this (survey_fullsize_case)."""
+    case = survey_fullsize_case(B=1, N=63, sigma_interior=True)
+    case["Rt"] = small_pose(torch.Generator().manual_seed(77), 1)
+    res = run_reference(ref, case, warp_type="homography_warp", automask=True)
+    sub = lambda t: t[..., ::8, ::8].contiguous()  # noqa: E731
+    blob = dict(Rt=case["Rt"], H_t2s=res["H_t2s"], rgb_rec=res["rgb_rec"], ph_loss=res["ph_loss"],
+                g_logits_sub8=sub(res["g_logits"]), g_sigma_sub8=sub(res["g_sigma"]),
+                l1_g_logits=res["g_logits"].double().abs().sum(), l1_g_sigma=res["g_sigma"].double().abs().sum(),
+                max_g_logits=res["g_logits"].abs().max(), max_g_sigma=res["g_sigma"].abs().max(),
+                sum_rgb_rec=res["rgb_rec"].double().sum())
+    print("fullsize_pinned_homography ph=%.8f sum_rgb=%.4f cond(H) up to %.3g" % (
+        float(res["ph_loss"]), float(blob["sum_rgb_rec"]), float(torch.linalg.cond(res["H_t2s"].double()).max())))
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in blob.items()}
+
+
 def scalars(res):
     f = lambda t: float(t.double().sum())  # noqa: E731
     a = lambda t: float(t.double().abs().sum())  # noqa: E731
@@ -424,6 +475,28 @@ def main():
     torch.manual_seed(0)
     if "--only-trainer-mono" in sys.argv:   # add the configs[3] fixtures without touching the others
         np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
+        return
+    if "--only-homography-pins" in sys.argv:   # round 6: the reference's own H_t2s into the homography fixtures (everything else
+        # in them is regenerated bit for bit: seeded generators) + the full-size pinned KAT
+        for name, bkw, rkw in SMALL_CASES:
+            if rkw.get("warp_type") != "homography_warp":
+                continue
+            case = build_case(**bkw)
+            res = run_reference(ref, case, **rkw)
+            old = np.load(os.path.join(HERE, name + ".npz"))
+            for k in old.files:   # nothing else may move
+                if k.startswith("out_"):
+                    assert np.array_equal(old[k], res[k[4:]].numpy()), (name, k)
+            blob = {"in_" + k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in case.items()}
+            blob.update({"out_" + k: v.numpy() for k, v in res.items()})
+            blob["meta"] = np.frombuffer(json.dumps(dict(build=bkw, run=rkw)).encode(), dtype=np.uint8)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **blob)
+        old = np.load(os.path.join(HERE, "trainer_mono.npz"))
+        new = trainer_mono_vectors(ref)
+        for k in old.files:
+            assert np.array_equal(old[k], new[k]), k
+        np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **new)
+        np.savez_compressed(os.path.join(HERE, "homography_pinned_fullsize.npz"), **fullsize_pinned_homography(ref))
         return
     if "--only-pipeline" in sys.argv:
         np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **pipeline_vectors(ref))
@@ -442,6 +515,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "post_process.npz"), **post_process_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "trainer_mono.npz"), **trainer_mono_vectors(ref))
     np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **pipeline_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "homography_pinned_fullsize.npz"), **fullsize_pinned_homography(ref))
     kat = {}
     for name, _, rkw in FULL_CASES:
         case = survey_fullsize_case()

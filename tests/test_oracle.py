@@ -138,6 +138,48 @@ def test_post_process_against_reference_vectors(tag):
     assert rel_err(mask_novel, z["mask_novel"]) < TOL
 
 
+@pytest.mark.parametrize("name", [n for n in SMALL if n.startswith("homo")])
+def test_small_homography_fixture_on_the_references_own_matrices(name):
+    """The fixtures hold the H_t2s the REFERENCE computed (its fp32 torch.inverse, recorded inside HomographyWarp.forward,
+    layers.py:219).  With those pinned, everything downstream of the 3x3 algebra is compared without the inverse's backend in
+    the way (here LAPACK on both sides, so the unpinned test above agrees as well; on the GPU it is rocSOLVER or our kernel)."""
+    case, want, run = load_fixture(name)
+    got = run_oracle(case, run, H_t2s=want["H_t2s"])
+    for k in ("rgb_rec", "ph_loss", "g_logits", "g_sigma", "rgb_rec_layered", "logit_rec", "probability_rec"):
+        if float(want[k].abs().max()) == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+        else:
+            assert rel_err(got[k], want[k]) < TOL, (name, k, rel_err(got[k], want[k]))
+
+
+def test_fullsize_homography_on_the_references_own_matrices():
+    """192 x 640 x 63 planes, a pose with rotation and translation, mixture + automask (tests/golden/homography_pinned_fullsize.npz:
+    the reference's matrices and what it computed from them): the oracle on the same matrices."""
+    import numpy as np
+    from conftest import GOLDEN
+    from planedepth_amd.synthetic import survey_fullsize_case
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(GOLDEN, "homography_pinned_fullsize.npz")).items()}
+    case = survey_fullsize_case(B=1, N=63, sigma_interior=True)
+    case["Rt"] = z["Rt"]
+    got = run_oracle(case, dict(warp_type="homography_warp", automask=True), H_t2s=z["H_t2s"])
+    assert rel_err(got["rgb_rec"], z["rgb_rec"]) < TOL
+    assert abs(float(got["ph_loss"]) - float(z["ph_loss"])) < 1e-6 * abs(float(z["ph_loss"]))
+    for k in ("g_logits", "g_sigma"):
+        sub = got[k][..., ::8, ::8]
+        assert float((sub - z[k + "_sub8"]).abs().max()) < TOL * float(z["max_" + k]), k
+        assert abs(float(got[k].double().abs().sum()) - float(z["l1_" + k])) < 1e-5 * float(z["l1_" + k]), k
+    assert rel_err(got["H_t2s"], z["H_t2s"]) < 1e-2   # (the oracle's own inverse: same formula, cond(H) up to 3e5)
+
+
+@pytest.mark.parametrize("tag", ["homo3", "homo_nostereo_l1"])
+def test_trainer_mono_fixture_on_the_references_own_matrices(tag):
+    from cases import load_trainer_fixture, run_oracle_trainer
+    z, meta = load_trainer_fixture(tag)
+    got = run_oracle_trainer(z, meta, pin_matrices=True)
+    for k in [k for k in got if k.startswith("rgb_rec")] + ["ph_loss", "total_loss", "g_logits"] + (["g_sigma"] if meta["use_mixture_loss"] else []):
+        assert rel_err(got[k], z[k]) < TOL, (tag, k, rel_err(got[k], z[k]))
+
+
 @pytest.mark.parametrize("tag", ["homo3", "homo_nostereo_l1", "disp_xz"])
 def test_trainer_mono_fixture(tag):
     """BASELINE configs[3] as the trainer runs it (all target sides, decoder-made xz planes with non-frontal normals,
