@@ -352,13 +352,20 @@ int pd_smooth_loss_bwd_padded(int B, int C, int H, int W, int x_pad, const float
  *   pd_warp_sum      out[b,0] = min(cap, sum over n of planes[b,n] sampled at (x + sign*disp[b,n], y))      -> [B,1,H,W]
  * bilinear, zeros padding, align_corners=True, coordinates through the reference's normalise / un-normalise round trip.
  * disp [B,N] or, with PD_PP_DISP_DENSE, [B,N,H,W]; PD_PP_FLIP_SRC reads `planes` mirrored along x (the .flip(-1) of
- * trainer.py:451) without a flipped copy.
+ * trainer.py:451) without a flipped copy.  Per-plane disparities with an even W and N <= 64 (pd_warp_sum: any N) take the segment
+ * form (two pixels per lane, 12-byte taps, the softmax's samples of all planes in registers: sampled once); PD_PP_SEG=0 keeps
+ * the one-pixel-per-lane row kernels, PD_PP_ROWS=0 the per-pixel gather form (both exact: cross-checks).
  */
 enum pd_pp_flags { PD_PP_DISP_DENSE = 1, PD_PP_FLIP_SRC = 2 };
 int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp,
                     float* out, pd_stream_t stream);
 int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp, float cap,
                 float* out, pd_stream_t stream);
+/* disp_pp of trainer.py:458-461 in one pass: disp [2B,1,H,W] (the fixed model's output for cat([image, mirrored image])),
+ * o_fr / o_l [B,1,H,W] (the two occlusion masks pd_warp_sum produced) -> disp_pp [B,1,H,W];
+ *   mean = disp[b] / 2 + flip(disp[B + b]) / 2;  pp = mean o_fr + disp[b] (1 - o_fr);  disp_pp = pp o_l + flip(disp[B + b]) (1 - o_l). */
+int pd_pp_combine(int B, int H, int W, const float* disp, const float* o_fr, const float* o_l, float* disp_pp,
+                  pd_stream_t stream);
 
 /*
  * Trainer.add_flip_right_inputs (trainer.py:252-276): out [2B,C,H,W] = cat([own, flip(other, -1)]);

@@ -24,6 +24,7 @@ int check_launch(const char* what);
 struct Switches {
   bool no_rowpair;    // PD_NO_ROWPAIR=1: forward without row pairs
   bool pp_rows_off;   // PD_PP_ROWS=0: post-process kernels in per-pixel gather form
+  bool pp_seg_off;    // PD_PP_SEG=0: post-process kernels without the segment form (one pixel per lane, planes sampled twice)
   int row_waves;      // PD_ROW_WAVES=n: waves per row workgroup of the row-shift kernels (0 = default)
   int uni_chunk;      // PD_UNI_CHUNK=n: images per launch of the plane-uniform backward passes (0 = whole batch)
   bool fwd_stream;    // PD_FWD_STREAM=0: the headline forward on the plane-group row-shift kernel instead of the segment-stream one
@@ -233,6 +234,33 @@ __device__ __forceinline__ float normalise_roundtrip_rcp(float px, float size_m1
   const float hh = h + 0.5f;
   const float r = hh * size_m1;
   return (fabsf(px) == __builtin_inff()) ? px * size_m1 : r;   // +-inf stays +-inf (size_m1 > 0)
+}
+
+// One row of a 3x3 matrix times [x, y, 1] in the rounding order of torch's batched matmul on the host the golden vectors were
+// captured on (layers.py:221 `torch.matmul(H_t2s, pix_coords_t)`; oneDNN / MKL sgemm walks k in order with fused multiply-adds):
+// fl(fl(h1 * y + fl(h0 * x)) + h2).  Checked bit for bit against torch.matmul on the trainer fixtures' matrices (NOTEBOOK 11.3);
+// written out so that the compiler's contraction choice (which product it fuses) cannot change it.
+__device__ __forceinline__ float hrow_dot(float h0, float h1, float h2, float x, float y) {
+#pragma clang fp contract(off)
+  const float t0 = h0 * x;
+  const float t1 = __builtin_fmaf(h1, y, t0);
+  return t1 + h2;
+}
+
+__device__ __forceinline__ float hrow_dot4(float h0, float h1, float h2, float h3, float x, float y, float z, float w) {
+#pragma clang fp contract(off)
+  const float t0 = h0 * x;
+  const float t1 = __builtin_fmaf(h1, y, t0);
+  const float t2 = __builtin_fmaf(h2, z, t1);
+  return __builtin_fmaf(h3, w, t2);
+}
+
+// The facing test's left-hand side (layers.py:223: `(matmul(inv_K, pix) * matmul(R, n)).sum(1)`): three products rounded on their
+// own, added in index order — no contraction, so that a pixel on the horizon line falls on the reference's side of it.
+__device__ __forceinline__ float facing_dot(float r0, float r1, float r2, float q0, float q1, float q2) {
+#pragma clang fp contract(off)
+  const float a = r0 * q0, b = r1 * q1, c = r2 * q2;
+  return (a + b) + c;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -17,9 +17,9 @@ __global__ __launch_bounds__(kBlock) void backproject_kernel(int HW, int W, cons
   const float y = (float)(pix / W), x = (float)(pix % W);
   const float d = depth[(long)b * HW + pix];
   float* o = cam + (long)b * 4 * HW + pix;
-  o[0] = d * (Ki[0] * x + Ki[1] * y + Ki[2]);
-  o[HW] = d * (Ki[4] * x + Ki[5] * y + Ki[6]);
-  o[2 * HW] = d * (Ki[8] * x + Ki[9] * y + Ki[10]);
+  o[0] = d * hrow_dot(Ki[0], Ki[1], Ki[2], x, y);      // (layers.py:152 torch.matmul's rounding order: pd_common.h)
+  o[HW] = d * hrow_dot(Ki[4], Ki[5], Ki[6], x, y);
+  o[2 * HW] = d * hrow_dot(Ki[8], Ki[9], Ki[10], x, y);
   o[3 * HW] = 1.0f;
 }
 
@@ -45,9 +45,9 @@ __global__ __launch_bounds__(kBlock) void project3d_kernel(int H, int W, float e
   const float* Pm = P + (long)b * 12;  // [3,4]
   const float* c = cam + (long)b * 4 * HW + pix;
   const float X = c[0], Y = c[HW], Z = c[2 * HW], Wh = c[3 * HW];
-  const float p0 = Pm[0] * X + Pm[1] * Y + Pm[2] * Z + Pm[3] * Wh;
-  const float p1 = Pm[4] * X + Pm[5] * Y + Pm[6] * Z + Pm[7] * Wh;
-  const float z = Pm[8] * X + Pm[9] * Y + Pm[10] * Z + Pm[11] * Wh + eps;
+  const float p0 = hrow_dot4(Pm[0], Pm[1], Pm[2], Pm[3], X, Y, Z, Wh);   // (layers.py:174 torch.matmul's rounding order)
+  const float p1 = hrow_dot4(Pm[4], Pm[5], Pm[6], Pm[7], X, Y, Z, Wh);
+  const float z = hrow_dot4(Pm[8], Pm[9], Pm[10], Pm[11], X, Y, Z, Wh) + eps;
   float2 o;
   o.x = normalise(p0 / z, (float)(W - 1));
   o.y = normalise(p1 / z, (float)(H - 1));
@@ -113,11 +113,11 @@ __global__ __launch_bounds__(kBlock) void homography_grid_kernel(int H, int W, c
   const float* Ki = invK3 + (long)m * 9;
   const float* rn = Rn + (long)m * 3;
   const float fy = (float)(pix / W), fx = (float)(pix % W);
-  const float p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
-  const float p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
-  const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
-  const float facing = (Ki[0] * fx + Ki[1] * fy + Ki[2]) * rn[0] + (Ki[3] * fx + Ki[4] * fy + Ki[5]) * rn[1] +
-                       (Ki[6] * fx + Ki[7] * fy + Ki[8]) * rn[2];
+  const float p0 = hrow_dot(Hm[0], Hm[1], Hm[2], fx, fy);
+  const float p1 = hrow_dot(Hm[3], Hm[4], Hm[5], fx, fy);
+  const float z = hrow_dot(Hm[6], Hm[7], Hm[8], fx, fy);
+  const float facing = facing_dot(hrow_dot(Ki[0], Ki[1], Ki[2], fx, fy), hrow_dot(Ki[3], Ki[4], Ki[5], fx, fy),
+                                  hrow_dot(Ki[6], Ki[7], Ki[8], fx, fy), rn[0], rn[1], rn[2]);
   const float zc = (z < 1e-7f) ? 1e-7f : z;
   float2 o;
   o.x = normalise(p0 / zc, (float)(W - 1));
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(kBlock) void homography_grid_bwd_kernel(int H, int 
     if (pix < HW) {
       const int iy = pix / W;
       const float fy = (float)iy, fx = (float)(pix - iy * W);
-      const float p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
-      const float p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
-      const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
+      const float p0 = hrow_dot(Hm[0], Hm[1], Hm[2], fx, fy);
+      const float p1 = hrow_dot(Hm[3], Hm[4], Hm[5], fx, fy);
+      const float z = hrow_dot(Hm[6], Hm[7], Hm[8], fx, fy);
       const bool clamped = z < 1e-7f;
       const float zc = clamped ? 1e-7f : z;
       const float2 g = reinterpret_cast<const float2*>(g_grid)[(long)m * HW + pix];

@@ -67,8 +67,12 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_LOAD_AUX
 #define PD_STREAM_LOAD_AUX 0    // same for the tap loads
 #endif
+#ifndef PD_STREAM_DEAD
+#define PD_STREAM_DEAD 1  // (plane, segment) items none of whose slots has a target inside the row (shift beyond the segment: the near planes'
+#endif                    // leading segments) issue no memory reads (zero-extent descriptors), read no context, do no arithmetic and store
+                          // the zeros they have to store: 11 of the 245 items of a headline row (round 6)
 #ifndef PD_STREAM_OCC
-#define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 77 = 6 waves per SIMD
+#define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 76 = 6 waves per SIMD
 #endif
 
 constexpr int kSlots = 2;               // source slots per lane
@@ -98,6 +102,7 @@ struct StreamLds {
   int* special;   // [1]  any plane with a negative shift or an irregular one (the epilogue has work)
   float4* tail;   // TAIL: [CW] per SOURCE pixel (lse of the decoder's logits, 1 / sum pi/sigma, disp, d loss / d disp)
   float* dpl;     // TAIL: [N]  the planes' disparities (unsigned, unclamped: the decoder's disp_layered)
+  int* live;      // [N]  PD_STREAM_DEAD: first live segment | (one past the last live segment) << 16
   int CW;
 };
 
@@ -167,21 +172,23 @@ struct StreamRow {     // workgroup-uniform
 
 template <bool MIX, int NROWS>
 __device__ __forceinline__ void stream_issue(StreamGroup<NROWS>& g, const SweepArgs& a, const StreamRow& r, int n, int seg,
-                                             unsigned lane8, int HW) {
+                                             unsigned lane8, int HW, int ext = -1) {
+  // ext: the row descriptors' extent in floats (wave-uniform); 0 turns the item's loads into hardware no-ops that return zeros
+  const int Wx = ext < 0 ? a.W : ext;
   const unsigned soff = (unsigned)seg * (kSeg * 4);
   const float* pl = plane_ptr(a.logits + (long)r.b * a.N * HW, n, HW);
-  const v3f la = buf_load3(row_rsrc(pl + (long)r.yA * a.W, a.W), lane8, soff);
+  const v3f la = buf_load3(row_rsrc(pl + (long)r.yA * a.W, Wx), lane8, soff);
   g.l[0][0] = la.x; g.l[0][1] = la.y; g.l[0][2] = la.z;
   if (NROWS == 2) {
-    const v3f lb = buf_load3(row_rsrc(pl + (long)r.yB * a.W, a.W), lane8, soff);
+    const v3f lb = buf_load3(row_rsrc(pl + (long)r.yB * a.W, Wx), lane8, soff);
     g.l[NROWS - 1][0] = lb.x; g.l[NROWS - 1][1] = lb.y; g.l[NROWS - 1][2] = lb.z;
   }
   if (MIX) {
     const float* ps = plane_ptr(a.sigma + (long)r.b * a.N * HW, n, HW);
-    const v3f sa = buf_load3(row_rsrc(ps + (long)r.yA * a.W, a.W), lane8, soff);
+    const v3f sa = buf_load3(row_rsrc(ps + (long)r.yA * a.W, Wx), lane8, soff);
     g.s[0][0] = sa.x; g.s[0][1] = sa.y; g.s[0][2] = sa.z;
     if (NROWS == 2) {
-      const v3f sb = buf_load3(row_rsrc(ps + (long)r.yB * a.W, a.W), lane8, soff);
+      const v3f sb = buf_load3(row_rsrc(ps + (long)r.yB * a.W, Wx), lane8, soff);
       g.s[NROWS - 1][0] = sb.x; g.s[NROWS - 1][1] = sb.y; g.s[NROWS - 1][2] = sb.z;
     }
   }
@@ -361,6 +368,31 @@ __device__ __forceinline__ void stream_stage_ctx(const SweepArgs& a, const BwdOu
   }
 }
 
+// One plane's staged shift (stream_body's form) + its live segment range (PD_STREAM_DEAD).  Returns "special".
+template <bool TAIL>
+__device__ __forceinline__ int stage_shift(const SweepArgs& a, const StreamLds& L, int i, float plane_i, bool masked, int nseg) {
+  const int W = a.W;
+  const float lim = (float)(W + 2), tol = irregular_tol(W);
+  const float sdr = a.sign * plane_i;
+  const float sd = (!masked && sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
+  const float fl = floorf(sd), fr = sd - fl;
+  const int k = (int)fl;
+  const bool inview = fabsf(sd) < (float)(W + 1);
+  const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
+  L.shift[i] = make_int2(__float_as_int(sd), k * 2 + irr);
+  if (TAIL) L.dpl[i] = plane_i;
+  L.red[i] = 0.0f;
+  // Slot xs serves the targets xs - k (left tap) and xs - 1 - k (right tap).  k >= 0: none of segment s is inside the row when
+  // s * kSeg + kSeg - 1 < k; k < 0: when s * kSeg - 1 - k >= W.  Irregular planes keep every segment (their general path decides).
+  int lo = 0, hi = nseg;
+  if (!irr) {
+    if (k >= 0) lo = min(k / kSeg, nseg);
+    else hi = min(nseg, max(0, (W + 1 + k + kSeg - 1) / kSeg));
+  }
+  L.live[i] = lo | (hi << 16);
+  return (irr || (k < 0 && inview)) ? 1 : 0;
+}
+
 template <bool MIX, int NROWS, bool PK, bool TAIL>
 __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o, int b, int y, const RowSel& row, const StreamLds& L) {
   constexpr int D = (NROWS == 1) ? PD_STREAM_D1 : PD_STREAM_D2;
@@ -379,48 +411,6 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
 
-  // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
-  stream_stage_ctx<MIX, NROWS, PK, TAIL>(a, o, r, L, HW);
-  if (threadIdx.x == 0) *L.special = 0;
-  __syncthreads();
-  {
-    const float lim = (float)(W + 2), tol = irregular_tol(W);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      const long di = (a.flags & PD_DISP_ROWS) ? ((long)r.b * N + i) * a.H + r.y : (long)r.b * N + i;
-      const float sdr = a.sign * a.plane[di];
-      // PD_MASK_ROWS: a masked plane samples as all-zero features (trainer.py:580) — what a plane shifted out of view does
-      const bool masked = a.mask_rows && a.mask_rows[((long)r.b * N + i) * a.H + r.y] == 0.0f;
-      const float sd = (!masked && sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f && !masked) ? -lim : lim);  // NaN -> +lim
-      const float fl = floorf(sd), fr = sd - fl;
-      const int k = (int)fl;
-      const bool inview = fabsf(sd) < (float)(W + 1);
-      const int irr = (inview && (fr < tol || fr > 1.0f - tol)) ? 1 : 0;
-      L.shift[i] = make_int2(__float_as_int(sd), k * 2 + irr);
-      if (TAIL) L.dpl[i] = a.plane[di];
-      L.red[i] = 0.0f;
-      if (irr || (k < 0 && inview)) *L.special = 1;
-    }
-  }
-  __syncthreads();
-  const int special = __builtin_amdgcn_readfirstlane(*L.special);
-  if (special) {   // irregular planes: their gradient rows are accumulated with atomics, so they start from zero
-    for (int n = 0; n < N; ++n) {
-      if (!(L.shift[n].y & 1)) continue;
-      for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        const long at = ((long)r.b * N + n) * HW + (long)r.y * W + x;
-        float il = 0.0f, is = 0.0f;
-        if (TAIL) {   // the tail's own term goes in first; the atomics then add the sweep's shares (sigma's already scaled)
-          const TailTerm tt = tail_term(L.tail[x + 2], a.logits[at], a.sigma[at], L.dpl[n], o.tail_raw_sigma + at);
-          il = tt.t; is = -tt.tos * tt.fs;
-          if (want_plane) atomicAdd(&L.red[n], a.sign * tt.gdl);
-        }
-        if (o.g_logits) o.g_logits[at] = il;
-        if (MIX && o.g_sigma) o.g_sigma[at] = is;
-      }
-    }
-    __syncthreads();
-  }
-
   // ---- this wave's contiguous range of the row's (plane, segment) list -------------------------------------------
   const int items = N * nseg;
   const int i0 = __builtin_amdgcn_readfirstlane((int)((long)items * wave / nwaves));
@@ -430,22 +420,70 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   float carry_l = 0.0f, carry_s = 0.0f, gacc = 0.0f;
   int n = i0 / nseg, seg = i0 - n * nseg;            // the item being computed
   int pn = n, pseg = seg;                            // the item being prefetched
+  constexpr bool kDead = PD_STREAM_DEAD && !TAIL;    // (TAIL: a dead item's stores still carry the tail's own terms, which need the taps)
+  int p_live = nseg << 16;                           // live segment range of the plane being prefetched (lo | hi << 16): all, until staged
   auto advance = [&](int& nn, int& ss) {
     ++ss;
     if (ss == nseg) { ss = 0; ++nn; }
   };
   StreamGroup<NROWS> g[D + 1];
   auto prefetch = [&](StreamGroup<NROWS>& grp) {
-    stream_issue<MIX, NROWS>(grp, a, r, min(pn, N - 1), pseg, lane8, HW);   // past the end: re-load the last plane (unused)
+    int ext = -1;
+    if (kDead) ext = (pseg < (p_live & 0xFFFF) || pseg >= (p_live >> 16)) ? 0 : W;   // a dead item's loads: no-ops that return zeros
+    stream_issue<MIX, NROWS>(grp, a, r, min(pn, N - 1), pseg, lane8, HW, ext);   // past the end: re-load the last plane (unused)
     advance(pn, pseg);
+    if (kDead && pseg == 0) p_live = __builtin_amdgcn_readfirstlane(L.live[min(pn, N - 1)]);   // (once per plane)
   };
+
+  // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
+  int special;
+  stream_stage_ctx<MIX, NROWS, PK, TAIL>(a, o, r, L, HW);
+  if (threadIdx.x == 0) *L.special = 0;
+  __syncthreads();
+  {
+    int flag = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      const long di = (a.flags & PD_DISP_ROWS) ? ((long)r.b * N + i) * a.H + r.y : (long)r.b * N + i;
+      const bool masked = a.mask_rows && a.mask_rows[((long)r.b * N + i) * a.H + r.y] == 0.0f;
+      flag |= stage_shift<TAIL>(a, L, i, a.plane[di], masked, nseg);
+    }
+    if (flag) *L.special = 1;
+  }
+  __syncthreads();
+  special = __builtin_amdgcn_readfirstlane(*L.special);
+
+  if (special) {   // irregular planes: their gradient rows are accumulated with atomics, so they start from zero
+    for (int n2 = 0; n2 < N; ++n2) {
+      if (!(L.shift[n2].y & 1)) continue;
+      for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const long at = ((long)r.b * N + n2) * HW + (long)r.y * W + x;
+        float il = 0.0f, is = 0.0f;
+        if (TAIL) {   // the tail's own term goes in first; the atomics then add the sweep's shares (sigma's already scaled)
+          const TailTerm tt = tail_term(L.tail[x + 2], a.logits[at], a.sigma[at], L.dpl[n2], o.tail_raw_sigma + at);
+          il = tt.t; is = -tt.tos * tt.fs;
+          if (want_plane) atomicAdd(&L.red[n2], a.sign * tt.gdl);
+        }
+        if (o.g_logits) o.g_logits[at] = il;
+        if (MIX && o.g_sigma) o.g_sigma[at] = is;
+      }
+    }
+    __syncthreads();
+  }
+  if (kDead) p_live = __builtin_amdgcn_readfirstlane(L.live[min(pn, N - 1)]);
+
   auto step = [&](const StreamGroup<NROWS>& grp) {
     const int2 sh = L.shift[n];
+    const int lv = kDead ? __builtin_amdgcn_readfirstlane(L.live[n]) : 0;
     const float sd = __int_as_float(__builtin_amdgcn_readfirstlane(sh.x));
     const int kk = __builtin_amdgcn_readfirstlane(sh.y);
     const int k = kk >> 1;
     if (seg == 0) carry_l = carry_s = 0.0f;
-    if (kk & 1) {   // irregular plane (wave-uniform branch): exact per-lane floor, atomics into the zero-filled row
+    if (kDead && (seg < (lv & 0xFFFF) || seg >= (lv >> 16))) {   // dead item (wave-uniform): zeros to store, nothing to read
+      const unsigned soff = (unsigned)seg * (kSeg * 4);
+      buf_store2(row_rsrc_bytes(plane_ptr(o.g_logits + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gl_bytes), lane8, soff, 0.0f, 0.0f);
+      if (MIX) buf_store2(row_rsrc_bytes(plane_ptr(o.g_sigma + (long)r.b * a.N * HW + (long)r.y * a.W, n, HW), gs_bytes), lane8, soff, 0.0f, 0.0f);
+      carry_l = carry_s = 0.0f;
+    } else if (kk & 1) {   // irregular plane (wave-uniform branch): exact per-lane floor, atomics into the zero-filled row
 #pragma unroll
       for (int i = 0; i < kSlots; ++i) {
         const float gd = stream_general_slot<MIX, NROWS, PK, TAIL>(a, o, r, L, n, seg * kSeg + lane * kSlots + i, k, sd, true, HW, Wm1, rcpWm1);
@@ -551,6 +589,7 @@ __global__ __launch_bounds__(kStreamThreadsMax, TAIL ? 6 : PD_STREAM_OCC) void r
   L.hand = L.red + a.N;
   L.special = reinterpret_cast<int*>(L.hand + 2 * (blockDim.x >> 6));
   L.dpl = reinterpret_cast<float*>(L.special + 4);
+  L.live = reinterpret_cast<int*>(L.dpl + a.N);
   const int y = block_row(bwd_rowid(a.B, a.H), a.H), b = wg_image(a.B, a.H);
   const RowSel row = two_row_form(make_row_sel(y, a.H), a.row_eps);
   if (row.nrows == 2 && !(kStreamAbl & 4)) stream_body<MIX, 2, PK, TAIL>(a, o, b, y, row, L);
@@ -576,7 +615,7 @@ __global__ void reduce_rows_stream_kernel(const float* __restrict__ partials, fl
 static size_t rowstream_lds_bytes(const pd_sweep_desc* d, int nwaves, bool packed, bool tail = false) {
   const size_t CW = (size_t)ceil_div(d->W, kSeg) * kSeg + 4;
   return CW * (packed ? 3 * sizeof(float4) + sizeof(float2) : (tail ? 5 : 4) * sizeof(float4)) +
-         (size_t)d->N * (sizeof(float2) + sizeof(float) + (tail ? sizeof(float) : 0)) + (size_t)nwaves * 2 * sizeof(float) + 32;
+         (size_t)d->N * (sizeof(float2) + 3 * sizeof(float)) + (size_t)nwaves * 2 * sizeof(float) + 32;
 }
 struct StreamShape { int nwaves; bool packed; size_t lds; };
 static StreamShape rowstream_shape(const pd_sweep_desc* d, bool tail = false) {

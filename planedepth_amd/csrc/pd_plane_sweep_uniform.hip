@@ -56,12 +56,12 @@ __device__ __forceinline__ UniGeom uni_geom(const float* __restrict__ Hm, const 
                                             int x, int y) {
   UniGeom u;
   const float fx = (float)x, fy = (float)y;
-  u.g.p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
-  u.g.p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
-  const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
-  u.r0 = Ki[0] * fx + Ki[1] * fy + Ki[2];
-  u.r1 = Ki[3] * fx + Ki[4] * fy + Ki[5];
-  u.r2 = Ki[6] * fx + Ki[7] * fy + Ki[8];
+  u.g.p0 = hrow_dot(Hm[0], Hm[1], Hm[2], fx, fy);
+  u.g.p1 = hrow_dot(Hm[3], Hm[4], Hm[5], fx, fy);
+  const float z = hrow_dot(Hm[6], Hm[7], Hm[8], fx, fy);
+  u.r0 = hrow_dot(Ki[0], Ki[1], Ki[2], fx, fy);
+  u.r1 = hrow_dot(Ki[3], Ki[4], Ki[5], fx, fy);
+  u.r2 = hrow_dot(Ki[6], Ki[7], Ki[8], fx, fy);
   u.z_ok = (z > kZMin);
   u.g.z_clamped = (z < kZMin);
   u.g.zc = u.g.z_clamped ? kZMin : z;
@@ -75,14 +75,14 @@ __device__ __forceinline__ UniGeom uni_geom(const float* __restrict__ Hm, const 
   return u;
 }
 __device__ __forceinline__ bool uni_mask(const UniGeom& u, const float* __restrict__ Rn) {
-  return ((u.r0 * Rn[0] + u.r1 * Rn[1] + u.r2 * Rn[2]) > 0.0f) && u.z_ok;   // layers.py:223-225, same operation order
+  return (facing_dot(u.r0, u.r1, u.r2, Rn[0], Rn[1], Rn[2]) > 0.0f) && u.z_ok;   // layers.py:223-225, same operation order
 }
 // The plane loops fetch plane n+1's normal (three scalar loads) while plane n is reduced: loaded where it is used, every
 // iteration began with a wait for the scalar cache.
 struct RnAhead {
   float q0, q1, q2;
   __device__ __forceinline__ void fetch(const float* __restrict__ Rn, int n) { q0 = Rn[n * 3]; q1 = Rn[n * 3 + 1]; q2 = Rn[n * 3 + 2]; }
-  __device__ __forceinline__ bool mask(const UniGeom& u) const { return ((u.r0 * q0 + u.r1 * q1 + u.r2 * q2) > 0.0f) && u.z_ok; }
+  __device__ __forceinline__ bool mask(const UniGeom& u) const { return (facing_dot(u.r0, u.r1, u.r2, q0, q1, q2) > 0.0f) && u.z_ok; }
 };
 
 // One image's [N,H,W] block as a buffer resource: a tap load is then "descriptor + the lane's 32-bit tap offset + the plane's

@@ -9,8 +9,9 @@
 // reference runs this under the fixed (no-grad) networks and detaches the result (:466).
 #include <math.h>
 #include <stdlib.h>
+#include <utility>
 #include "pd_common.h"
-#include "pd_rowgeom.h"
+#include "pd_rowshift_common.h"
 
 namespace pd {
 
@@ -274,6 +275,213 @@ __global__ __launch_bounds__(kWave) void warp_sum_rows_kernel(WarpArgs a, float 
   if (x < a.W) out[(long)b * HW + (long)y * a.W + x] = fminf(acc, cap);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segment form of the two (round 6): the segment-stream forward's access shape (pd_plane_sweep_fwdstream.hip).  One wave owns a
+// 128-pixel segment of a target row, a lane two adjacent pixels; their taps on plane n are the three source values at
+// x + k .. x + k + 2, k = floor(s d_n): ONE 12-byte load per live source row (half the memory instructions per pixel of the
+// 8-byte form above), coordinates through stream_ix, and — what the softmax gains most from — the sampled logits of ALL planes
+// stay in registers (2 x N <= 128 VGPRs), so the planes are sampled ONCE: the kernels above sample twice (statistics, then
+// probabilities).  FLIP reads the same three columns mirrored: the taps of pixels x, x+1 at mirrored columns c, c+1, c+2 are the
+// actual columns W-1-c .. W-3-c, one 12-byte load at W-3-c in reverse order.  Exactness as in the forward: planes whose
+// frac(s d) is within irregular_tol of an integer, and segments in which a lane's load would START at column -3 .. -1 (such a
+// load reads as zeros as a whole), take the per-pixel path of the row kernels above (exact floor(ix), 8-byte pairs).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSegPix = 2 * kWave;   // pixels per wave
+constexpr int kSegWaves = 4;         // waves per workgroup (independent items)
+typedef float v3f_pp __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ v3f_pp pp_load3(PRsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(v3f_pp, __builtin_amdgcn_raw_buffer_load_b96(r, (int)byte_off, 0, 0));
+}
+
+struct SegPlane {   // wave-uniform: one plane's shift for this segment
+  float sd;
+  int k;
+  bool general;
+};
+template <bool FLIP>
+__device__ __forceinline__ SegPlane seg_plane(const WarpArgs& a, int b, int n, int xseg) {
+  SegPlane p;
+  p.sd = plane_shift(a, b, n);
+  const float fl = floorf(p.sd), fr = p.sd - fl;
+  p.k = (int)fl;
+  const float tol = irregular_tol(a.W);
+  const bool inview = fabsf(p.sd) < (float)(a.W + 1);
+  const bool irr = inview && (fr < tol || fr > 1.0f - tol);
+  // first columns of the lanes' loads: c0 + 2 i (plain) or W - 3 - c0 - 2 i (mirrored), i = 0 .. 63
+  const int c0 = xseg + p.k;
+  const int lo = FLIP ? a.W - 3 - c0 - 2 * (kWave - 1) : c0, hi = FLIP ? a.W - 3 - c0 : c0 + 2 * (kWave - 1);
+  p.general = irr || (lo < 0 && hi >= -3);
+  return p;
+}
+
+// the two samples of a lane on one plane from its loaded taps (A = first live row, B = second)
+template <bool FLIP, int NR>
+__device__ __forceinline__ void seg_values(const WarpArgs& a, const RowTaps& r, const SegPlane& p, float x0f, const v3f_pp& ta,
+                                           const v3f_pp& tb, float& v0, float& v1) {
+  const float kf = (float)p.k;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float xtf = x0f + (float)i, xsf = xtf + kf;          // integers below 2^24: exact
+    const float ix = stream_ix(xtf, p.sd, a.Wm1, a.rcpWm1);
+    const float w1 = ix - xsf, w0 = (xsf + 1.0f) - ix;         // torch's (ix - x0), (x1 - ix) with x0 = x + k
+    // plain: pixel i reads taps i (w0), i + 1 (w1); mirrored: the three columns arrive reversed
+    const float a0 = FLIP ? (i == 0 ? ta.z : ta.y) : (i == 0 ? ta.x : ta.y), a1 = FLIP ? (i == 0 ? ta.y : ta.x) : (i == 0 ? ta.y : ta.z);
+    float v = (a0 * w0 + a1 * w1) * r.wa;
+    if (NR == 2) {
+      const float b0 = FLIP ? (i == 0 ? tb.z : tb.y) : (i == 0 ? tb.x : tb.y), b1 = FLIP ? (i == 0 ? tb.y : tb.x) : (i == 0 ? tb.y : tb.z);
+      v += (b0 * w0 + b1 * w1) * r.wb;
+    }
+    if (i == 0) v0 = v; else v1 = v;
+  }
+}
+
+// f(n, v0, v1) for every plane of the lane's two pixels, in plane order; loads of kGroup planes in flight
+template <bool FLIP, int NR, typename F>
+__device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
+                                          int x0, int HW, int n0, F& f) {
+  const float x0f = (float)x0;
+  {
+    SegPlane sp[kGroup];
+    v3f_pp ta[kGroup], tb[kGroup];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const int n = min(n0 + u, a.N - 1);
+      sp[u] = seg_plane<FLIP>(a, b, n, xseg);
+      const float* pl = pb + (long)n * HW;
+      const unsigned off = (unsigned)(FLIP ? a.W - 3 - (x0 + sp[u].k) : x0 + sp[u].k) << 2;
+      ta[u] = pp_load3(pp_row_rsrc(pl + (long)r.ra * a.W, a.W), off);
+      if (NR == 2) tb[u] = pp_load3(pp_row_rsrc(pl + (long)r.rb * a.W, a.W), off);
+      else tb[u] = ta[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const int n = n0 + u;
+      if (n < a.N) {   // (uniform)
+      float v0, v1;
+      if (sp[u].general) {   // (uniform) exact per-pixel path
+        float o0[1], o1[1];
+        rows_group<FLIP, NR, 1>(a, pb, r, b, n, x0, HW, o0);
+        rows_group<FLIP, NR, 1>(a, pb, r, b, n, x0 + 1, HW, o1);
+        v0 = o0[0]; v1 = o1[0];
+      } else {
+        seg_values<FLIP, NR>(a, r, sp[u], x0f, ta[u], tb[u], v0, v1);
+      }
+      f(n, v0, v1);
+      }
+    }
+  }
+}
+// NMAX > 0: the plane loop fully unrolled over NMAX >= N planes, group by group through an index pack (the callback then sees
+// compile-time plane indices and its per-plane state stays in registers; a `break` in a pragma-unrolled loop left it in scratch);
+// NMAX == 0: a run-time loop
+template <bool FLIP, int NR, typename F, int... G>
+__device__ __forceinline__ void seg_groups(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
+                                           int x0, int HW, F& f, std::integer_sequence<int, G...>) {
+  ((G * kGroup < a.N ? seg_group<FLIP, NR>(a, pb, r, b, xseg, x0, HW, G * kGroup, f) : (void)0), ...);
+}
+template <bool FLIP, int NR, int NMAX, typename F>
+__device__ __forceinline__ void seg_for_each(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
+                                             int x0, int HW, F f) {
+  if constexpr (NMAX > 0) {
+    seg_groups<FLIP, NR>(a, pb, r, b, xseg, x0, HW, f, std::make_integer_sequence<int, NMAX / kGroup>{});
+  } else {
+    for (int n0 = 0; n0 < a.N; n0 += kGroup) seg_group<FLIP, NR>(a, pb, r, b, xseg, x0, HW, n0, f);
+  }
+}
+
+// which (image, row, segment) a wave serves: items row-major, kSegWaves consecutive ones per workgroup
+struct SegItem { int b, y, xseg; bool on; };
+__device__ __forceinline__ SegItem seg_item(const WarpArgs& a, int B) {
+  const int nseg = (a.W + kSegPix - 1) / kSegPix;
+  const long item = (long)blockIdx.x * kSegWaves + (threadIdx.x >> 6);
+  SegItem s;
+  s.on = item < (long)B * a.H * nseg;
+  const long it = s.on ? item : 0;
+  s.xseg = (int)(it % nseg) * kSegPix;
+  s.y = (int)((it / nseg) % a.H);
+  s.b = (int)(it / ((long)nseg * a.H));
+  s.xseg = __builtin_amdgcn_readfirstlane(s.xseg); s.y = __builtin_amdgcn_readfirstlane(s.y); s.b = __builtin_amdgcn_readfirstlane(s.b);
+  return s;
+}
+
+template <bool FLIP, int NR, int NMAX>
+__device__ __forceinline__ void seg_softmax_body(const WarpArgs& a, const SegItem& it, const RowTaps& r, float* __restrict__ out) {
+  const int HW = a.H * a.W, lane = threadIdx.x & (kWave - 1);
+  const int x0 = it.xseg + 2 * lane;
+  const float* pb = a.planes + (long)it.b * a.N * HW;
+  float l0[NMAX], l1[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) l0[n] = l1[n] = -INFINITY;
+  float m0 = -INFINITY, m1 = -INFINITY;
+  seg_for_each<FLIP, NR, NMAX>(a, pb, r, it.b, it.xseg, x0, HW, [&](int n, float v0, float v1) {
+#pragma unroll
+    for (int q = 0; q < NMAX; ++q) if (q == n) { l0[q] = v0; l1[q] = v1; }   // (n is a compile-time constant once unrolled)
+    m0 = fmaxf(m0, v0); m1 = fmaxf(m1, v1);
+  });
+  float Z0 = 0.0f, Z1 = 0.0f;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {   // (planes beyond N hold -inf: they add exp(-inf) = 0)
+    l0[n] = __expf(l0[n] - m0); l1[n] = __expf(l1[n] - m1);
+    Z0 += l0[n]; Z1 += l1[n];
+  }
+  if (x0 >= a.W) return;   // (W is even: the lane's two pixels are inside or outside together)
+  const float i0 = 1.0f / Z0, i1 = 1.0f / Z1;
+  float* ob = out + (long)it.b * a.N * HW + (long)it.y * a.W + x0;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    if (n < a.N) *reinterpret_cast<float2*>(ob + (long)n * HW) = make_float2(l0[n] * i0, l1[n] * i1);
+}
+
+template <bool FLIP, int NMAX>
+__global__ __launch_bounds__(kSegWaves* kWave) void warp_softmax_seg_kernel(WarpArgs a, int B, float* __restrict__ out) {
+  const SegItem it = seg_item(a, B);
+  if (!it.on) return;
+  const RowTaps r = row_taps(it.y, a.H);   // wave-uniform
+  if (r.wb != 0.0f) seg_softmax_body<FLIP, 2, NMAX>(a, it, r, out);
+  else              seg_softmax_body<FLIP, 1, NMAX>(a, it, r, out);
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(kSegWaves* kWave) void warp_sum_seg_kernel(WarpArgs a, int B, float cap, float* __restrict__ out) {
+  const SegItem it = seg_item(a, B);
+  if (!it.on) return;
+  const RowTaps r = row_taps(it.y, a.H);
+  const int HW = a.H * a.W, lane = threadIdx.x & (kWave - 1);
+  const int x0 = it.xseg + 2 * lane;
+  const float* pb = a.planes + (long)it.b * a.N * HW;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  auto add = [&](int, float v0, float v1) { acc0 += v0; acc1 += v1; };
+  if (r.wb != 0.0f) seg_for_each<FLIP, 2, 0>(a, pb, r, it.b, it.xseg, x0, HW, add);
+  else              seg_for_each<FLIP, 1, 0>(a, pb, r, it.b, it.xseg, x0, HW, add);
+  if (x0 < a.W) *reinterpret_cast<float2*>(out + (long)it.b * HW + (long)it.y * a.W + x0) = make_float2(fminf(acc0, cap), fminf(acc1, cap));
+}
+
+// disp_pp of trainer.py:458-461 from the two occlusion masks: one pass instead of eight elementwise launches.
+//   mean = disp[b] * 0.5 + flip(disp[B + b]) * 0.5;  pp = mean * o_fr + disp[b] * (1 - o_fr);  pp = pp * o_l + flip(disp[B + b]) * (1 - o_l)
+// in torch's operation order (every product and sum rounded on its own).
+__global__ __launch_bounds__(kBlock) void pp_combine_kernel(int B, int H, int W, const float* __restrict__ disp,
+                                                            const float* __restrict__ o_fr, const float* __restrict__ o_l,
+                                                            float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long HW = (long)H * W, i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const int b = (int)(i / HW);
+  const long p = i - (long)b * HW;
+  const int y = (int)(p / W), x = (int)(p - (long)y * W);
+  const float d0 = disp[i], df = disp[((long)B + b) * HW + (long)y * W + (W - 1 - x)];
+  const float ofr = o_fr[i], ol = o_l[i];
+  const float mean = d0 * 0.5f + df * 0.5f;
+  float pp = mean * ofr + d0 * (1.0f - ofr);
+  pp = pp * ol + df * (1.0f - ol);
+  out[i] = pp;
+}
+
+// pixel pairs: even width, 8-byte aligned output rows; the softmax holds 2 N samples in registers
+static bool seg_applicable(const WarpArgs& a, int B, const float* out, int nmax) {
+  return !switches().pp_seg_off && !a.dense && (a.W % 2 == 0) && a.N <= nmax && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
+         (long)B * a.H * ((a.W + kSegPix - 1) / kSegPix) < (1L << 31) * kSegWaves && a.W <= (1 << 24);
+}
+
 // the row kernels need 32-bit byte offsets inside a row and grid dimensions within the launch limits
 static bool rows_applicable(const WarpArgs& a, int B) {
   return !switches().pp_rows_off && !a.dense && a.H <= 65535 && B <= 65535 && a.W <= (1 << 24);
@@ -310,6 +518,15 @@ extern "C" int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags
   WarpArgs a;
   if (int rc = warp_args(a, B, N, H, W, sign, flags, planes, disp)) return rc;
   PD_REQUIRE(out && out != planes, "out must be a distinct buffer");
+  if (seg_applicable(a, B, out, 64)) {
+    const int nseg = ceil_div(W, kSegPix);
+    const dim3 g((unsigned)(((long)B * H * nseg + kSegWaves - 1) / kSegWaves));
+    if (N <= 32) { if (a.flip) warp_softmax_seg_kernel<true, 32><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out);
+                   else        warp_softmax_seg_kernel<false, 32><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out); }
+    else         { if (a.flip) warp_softmax_seg_kernel<true, 64><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out);
+                   else        warp_softmax_seg_kernel<false, 64><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out); }
+    return check_launch("warp_softmax_seg_kernel");
+  }
   if (rows_applicable(a, B)) {
     dim3 g(ceil_div(W, kWave), H, B);
     if (a.flip) warp_softmax_rows_kernel<true><<<g, kWave, 0, (hipStream_t)stream>>>(a, out);
@@ -327,6 +544,13 @@ extern "C" int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, co
   WarpArgs a;
   if (int rc = warp_args(a, B, N, H, W, sign, flags, planes, disp)) return rc;
   PD_REQUIRE(out, "NULL output");
+  if (seg_applicable(a, B, out, 1 << 20)) {
+    const int nseg = ceil_div(W, kSegPix);
+    const dim3 g((unsigned)(((long)B * H * nseg + kSegWaves - 1) / kSegWaves));
+    if (a.flip) warp_sum_seg_kernel<true><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, cap, out);
+    else        warp_sum_seg_kernel<false><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, cap, out);
+    return check_launch("warp_sum_seg_kernel");
+  }
   if (rows_applicable(a, B)) {
     dim3 g(ceil_div(W, kWave), H, B);
     if (a.flip) warp_sum_rows_kernel<true><<<g, kWave, 0, (hipStream_t)stream>>>(a, cap, out);
@@ -337,4 +561,12 @@ extern "C" int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, co
   if (a.flip) warp_sum_kernel<true><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, cap, out);
   else        warp_sum_kernel<false><<<grid, kBlock, 0, (hipStream_t)stream>>>(a, cap, out);
   return check_launch("warp_sum_kernel");
+}
+
+extern "C" int pd_pp_combine(int B, int H, int W, const float* disp, const float* o_fr, const float* o_l, float* disp_pp,
+                             pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31) * kBlock, "bad shape");
+  PD_REQUIRE(disp && o_fr && o_l && disp_pp, "NULL pointer");
+  pp_combine_kernel<<<(unsigned)(((long)B * H * W + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, disp, o_fr, o_l, disp_pp);
+  return check_launch("pp_combine_kernel");
 }

@@ -49,13 +49,13 @@ __device__ __forceinline__ PlaneGeom plane_coords(const SweepArgs& a, const Coor
     const float* Rn = a.plane_aux + ((long)b * a.N + n) * 3;
     const float* Ki = a.inv_K3 + (long)b * 9;
     const float fx = (float)x, fy = (float)y;
-    g.p0 = Hm[0] * fx + Hm[1] * fy + Hm[2];
-    g.p1 = Hm[3] * fx + Hm[4] * fy + Hm[5];
-    const float z = Hm[6] * fx + Hm[7] * fy + Hm[8];
-    const float r0 = Ki[0] * fx + Ki[1] * fy + Ki[2];
-    const float r1 = Ki[3] * fx + Ki[4] * fy + Ki[5];
-    const float r2 = Ki[6] * fx + Ki[7] * fy + Ki[8];
-    const float facing = r0 * Rn[0] + r1 * Rn[1] + r2 * Rn[2];
+    g.p0 = hrow_dot(Hm[0], Hm[1], Hm[2], fx, fy);
+    g.p1 = hrow_dot(Hm[3], Hm[4], Hm[5], fx, fy);
+    const float z = hrow_dot(Hm[6], Hm[7], Hm[8], fx, fy);
+    const float r0 = hrow_dot(Ki[0], Ki[1], Ki[2], fx, fy);
+    const float r1 = hrow_dot(Ki[3], Ki[4], Ki[5], fx, fy);
+    const float r2 = hrow_dot(Ki[6], Ki[7], Ki[8], fx, fy);
+    const float facing = facing_dot(r0, r1, r2, Rn[0], Rn[1], Rn[2]);
     mask = (facing > 0.0f) && (z > kZMin);
     g.z_clamped = (z < kZMin);
     g.zc = g.z_clamped ? kZMin : z;

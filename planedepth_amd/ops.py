@@ -821,7 +821,10 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
     if plane_uniform and N * H * W >= (1 << 29):
         plane_uniform = False   # the plane-uniform kernels address one image's [N,H,W] block with 32-bit byte offsets; beyond
         # that the per-plane route below (one matrix per plane, 64-bit addressing) serves the same poses
-    if stereo_rows and not T.requires_grad and not norm.requires_grad:
+    # (PD_TORCH_HOMOGRAPHY: the row form's premise h00 = 1, z = 1 holds to 2e-7 for the fp64-formed matrices only; an fp32
+    # torch.inverse at cond ~1e3 leaves h00 - 1 ~ 1e-5, i.e. up to 6e-3 pixels across a 640-pixel row, which the reference's own
+    # chain carries into the result (measured on the reference-captured matrices: rgb_rec 1.9e-4 off) -> per-plane kernels)
+    if stereo_rows and not TORCH_HOMOGRAPHY and not T.requires_grad and not norm.requires_grad:
         return _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, use_mixture_loss, automask,
                                   return_mean, defer, render_probability, dists)
     ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
@@ -865,22 +868,7 @@ def plane_sweep_homography(src, tgt, logits, sigma, distance, norm, T, K, inv_K,
 def _stereo_rows_sweep(src, tgt, logits, sigma, distance, norm, T, K, inv_K, mix, automask, return_mean, defer=False,
                        render=False, dists=None):
     B, N, H, W = logits.shape
-    if TORCH_HOMOGRAPHY:
-        ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731
-        H_t2s, Rn = homography_matrices(distance, norm, ex(T), ex(K), ex(inv_K))
-        Hm = H_t2s.reshape(B, N, 3, 3)
-        y = torch.arange(H, device=logits.device, dtype=torch.float32).reshape(1, 1, H)
-        # layers.py:219, 227-229 at h00 = 1, z = 1 (they differ from 1 by the inverse's rounding, <= 2e-7 * W pixels:
-        # the same order as one ulp of the coordinate itself)
-        shift = Hm[:, :, 0, 1, None] * y + Hm[:, :, 0, 2, None]                            # [B,N,H] pixels
-        with torch.no_grad():
-            ik = inv_K[:, :3, :3]
-            ray = ik[:, None, :, 1, None] * y[..., None, :] + ik[:, None, :, 2, None]       # [B,1,3,H]: inv_K (0, y, 1)^T
-            facing = (ray * Rn.reshape(B, N, 3, 1)).sum(2) > 0.0                            # layers.py:223 (Rn_x = 0)
-            z = Hm[:, :, 2, 1, None] * y + Hm[:, :, 2, 2, None]
-            mask = (facing & (z > 1e-7)).float()                                            # layers.py:224-225
-    else:
-        shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
+    shift, mask, _ = homography_matrices_fused(distance, norm, T, K, inv_K, C.PD_HMAT_STEREO_ROWS, rows=H)
     return plane_sweep_disp(src, tgt, logits, sigma, None, None, target_side="r", use_mixture_loss=mix,
                             automask=automask, row_uniform=True, return_mean=return_mean, defer=defer,
                             render_probability=render, dists=dists, _rows=(shift, mask))
@@ -1084,6 +1072,24 @@ def warp_sum(planes, disp_layered, sign, cap=1.0, flip_src=False):
     return out
 
 
+def pp_combine(disp, o_fr, o_l):
+    """disp_pp of trainer.py:458-461 in one launch: ``disp`` [2B,1,H,W] (image, mirrored image), the occlusion masks
+    ``o_fr`` / ``o_l`` [B,1,H,W] -> mean-of-both where o_fr says so, the mirrored pass's disparity where o_l is 0."""
+    lib = C.load()
+    C.require_gpu_tensor("disp", disp)
+    B2, _, H, W = disp.shape
+    B = B2 // 2
+    C.require_gpu_tensor("o_fr", o_fr, (B, 1, H, W))
+    C.require_gpu_tensor("o_l", o_l, (B, 1, H, W))
+    with torch.no_grad():
+        disp, o_fr, o_l = (_contig(t.detach()) for t in (disp, o_fr, o_l))
+        out = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        with C.on_device(disp.device):
+            C.check(lib.pd_pp_combine(B, H, W, C.ptr(disp), C.ptr(o_fr), C.ptr(o_l), C.ptr(out), C.stream_handle(disp.device)),
+                    "pd_pp_combine")
+    return out
+
+
 def post_process_disp(logits, probability, disp, disp_layered):
     """trainer.py:421-466 given the fixed model's outputs for cat([image, mirrored image]) -> (disp_pp, mask_novel)."""
     B = probability.shape[0] // 2
@@ -1093,10 +1099,7 @@ def post_process_disp(logits, probability, disp, disp_layered):
         o_l = warp_sum(plr, dl_l, -1.0)                                  # :447-449
         pfrl = warp_softmax(logits[B:], dl_l, -1.0, flip_src=True)       # :451-453 (the flip is folded into the read)
         o_fr = warp_sum(pfrl, dl_r, +1.0)                                # :454-456
-        disp_f = disp[B:].flip(-1)
-        mean_disp = disp[:B] * 0.5 + disp_f * 0.5                        # :458
-        disp_pp = mean_disp * o_fr + disp[:B] * (1 - o_fr)               # :460
-        disp_pp = disp_pp * o_l + disp_f * (1 - o_l)                     # :461
+        disp_pp = pp_combine(disp, o_fr, o_l)                            # :458-461
         prob = probability.tensor() if hasattr(probability, "tensor") else probability
         mask_novel = warp_sum(prob[:B], dl_r, +1.0)                      # :463-465
     return disp_pp, mask_novel
