@@ -6,9 +6,8 @@
 // colour taps, coordinates: 148 VGPRs = 3 waves per SIMD, 12 per CU) and splits a row's segments and planes over four
 // waves that meet in LDS.  Measured: its load phase and its arithmetic are both latency-bound at that occupancy (all
 // arithmetic compiled out: 0.136 ms; all tap loads compiled out: 0.092 ms; 30 VALU per pixel and plane are 0.02 ms of
-// issue time), and neither persistent workgroups nor overlapped row staging move it (scripts/experiments/
-// pd_plane_sweep_rowpersist.hip.txt, NOTEBOOK.md 9.1).  This kernel is the forward counterpart of the row-stream
-// backward's loop (0.123 -> 0.104 ms isolated at 8x49x192x640, NOTEBOOK.md 9.2):
+// issue time), and neither persistent workgroups nor overlapped row staging move it (docs/archive/experiments/
+// pd_plane_sweep_rowpersist.hip.txt, NOTEBOOK.md 9.1).  This kernel is the forward counterpart of the row-stream backward's loop (0.123 -> 0.104 ms isolated at 8x49x192x640, NOTEBOOK.md 9.2):
 //   * one wave owns one 128-pixel segment of a target row and ALL planes: no split of the online softmax, no partial
 //     sums through LDS, no barrier after the row's constants are staged, one pipeline fill per wave;
 //   * a lane owns two adjacent target pixels; the taps of both on plane n are the three source values at xt + k ..

@@ -59,7 +59,7 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #ifndef PD_STREAM_STORE_AUX
 #define PD_STREAM_STORE_AUX 2   // cache-policy bits of the gradient stores (1 = sc0, 2 = nt, 16 = sc1; 0 = write-back).  nt: the
 #endif                          // 385 MB of gradients stream past the caches instead of leaving ~256 MB of dirty lines behind for
-                                // the next kernels to evict.  Measured (round 4, scripts/gpu_r4_nt.sh): in the hot-path loop this
+                                // the next kernels to evict.  Measured (round 4, docs/archive/scripts/gpu_r4_nt.sh): in the hot-path loop this
                                 // kernel pays its own writes (0.178 -> 0.194 ms) and the forward that follows stops paying them
                                 // (0.126-0.133 -> 0.108 ms): step +2-3 %; inside the DDP training step, where the fused decoder
                                 // tail's backward is the consumer, BOTH get faster (this kernel 0.177-0.195 -> 0.170 ms, the

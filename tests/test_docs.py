@@ -33,7 +33,7 @@ def test_every_cited_test_exists():
 
 def test_every_cited_source_file_exists():
     missing = {}
-    pat = re.compile(r"\b((?:planedepth_amd|tests|scripts|oracle|include|profiles)/[\w./-]+\.(?:py|hip\.txt|hip|h|sh|md|json|npz|csv))(?![\w.])")
+    pat = re.compile(r"(?<![\w/-])((?:docs/archive/scripts|docs/archive/experiments|planedepth_amd|tests|scripts|oracle|include|profiles)/[\w./-]+\.(?:py|hip\.txt|hip|h|sh|md|json|npz|csv))(?![\w.])")
     for doc in DOCS:
         path = os.path.join(ROOT, doc)
         if not os.path.isfile(path):

@@ -1689,11 +1689,11 @@ def test_trainer_mono_fixture_through_patch_trainer(tag, stereo_constant, monkey
     adopted the product methods with patch_trainer."""
     from cases import cap_for, load_trainer_fixture, run_oracle_trainer
     from gpu_cases import run_product_trainer
-    from planedepth_amd import ops
+    from planedepth_amd import sweep
     z, meta = load_trainer_fixture(tag)
     taken = []
-    rows_sweep = ops._stereo_rows_sweep
-    monkeypatch.setattr(ops, "_stereo_rows_sweep", lambda *a, **k: (taken.append(1), rows_sweep(*a, **k))[1])
+    rows_sweep = sweep._stereo_rows_sweep
+    monkeypatch.setattr(sweep, "_stereo_rows_sweep", lambda *a, **k: (taken.append(1), rows_sweep(*a, **k))[1])
     got = run_product_trainer(z, meta, stereo_constant=stereo_constant)
     # the stereo side runs as per-row shifts on the row-shift kernels exactly when its pose is the dataset's constant
     assert len(taken) == (1 if stereo_constant else 0)
