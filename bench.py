@@ -360,11 +360,11 @@ def next_rows_times(args, device, iters=100):
 
     def tail_fwd():
         with torch.no_grad():
-            dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+            dl = ops.plane_disparities(lv, 2.0, 300.0, W)[0].expand(-1, -1, H, W)
             return ops.decoder_tail(raw_l, raw_s, None, dl)
 
     def tail_fwd_bwd():
-        dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+        dl = ops.plane_disparities(lv, 2.0, 300.0, W)[0].expand(-1, -1, H, W)   # (depth_decoder.py:150-152 in one launch each way)
         logits, sigma, disp, depth, _ = ops.decoder_tail(raw_l, raw_s, None, dl)
         torch.autograd.backward([logits, sigma, disp], [gl, gs, gd])
         raw_l.grad = raw_s.grad = lv.grad = None
@@ -423,7 +423,7 @@ def next_rows_times(args, device, iters=100):
     gt = mk(B, N - 1, H, W)
 
     def plade_fwd_bwd():   # PladeNet's tail with --render_probability (plade_net.py:309-341): the producer of outputs["dists"]
-        dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).expand(-1, -1, H, W)
+        dl = ops.plane_disparities(lv, 2.0, 300.0, W)[0].expand(-1, -1, H, W)   # (plade_net.py:280-285 in one launch each way)
         logits, dists, sigma, disp, depth, _ = ops.plade_tail(raw_lp, raw_s, dl)
         torch.autograd.backward([logits, dists, sigma, disp], [gl, gt, gs, gd])
         raw_lp.grad = raw_s.grad = lv.grad = None
@@ -450,8 +450,8 @@ def next_rows_times(args, device, iters=100):
                          "shape": [2 * Bp, N, H, W]},
         "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot (host-paced "
                 "where the Python / autograd overhead exceeds the kernels' time: fwd_bwd_ms of the two small operators and of "
-                "the PladeNet tail (ten small torch launches for its per-plane disparities around the two kernels) is the "
-                "box's CPU speed; fwd_bwd_device_ms is the same call replayed from a HIP graph, i.e. the device's share, and "
+                "the PladeNet tail is the box's CPU speed (its per-plane disparities come from ops.plane_disparities: one launch each "
+                "way instead of the ten elementwise ones of round 5); fwd_bwd_device_ms is the same call replayed from a HIP graph, i.e. the device's share, and "
                 "what plade_tail_render's GB/s is computed from)" % iters,
     }
 

@@ -367,6 +367,14 @@ int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* 
 int pd_pp_combine(int B, int H, int W, const float* disp, const float* o_fr, const float* o_l, float* disp_pp,
                   pd_stream_t stream);
 
+/* trainer.py:443-465 behind ONE call (six launches on `stream`): logits / probability [2B,N,H,W] and disp [2B,1,H,W] are the fixed
+ * model's outputs for cat([image, mirrored image]) (B = half of that batch; of `probability` only the first B images are read),
+ * disp_layered [2B,N] or, PD_PP_DISP_DENSE, [2B,N,H,W]; workspace: pd_post_process_workspace_floats floats;
+ * -> disp_pp, mask_novel [B,1,H,W]. */
+size_t pd_post_process_workspace_floats(int B, int N, int H, int W);
+int pd_post_process(int B, int N, int H, int W, int flags, const float* logits, const float* probability, const float* disp,
+                    const float* disp_layered, float* workspace, float* disp_pp, float* mask_novel, pd_stream_t stream);
+
 /*
  * Trainer.add_flip_right_inputs (trainer.py:252-276): out [2B,C,H,W] = cat([own, flip(other, -1)]);
  * negate_c0 flips the sign of channel 0 in the mirrored half (the x-coordinate channel of `grid`, trainer.py:258-260).
@@ -381,6 +389,17 @@ int pd_cat_flip(int B, int C, int H, int W, const float* own, const float* other
  * torch.linspace(-1, 1, full_h)[h0 + y] (scalar formula; within one ulp of ATen's vectorised CPU kernel).
  */
 int pd_crop_grid(int B, int H, int W, const int32_t* params, float* grid, pd_stream_t stream);
+
+/*
+ * The decoders' disparity levels (networks/depth_decoder.py:147-152, networks/plade_net.py:280-285), one launch each way:
+ *   disp[m] = disp_max * (disp_min / disp_max) ** (levels[m] / (no_levels - 1));   distance[m] = dist_num / disp[m]
+ * over M = B * N values (levels = arange(no_levels) + the learnt residual; dist_num = 0.1 * 0.58 * W, `distance` may be NULL).
+ * pd_plane_levels_bwd: g_levels from the upstream gradients of disp and / or distance (either may be NULL) and the forward's disp.
+ */
+int pd_plane_levels_fwd(int M, int no_levels, float disp_min, float disp_max, float dist_num, const float* levels, float* disp,
+                        float* distance, pd_stream_t stream);
+int pd_plane_levels_bwd(int M, int no_levels, float disp_min, float disp_max, float dist_num, const float* disp,
+                        const float* g_disp, const float* g_distance, float* g_levels, pd_stream_t stream);
 
 /*
  * Photometric loss under the occlusion mask `mask_novel` (trainer.py:724-742; the mask is produced after

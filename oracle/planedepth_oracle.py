@@ -103,14 +103,16 @@ def homography_matrices(d, n, T, K, inv_K):
     return H_t2s, Rn
 
 
-def homography_grid(d, n, T, K, inv_K, H, W, H_t2s=None):
+def homography_grid(d, n, T, K, inv_K, H, W, H_t2s=None, Rn=None):
     """layers.py:206-234 -> (grid [BN,H,W,2], padding_mask bool [B,N,1,H,W]).
 
-    ``H_t2s`` may be supplied to pin the [BN,3,3] algebra (tests that isolate the per-pixel part).
+    ``H_t2s`` (and ``Rn`` [BN,3], the rotated normals of the facing test) may be supplied to pin the [BN,3,3] algebra (tests
+    that isolate the per-pixel part).
     """
     B, N = d.shape
-    H_own, Rn = homography_matrices(d, n, T, K, inv_K)
+    H_own, Rn_own = homography_matrices(d, n, T, K, inv_K)
     H_t2s = H_own if H_t2s is None else H_t2s
+    Rn = Rn_own if Rn is None else Rn.reshape(B * N, 3, 1).to(H_own.dtype)
     pix = _pixel_rays(H, W, d.dtype, d.device).expand(B * N, -1, -1)
     p = torch.matmul(H_t2s, pix)
     facing = (torch.matmul(inv_K[:, :3, :3], pix) * Rn).sum(1) > 0.0
@@ -302,7 +304,7 @@ def warp_and_loss(src, target, logits, sigma, *, warp_type="disp_warp", target_s
                   disp_layered=None, padding_mask=None,
                   distance=None, norm=None, T=None, K=None, inv_K=None,
                   use_mixture_loss=True, automask=False, mask_novel=None,
-                  render_probability=False, dists=None, sampler=bilinear_sample, H_t2s=None):
+                  render_probability=False, dists=None, sampler=bilinear_sample, H_t2s=None, Rn=None):
     """pred_novel_images + photometric part of compute_losses for ONE target view.
 
     Returns dict(rgb_rec, ph_map, ph_loss (=ph_map.mean()), pred, sweep=<all layered tensors>).
@@ -313,7 +315,7 @@ def warp_and_loss(src, target, logits, sigma, *, warp_type="disp_warp", target_s
         mask = padding_mask[:, :, None]
     elif warp_type == "homography_warp":
         ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731  trainer.py:557-559
-        grid, mask = homography_grid(distance, norm, ex(T), ex(K), ex(inv_K), H, W, H_t2s=H_t2s)
+        grid, mask = homography_grid(distance, norm, ex(T), ex(K), ex(inv_K), H, W, H_t2s=H_t2s, Rn=Rn)
     elif warp_type == "depth_warp":  # trainer.py:533-538 (padding_mask never assigned there — SURVEY F4; use the decoder's)
         depths = disp_to_depth(disp_layered, W)
         ex = lambda M: M[:, None].expand(-1, N, -1, -1).reshape(B * N, 4, 4)  # noqa: E731

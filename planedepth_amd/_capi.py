@@ -90,8 +90,12 @@ SIGNATURES = {
     "pd_smooth_loss_bwd_padded": (_I, [_I] * 5 + [_P, _L, _L, _P, _L, _L, _L, _F, _P, _P, _P]),
     "pd_warp_softmax": (_I, [_I] * 4 + [_F, _I, _P, _P, _P, _P]),
     "pd_warp_sum": (_I, [_I] * 4 + [_F, _I, _P, _P, _F, _P, _P]),
+    "pd_post_process_workspace_floats": (ctypes.c_size_t, [_I] * 4),
+    "pd_post_process": (_I, [_I] * 5 + [_P] * 8),
     "pd_pp_combine": (_I, [_I] * 3 + [_P] * 5),
     "pd_cat_flip": (_I, [_I] * 4 + [_P, _P, _I, _P, _P]),
+    "pd_plane_levels_fwd": (_I, [_I, _I, _F, _F, _F, _P, _P, _P, _P]),
+    "pd_plane_levels_bwd": (_I, [_I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
     "pd_crop_grid": (_I, [_I] * 3 + [_P, _P, _P]),
     "pd_selftest_division": (_I, [_F, _I, _F, _F, _P, _P]),
     "pd_experiments": (_I, []),

@@ -3,6 +3,7 @@
 // image.  The reference issues a flip (copy) and a cat (second copy) per tensor; here one kernel writes the doubled
 // batch directly.  `negate_c0` covers the grid tensor, whose x-coordinate channel changes sign under the mirror
 // (trainer.py:258-260).  Pure data movement: bit-exact.
+#include <math.h>
 #include "pd_common.h"
 
 namespace pd {
@@ -52,9 +53,56 @@ __global__ __launch_bounds__(kBlock) void crop_grid_kernel(int H, int W, const i
   o[(long)H * W + i] = linspace_m1_1(h0 + y, full_h);
 }
 
+// The decoders' disparity levels (networks/depth_decoder.py:147-152, networks/plade_net.py:280-285):
+//   disp_layered[b,n] = disp_max * (disp_min / disp_max) ** (levels[b,n] / (no_levels - 1)),  distance = 0.1 * 0.58 * W / disp_layered
+// with levels = arange(no_levels) + the learnt residual.  The reference spends ~5 elementwise launches forward and ~8 backward
+// on these [B,N,1,1] tensors every step; one launch each way here (torch's operation order: the base rounded to fp32 once, the
+// exponent's division, powf, the product).
+__global__ void plane_levels_fwd_kernel(int M, float base, float disp_max, float inv_nm1_den, float dist_num,
+                                        const float* __restrict__ levels, float* __restrict__ disp, float* __restrict__ distance) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= M) return;
+  const float e = levels[i] / inv_nm1_den;
+  const float d = disp_max * powf(base, e);
+  disp[i] = d;
+  if (distance) distance[i] = dist_num / d;
+}
+// d disp / d level = disp ln(base) / (no_levels - 1);  d distance / d disp = -distance / disp
+__global__ void plane_levels_bwd_kernel(int M, float ln_base, float inv_nm1_den, float dist_num, const float* __restrict__ disp,
+                                        const float* __restrict__ g_disp, const float* __restrict__ g_distance,
+                                        float* __restrict__ g_levels) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= M) return;
+  const float d = disp[i];
+  float g = g_disp ? g_disp[i] : 0.0f;
+  if (g_distance) g -= g_distance[i] * dist_num / (d * d);
+  g_levels[i] = g * d * ln_base / inv_nm1_den;
+}
+
 }  // namespace pd
 
 using namespace pd;
+
+extern "C" int pd_plane_levels_fwd(int M, int no_levels, float disp_min, float disp_max, float dist_num, const float* levels,
+                                   float* disp, float* distance, pd_stream_t stream) {
+  PD_REQUIRE(M > 0 && no_levels > 1 && disp_min > 0.0f && disp_max > 0.0f, "bad arguments");
+  PD_REQUIRE(levels && disp, "NULL pointer");
+  const float base = (float)((double)disp_min / (double)disp_max);   // the reference's Python-float quotient, rounded once
+  plane_levels_fwd_kernel<<<ceil_div(M, kBlock), kBlock, 0, (hipStream_t)stream>>>(M, base, disp_max, (float)(no_levels - 1), dist_num,
+                                                                                  levels, disp, distance);
+  return check_launch("plane_levels_fwd_kernel");
+}
+
+extern "C" int pd_plane_levels_bwd(int M, int no_levels, float disp_min, float disp_max, float dist_num, const float* disp,
+                                   const float* g_disp, const float* g_distance, float* g_levels, pd_stream_t stream) {
+  PD_REQUIRE(M > 0 && no_levels > 1 && disp_min > 0.0f && disp_max > 0.0f, "bad arguments");
+  PD_REQUIRE(disp && g_levels && (g_disp || g_distance), "NULL pointer");
+  const float base = (float)((double)disp_min / (double)disp_max);
+  plane_levels_bwd_kernel<<<ceil_div(M, kBlock), kBlock, 0, (hipStream_t)stream>>>(M, logf(base), (float)(no_levels - 1), dist_num, disp,
+                                                                                  g_disp, g_distance, g_levels);
+  return check_launch("plane_levels_bwd_kernel");
+}
 
 extern "C" int pd_crop_grid(int B, int H, int W, const int* params, float* grid, pd_stream_t stream) {
   PD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long)H * W < (1L << 31), "bad shape");

@@ -91,7 +91,7 @@ extern "C" int pd_build_flags(void) {
 #endif
   return f;
 }
-extern "C" int pd_version(void) { (void)pd::switches(); return 250; /* 0.2.5: pd_build_flags (timing-ablation switches need -DPD_DIAGNOSTICS), pd_plane_sweep_bwd_tail, pd_sweep_bwd_tail_fuses, pd_sweep_bwd_plane_adds, pd_sweep_auto_row_eps, PD_BWD_PLANE_ZEROED, PD_IMPL_EXACT_ROWS, PD_ROW_EPS; 0.2.4: pd_uniform_fwd_pair / pd_uniform_bwd_pair (pd_sweep_view), pd_plade_tail_*, PD_PH_MEAN_ZEROED; 0.2.3: segment-stream forward (pd_plane_sweep_fwdstream.hip; PD_IMPL_ROWS1 selects the plane-group forward too), pd_source_hash; 0.2.2: gather backward for per-plane homographies (pd_debug_gather_flags), pd_uniform_gather_pair + PD_BWD_DEFER_GATHER, packed wide-row context; 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
+extern "C" int pd_version(void) { (void)pd::switches(); return 260; /* 0.2.6: pd_post_process (+ _workspace_floats), pd_pp_combine, pd_plane_levels_fwd/bwd, PD_PP_SEG (segment-form post-process warps), homography row products in torch.matmul's rounding order; 0.2.5: pd_build_flags (timing-ablation switches need -DPD_DIAGNOSTICS), pd_plane_sweep_bwd_tail, pd_sweep_bwd_tail_fuses, pd_sweep_bwd_plane_adds, pd_sweep_auto_row_eps, PD_BWD_PLANE_ZEROED, PD_IMPL_EXACT_ROWS, PD_ROW_EPS; 0.2.4: pd_uniform_fwd_pair / pd_uniform_bwd_pair (pd_sweep_view), pd_plade_tail_*, PD_PH_MEAN_ZEROED; 0.2.3: segment-stream forward (pd_plane_sweep_fwdstream.hip; PD_IMPL_ROWS1 selects the plane-group forward too), pd_source_hash; 0.2.2: gather backward for per-plane homographies (pd_debug_gather_flags), pd_uniform_gather_pair + PD_BWD_DEFER_GATHER, packed wide-row context; 0.2.1: row-stream backward, PD_IMPL_UNIFORM_DIRECT, pd_experiments, environment switches read once; 0.2.0: PD_HOMO_UNIFORM, PD_BWD_ACCUMULATE, pd_homography_matrices_*, pd_masked_photometric_*, pd_crop_grid; 0.1.1: fused mean of ph_map */ }
 extern "C" const char* pd_last_error(void) { return pd::g_err; }
 
 // What this binary was compiled from.  The marker string is also what __graft_entry__.build() looks for in the file's bytes

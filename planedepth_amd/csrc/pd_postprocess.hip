@@ -283,8 +283,10 @@ __global__ __launch_bounds__(kWave) void warp_sum_rows_kernel(WarpArgs a, float 
 // stay in registers (2 x N <= 128 VGPRs), so the planes are sampled ONCE: the kernels above sample twice (statistics, then
 // probabilities).  FLIP reads the same three columns mirrored: the taps of pixels x, x+1 at mirrored columns c, c+1, c+2 are the
 // actual columns W-1-c .. W-3-c, one 12-byte load at W-3-c in reverse order.  Exactness as in the forward: planes whose
-// frac(s d) is within irregular_tol of an integer, and segments in which a lane's load would START at column -3 .. -1 (such a
-// load reads as zeros as a whole), take the per-pixel path of the row kernels above (exact floor(ix), 8-byte pairs).
+// frac(s d) is within irregular_tol of an integer take the per-pixel path of the row kernels above (exact floor(ix), 8-byte
+// pairs).  A lane whose load would START at column -2 or -1 (such a load reads as zeros as a whole although its last columns are
+// inside the row; at -3 its last dword passes the 32-bit range check and reads the neighbouring row) aims it at column 0 and
+// shifts the three values into place (seg_load) — no per-segment fallback for negative shifts.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSegPix = 2 * kWave;   // pixels per wave
 constexpr int kSegWaves = 4;         // waves per workgroup (independent items)
@@ -307,11 +309,27 @@ __device__ __forceinline__ SegPlane seg_plane(const WarpArgs& a, int b, int n, i
   const float tol = irregular_tol(a.W);
   const bool inview = fabsf(p.sd) < (float)(a.W + 1);
   const bool irr = inview && (fr < tol || fr > 1.0f - tol);
-  // first columns of the lanes' loads: c0 + 2 i (plain) or W - 3 - c0 - 2 i (mirrored), i = 0 .. 63
-  const int c0 = xseg + p.k;
-  const int lo = FLIP ? a.W - 3 - c0 - 2 * (kWave - 1) : c0, hi = FLIP ? a.W - 3 - c0 : c0 + 2 * (kWave - 1);
-  p.general = irr || (lo < 0 && hi >= -3);
+  p.general = irr;   // (a load that would start left of the row is re-aimed per lane: seg_load)
   return p;
+}
+
+// Where a lane's 12-byte load goes when its three columns start at `start` (may be negative): columns left of the row are zero
+// padding, but the hardware drops a load that STARTS there as a whole (and lets the dword at byte offset -4 through).  start in
+// {-2, -1}: load columns 0 .. 2 and shift them right by adj = -start when the values are used; start <= -3: nothing of it is
+// inside the row — an offset beyond every row (the range check returns zeros).
+struct SegAim { unsigned off; int adj; };
+__device__ __forceinline__ SegAim seg_aim(int start) {
+  SegAim m;
+  m.adj = (start < 0 && start >= -2) ? -start : 0;
+  m.off = (start <= -3) ? 0x7FFFFFF0u : ((unsigned)(start + m.adj) << 2);
+  return m;
+}
+__device__ __forceinline__ v3f_pp seg_place(const v3f_pp& t, int adj) {
+  v3f_pp o;
+  o.x = (adj == 0) ? t.x : 0.0f;
+  o.y = (adj == 0) ? t.y : ((adj == 1) ? t.x : 0.0f);
+  o.z = (adj == 0) ? t.z : ((adj == 1) ? t.y : t.x);
+  return o;
 }
 
 // the two samples of a lane on one plane from its loaded taps (A = first live row, B = second)
@@ -343,14 +361,16 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
   {
     SegPlane sp[kGroup];
     v3f_pp ta[kGroup], tb[kGroup];
+    int adj[kGroup];
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
       const int n = min(n0 + u, a.N - 1);
       sp[u] = seg_plane<FLIP>(a, b, n, xseg);
       const float* pl = pb + (long)n * HW;
-      const unsigned off = (unsigned)(FLIP ? a.W - 3 - (x0 + sp[u].k) : x0 + sp[u].k) << 2;
-      ta[u] = pp_load3(pp_row_rsrc(pl + (long)r.ra * a.W, a.W), off);
-      if (NR == 2) tb[u] = pp_load3(pp_row_rsrc(pl + (long)r.rb * a.W, a.W), off);
+      const SegAim aim = seg_aim(FLIP ? a.W - 3 - (x0 + sp[u].k) : x0 + sp[u].k);
+      adj[u] = aim.adj;
+      ta[u] = pp_load3(pp_row_rsrc(pl + (long)r.ra * a.W, a.W), aim.off);
+      if (NR == 2) tb[u] = pp_load3(pp_row_rsrc(pl + (long)r.rb * a.W, a.W), aim.off);
       else tb[u] = ta[u];
     }
 #pragma unroll
@@ -364,7 +384,7 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
         rows_group<FLIP, NR, 1>(a, pb, r, b, n, x0 + 1, HW, o1);
         v0 = o0[0]; v1 = o1[0];
       } else {
-        seg_values<FLIP, NR>(a, r, sp[u], x0f, ta[u], tb[u], v0, v1);
+        seg_values<FLIP, NR>(a, r, sp[u], x0f, seg_place(ta[u], adj[u]), seg_place(tb[u], adj[u]), v0, v1);
       }
       f(n, v0, v1);
       }
@@ -432,8 +452,10 @@ __device__ __forceinline__ void seg_softmax_body(const WarpArgs& a, const SegIte
     if (n < a.N) *reinterpret_cast<float2*>(ob + (long)n * HW) = make_float2(l0[n] * i0, l1[n] * i1);
 }
 
+// (NMAX = 64: 128 registers of samples; bounded to three waves per SIMD — unbounded the allocator takes 206 VGPRs = two waves,
+// and the kernel is no faster than the row form)
 template <bool FLIP, int NMAX>
-__global__ __launch_bounds__(kSegWaves* kWave) void warp_softmax_seg_kernel(WarpArgs a, int B, float* __restrict__ out) {
+__global__ __launch_bounds__(kSegWaves* kWave, NMAX > 32 ? 3 : 4) void warp_softmax_seg_kernel(WarpArgs a, int B, float* __restrict__ out) {
   const SegItem it = seg_item(a, B);
   if (!it.on) return;
   const RowTaps r = row_taps(it.y, a.H);   // wave-uniform
@@ -523,6 +545,8 @@ extern "C" int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags
     const dim3 g((unsigned)(((long)B * H * nseg + kSegWaves - 1) / kSegWaves));
     if (N <= 32) { if (a.flip) warp_softmax_seg_kernel<true, 32><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out);
                    else        warp_softmax_seg_kernel<false, 32><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out); }
+    else if (N <= 52) { if (a.flip) warp_softmax_seg_kernel<true, 52><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out);   // (49 planes)
+                        else        warp_softmax_seg_kernel<false, 52><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out); }
     else         { if (a.flip) warp_softmax_seg_kernel<true, 64><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out);
                    else        warp_softmax_seg_kernel<false, 64><<<g, kSegWaves * kWave, 0, (hipStream_t)stream>>>(a, B, out); }
     return check_launch("warp_softmax_seg_kernel");
@@ -569,4 +593,31 @@ extern "C" int pd_pp_combine(int B, int H, int W, const float* disp, const float
   PD_REQUIRE(disp && o_fr && o_l && disp_pp, "NULL pointer");
   pp_combine_kernel<<<(unsigned)(((long)B * H * W + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, disp, o_fr, o_l, disp_pp);
   return check_launch("pp_combine_kernel");
+}
+
+// The whole of trainer.py:443-465 behind one call: six launches on `stream`, no host work in between (as separate operator
+// calls the ~0.2 ms of kernels at 8 x 49 x 192 x 640 were paced by the host's per-call overhead).
+extern "C" size_t pd_post_process_workspace_floats(int B, int N, int H, int W) {
+  return (size_t)B * N * H * W + (size_t)2 * B * H * W;
+}
+
+extern "C" int pd_post_process(int B, int N, int H, int W, int flags, const float* logits, const float* probability,
+                               const float* disp, const float* disp_layered, float* workspace, float* disp_pp, float* mask_novel,
+                               pd_stream_t stream) {
+  PD_REQUIRE(B > 0 && N > 0 && H > 0 && W > 1, "bad shape");
+  PD_REQUIRE((flags & ~PD_PP_DISP_DENSE) == 0, "unknown flags");
+  PD_REQUIRE(logits && probability && disp && disp_layered && workspace && disp_pp && mask_novel, "NULL pointer");
+  const size_t P = (size_t)H * W, img = (size_t)N * P;
+  const float* dl_r = disp_layered;                                                              // the image's planes
+  const float* dl_l = disp_layered + ((flags & PD_PP_DISP_DENSE) ? (size_t)B * img : (size_t)B * N);   // the mirrored image's
+  float* planes = workspace;
+  float* o_l = workspace + (size_t)B * img;
+  float* o_fr = o_l + (size_t)B * P;
+  int rc;
+  if ((rc = pd_warp_softmax(B, N, H, W, +1.0f, flags, logits, dl_r, planes, stream))) return rc;                         // :443-446
+  if ((rc = pd_warp_sum(B, N, H, W, -1.0f, flags, planes, dl_l, 1.0f, o_l, stream))) return rc;                         // :447-449
+  if ((rc = pd_warp_softmax(B, N, H, W, -1.0f, flags | PD_PP_FLIP_SRC, logits + (size_t)B * img, dl_l, planes, stream))) return rc;   // :451-453
+  if ((rc = pd_warp_sum(B, N, H, W, +1.0f, flags, planes, dl_r, 1.0f, o_fr, stream))) return rc;                        // :454-456
+  if ((rc = pd_pp_combine(B, H, W, disp, o_fr, o_l, disp_pp, stream))) return rc;                                        // :458-461
+  return pd_warp_sum(B, N, H, W, +1.0f, flags, probability, dl_r, 1.0f, mask_novel, stream);                             // :463-465
 }

@@ -22,13 +22,14 @@ from .sweep import (  # noqa: F401
     plane_sweep_multi, _flags, _SIGN, _per_plane_view, _FirstColumn, plane_sweep_disp,
     homography_matrices, _HomographyMatrices, homography_matrices_fused, plane_sweep_homography, _stereo_rows_sweep, plane_sweep_layers)
 from .tails import (  # noqa: F401
+    _PlaneLevels, plane_disparities,
     _DecoderTail, decoder_tail, _PladeTail, _RAY_NORM, camera_ray_norm, _camera_ray_norm,
     plade_tail)
 from .losses import (  # noqa: F401
     _SSIM, ssim, _ReprojLoss, reprojection_loss, _MixtureNLL, multimodal_loss,
     _MaskedPhotometric, masked_photometric, _row_strided, _SmoothLoss, smooth_loss_disp)
 from .postprocess import (  # noqa: F401
-    _pp_disp, warp_softmax, warp_sum, pp_combine, post_process_disp, cat_flip,
+    _pp_disp, warp_softmax, warp_sum, pp_combine, post_process_disp, post_process_disp_stepwise, cat_flip,
     crop_grid)
 from .geometry import (  # noqa: F401
     _Backproject, backproject_depth, _Project3D, project_3d, _HomographyGrid, homography_grid,

@@ -72,7 +72,28 @@ def pp_combine(disp, o_fr, o_l):
 
 
 def post_process_disp(logits, probability, disp, disp_layered):
-    """trainer.py:421-466 given the fixed model's outputs for cat([image, mirrored image]) -> (disp_pp, mask_novel)."""
+    """trainer.py:421-466 given the fixed model's outputs for cat([image, mirrored image]) -> (disp_pp, mask_novel): ONE C-ABI
+    call (pd_post_process: two warp-softmaxes, three warp-sums, the blend — six launches, no host work in between)."""
+    lib = C.load()
+    C.require_gpu_tensor("logits", logits)
+    B2, N, H, W = logits.shape
+    B = B2 // 2
+    with torch.no_grad():
+        prob = probability.tensor() if hasattr(probability, "tensor") else probability
+        logits, prob, disp = (_contig(t.detach()) for t in (logits, prob, disp))
+        dl, flags = _pp_disp(disp_layered.detach(), B2, N, H, W)
+        dev = logits.device
+        ws = torch.empty(lib.pd_post_process_workspace_floats(B, N, H, W), device=dev, dtype=torch.float32)
+        disp_pp = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+        mask_novel = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+        with C.on_device(dev):
+            C.check(lib.pd_post_process(B, N, H, W, flags, C.ptr(logits), C.ptr(prob), C.ptr(disp), C.ptr(dl), C.ptr(ws),
+                                        C.ptr(disp_pp), C.ptr(mask_novel), C.stream_handle(dev)), "pd_post_process")
+    return disp_pp, mask_novel
+
+
+def post_process_disp_stepwise(logits, probability, disp, disp_layered):
+    """The same through the single operators (cross-check of pd_post_process; what round 5 ran)."""
     B = probability.shape[0] // 2
     with torch.no_grad():
         dl_r, dl_l = disp_layered[:B], disp_layered[B:]

@@ -263,4 +263,44 @@ def plade_tail(raw_logits, raw_sigma, disp_layered, ray_norm=None, use_mixture_l
     return logits, dists, (sigma if use_mixture_loss else None), disp, depth, layers
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The decoders' disparity levels (networks/depth_decoder.py:147-152, networks/plade_net.py:280-285)
+# ---------------------------------------------------------------------------------------------------------------------
+class _PlaneLevels(torch.autograd.Function):
+    """levels [B,N] -> (disp [B,N], distance [B,N]); one launch each way instead of ~5 + ~8 elementwise ones."""
+
+    @staticmethod
+    def forward(ctx, levels, no_levels, disp_min, disp_max, dist_num):
+        lib = C.load()
+        C.require_gpu_tensor("levels", levels)
+        levels = _contig(levels)
+        disp, distance = torch.empty_like(levels), torch.empty_like(levels)
+        with C.on_device(levels.device):
+            C.check(lib.pd_plane_levels_fwd(levels.numel(), int(no_levels), float(disp_min), float(disp_max), float(dist_num),
+                                            C.ptr(levels), C.ptr(disp), C.ptr(distance), C.stream_handle(levels.device)),
+                    "pd_plane_levels_fwd")
+        ctx.save_for_backward(disp)
+        ctx.cfg = (int(no_levels), float(disp_min), float(disp_max), float(dist_num))
+        return disp, distance
+
+    @staticmethod
+    def backward(ctx, g_disp, g_distance):
+        lib = C.load()
+        disp, = ctx.saved_tensors
+        g = torch.empty_like(disp)
+        g_disp, g_distance = _contig(g_disp), _contig(g_distance)
+        with C.on_device(disp.device):
+            C.check(lib.pd_plane_levels_bwd(disp.numel(), *ctx.cfg, C.ptr(disp), C.ptr(g_disp), C.ptr(g_distance), C.ptr(g),
+                                            C.stream_handle(disp.device)), "pd_plane_levels_bwd")
+        return g, None, None, None, None
+
+
+def plane_disparities(levels, disp_min, disp_max, width, no_levels=None):
+    """``disp_max * (disp_min / disp_max) ** (levels / (no_levels - 1))`` and ``0.1 * 0.58 * W / that`` of the decoders
+    (networks/depth_decoder.py:150-152): ``levels`` [B,N,1,1] or [B,N] = arange(no_levels) (+ the plane residual).  Returns
+    (disp_layered [B,N,1,1] — expand it over H, W as the decoder does —, distance [B,N]); gradients flow into ``levels``."""
+    B, N = levels.shape[:2]
+    disp, distance = _PlaneLevels.apply(levels.reshape(B, N), N if no_levels is None else no_levels, disp_min, disp_max,
+                                        0.1 * 0.58 * width)
+    return disp.reshape(B, N, 1, 1), distance
 

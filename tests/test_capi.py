@@ -76,6 +76,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.pd_smooth_loss_fwd(1, 3, 1, 8, None, 0, 0, None, 0, 0, 0, 1.0, None, None) == 1
     assert lib.pd_warp_sum(1, 4, 8, 8, 1.0, 0, None, None, 1.0, None, None) == 1
     assert lib.pd_pp_combine(1, 8, 8, None, None, None, None, None) == 1
+    assert lib.pd_post_process(1, 4, 8, 8, 0, None, None, None, None, None, None, None, None) == 1
+    assert lib.pd_post_process_workspace_floats(2, 4, 8, 8) == 2 * 4 * 64 + 2 * 2 * 64
+    assert lib.pd_plane_levels_fwd(4, 4, 2.0, 300.0, 1.0, None, None, None, None) == 1
+    assert lib.pd_plane_levels_bwd(4, 4, 2.0, 300.0, 1.0, None, None, None, None, None) == 1
     assert lib.pd_cat_flip(0, 3, 8, 8, None, None, 0, None, None) == 1
     assert lib.pd_mixture_nll_fwd(1, 4, 8, 8, 1, None, None, None, None, None) == 1
     assert lib.pd_decoder_tail_bwd_workspace_floats(2, 49, 192, 640) == 2 * 480 * 49
