@@ -887,6 +887,15 @@ def main():
     pre_timed["steps_total"] = pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"]
     if "copy" not in args.skip_context:
         hbm_copy = measured_copy_rate(device)
+    # Host hygiene for the 5 ms windows: an eager step costs the host 0.17-0.24 ms of the 0.27 ms the device needs, so a pause of
+    # Python's cyclic collector (a generation-2 pass walks everything the set-up legs left behind) lands in a window twice: as
+    # the pause itself, and as the ~50 slower steps after any idle gap long enough for the device to clock down (measured: a
+    # collect() right in front of the warm-up steps cost the first window 10 %).  Collected and frozen HERE, with the launch
+    # probe's 124 steps still ahead; switched off for the timed windows below; --keep_gc leaves it alone (A/B).
+    import gc
+    if not args.keep_gc:
+        gc.collect()
+        gc.freeze()
     # ---- how the timed steps are issued ----
     # every rank must take the same path through the probe's collectives: a capture that failed anywhere means eager everywhere
     if args.launch in ("auto", "graph") and parallel.max_over_ranks(0.0 if graph_step is not None else 1.0, device) > 0.0:
@@ -916,13 +925,8 @@ def main():
     pre_timed["launch_probe_steps"] = 4 * 31 if (launch_probe and "steps_each" in launch_probe) else 0
     pre_timed["steps_total"] = (pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"] +
                                 pre_timed["launch_probe_steps"])
-    # Host hygiene for the 5 ms windows: an eager step costs the host 0.17-0.24 ms of the 0.27 ms the device needs, so a pause of
-    # Python's cyclic collector (a generation-2 pass walks everything the set-up legs left behind) lands in a window as -25 %.
-    # Collected once, frozen and switched off for the timed windows; --keep_gc leaves it on (A/B).
-    import gc
+    # (the collector is off from here to the end of the timed windows: see the collect / freeze above the launch probe)
     if not args.keep_gc:
-        gc.collect()
-        gc.freeze()
         gc.disable()
     for _ in range(args.warmup):
         step()
