@@ -17,7 +17,7 @@
  *     device (hipSetDevice / torch.cuda.device by the caller) and keep nothing between calls except per-device caches of
  *     device facts — the LDS a workgroup can be given, the dynamic-LDS limit already granted to a kernel — held in
  *     atomics indexed by the device ordinal (the rare raise is serialised by a mutex).  The few process-environment
- *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS, PD_FWD_STREAM, PD_ROW_EPS) are read ONCE, when
+ *     tuning switches (PD_NO_ROWPAIR, PD_ROW_WAVES, PD_UNI_CHUNK, PD_PP_ROWS, PD_PP_SEG, PD_PP_CHAIN, PD_FWD_STREAM, PD_ROW_EPS) are read ONCE, when
  *     the library is first used, never on the launch path; kernel selection per call goes through pd_sweep_desc.impl.
  */
 #ifndef PLANEDEPTH_HIP_H
@@ -367,7 +367,9 @@ int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* 
 int pd_pp_combine(int B, int H, int W, const float* disp, const float* o_fr, const float* o_l, float* disp_pp,
                   pd_stream_t stream);
 
-/* trainer.py:443-465 behind ONE call (six launches on `stream`): logits / probability [2B,N,H,W] and disp [2B,1,H,W] are the fixed
+/* trainer.py:443-465 behind ONE call (three launches on `stream` where a row's softmax fits the CU's LDS — per-plane disparities,
+ * even W <= 1024, N <= 64: the "row chains" keep softmax(warp(logits)) in LDS and take the second warp's plane sum from there, the
+ * [B,N,H,W] intermediate never reaches memory; PD_PP_CHAIN=0 or any other shape: the six launches of the single warps): logits / probability [2B,N,H,W] and disp [2B,1,H,W] are the fixed
  * model's outputs for cat([image, mirrored image]) (B = half of that batch; of `probability` only the first B images are read),
  * disp_layered [2B,N] or, PD_PP_DISP_DENSE, [2B,N,H,W]; workspace: pd_post_process_workspace_floats floats;
  * -> disp_pp, mask_novel [B,1,H,W]. */

@@ -9,4 +9,4 @@ from .layers import (SSIM, BackprojectDepth, HomographyWarp, Project3D, disp_to_
 from .trainer_path import (add_flip_right_inputs, compute_losses, compute_reprojection_loss, generate_post_process_disp,  # noqa: F401
                            patch_trainer, pred_novel_images, pred_self_images)
 
-__version__ = "0.2.5"   # = pd_version() 250 of the library (tests/test_capi.py checks that they agree)
+__version__ = "0.2.6"   # = pd_version() 260 of the library (tests/test_capi.py checks that they agree)

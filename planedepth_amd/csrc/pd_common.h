@@ -25,6 +25,7 @@ struct Switches {
   bool no_rowpair;    // PD_NO_ROWPAIR=1: forward without row pairs
   bool pp_rows_off;   // PD_PP_ROWS=0: post-process kernels in per-pixel gather form
   bool pp_seg_off;    // PD_PP_SEG=0: post-process kernels without the segment form (one pixel per lane, planes sampled twice)
+  bool pp_chain_off;  // PD_PP_CHAIN=0: pd_post_process through the single warps (the softmax's [B,N,H,W] intermediate in memory)
   int row_waves;      // PD_ROW_WAVES=n: waves per row workgroup of the row-shift kernels (0 = default)
   int uni_chunk;      // PD_UNI_CHUNK=n: images per launch of the plane-uniform backward passes (0 = whole batch)
   bool fwd_stream;    // PD_FWD_STREAM=0: the headline forward on the plane-group row-shift kernel instead of the segment-stream one

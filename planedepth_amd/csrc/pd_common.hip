@@ -22,6 +22,7 @@ const Switches& switches() {
     v.no_rowpair = getenv("PD_NO_ROWPAIR") != nullptr;
     v.pp_rows_off = num("PD_PP_ROWS") == 0;
     v.pp_seg_off = num("PD_PP_SEG") == 0 || v.pp_rows_off;
+    v.pp_chain_off = num("PD_PP_CHAIN") == 0;
     v.row_waves = num("PD_ROW_WAVES") > 0 ? num("PD_ROW_WAVES") : 0;
     v.uni_chunk = num("PD_UNI_CHUNK") > 0 ? num("PD_UNI_CHUNK") : 0;
     v.fwd_stream = num("PD_FWD_STREAM") != 0;

@@ -354,17 +354,20 @@ __device__ __forceinline__ void seg_values(const WarpArgs& a, const RowTaps& r, 
 }
 
 // f(n, v0, v1) for every plane of the lane's two pixels, in plane order; loads of kGroup planes in flight
-template <bool FLIP, int NR, typename F>
+template <bool FLIP, int NR, int G, typename F>
 __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
-                                          int x0, int HW, int n0, F& f) {
+                                          int x0, int HW, int n0, F& f, int nbase = 0, int nend = 1 << 30) {
+  // planes nbase + n0 .. nbase + n0 + G - 1 (those below min(nend, N)); the callback sees the index RELATIVE to nbase, which is a
+  // compile-time constant where the caller's loop is unrolled
   const float x0f = (float)x0;
+  const int nlim = min(nend, a.N);
   {
-    SegPlane sp[kGroup];
-    v3f_pp ta[kGroup], tb[kGroup];
-    int adj[kGroup];
+    SegPlane sp[G];
+    v3f_pp ta[G], tb[G];
+    int adj[G];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) {
-      const int n = min(n0 + u, a.N - 1);
+    for (int u = 0; u < G; ++u) {
+      const int n = min(nbase + n0 + u, a.N - 1);
       sp[u] = seg_plane<FLIP>(a, b, n, xseg);
       const float* pl = pb + (long)n * HW;
       const SegAim aim = seg_aim(FLIP ? a.W - 3 - (x0 + sp[u].k) : x0 + sp[u].k);
@@ -374,9 +377,9 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
       else tb[u] = ta[u];
     }
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) {
-      const int n = n0 + u;
-      if (n < a.N) {   // (uniform)
+    for (int u = 0; u < G; ++u) {
+      const int n = nbase + n0 + u;
+      if (n < nlim) {   // (uniform)
       float v0, v1;
       if (sp[u].general) {   // (uniform) exact per-pixel path
         float o0[1], o1[1];
@@ -386,7 +389,7 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
       } else {
         seg_values<FLIP, NR>(a, r, sp[u], x0f, seg_place(ta[u], adj[u]), seg_place(tb[u], adj[u]), v0, v1);
       }
-      f(n, v0, v1);
+      f(n0 + u, v0, v1);
       }
     }
   }
@@ -394,18 +397,18 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
 // NMAX > 0: the plane loop fully unrolled over NMAX >= N planes, group by group through an index pack (the callback then sees
 // compile-time plane indices and its per-plane state stays in registers; a `break` in a pragma-unrolled loop left it in scratch);
 // NMAX == 0: a run-time loop
-template <bool FLIP, int NR, typename F, int... G>
+template <bool FLIP, int NR, int G, typename F, int... I>
 __device__ __forceinline__ void seg_groups(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
-                                           int x0, int HW, F& f, std::integer_sequence<int, G...>) {
-  ((G * kGroup < a.N ? seg_group<FLIP, NR>(a, pb, r, b, xseg, x0, HW, G * kGroup, f) : (void)0), ...);
+                                           int x0, int HW, F& f, std::integer_sequence<int, I...>, int nbase, int nend) {
+  ((nbase + I * G < min(nend, a.N) ? seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, I * G, f, nbase, nend) : (void)0), ...);
 }
-template <bool FLIP, int NR, int NMAX, typename F>
+template <bool FLIP, int NR, int NMAX, typename F, int G = kGroup>   // G planes' loads in flight per wave
 __device__ __forceinline__ void seg_for_each(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
-                                             int x0, int HW, F f) {
+                                             int x0, int HW, F f, int nbase = 0, int nend = 1 << 30) {
   if constexpr (NMAX > 0) {
-    seg_groups<FLIP, NR>(a, pb, r, b, xseg, x0, HW, f, std::make_integer_sequence<int, NMAX / kGroup>{});
+    seg_groups<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, f, std::make_integer_sequence<int, (NMAX + G - 1) / G>{}, nbase, nend);
   } else {
-    for (int n0 = 0; n0 < a.N; n0 += kGroup) seg_group<FLIP, NR>(a, pb, r, b, xseg, x0, HW, n0, f);
+    for (int n0 = 0; n0 < a.N; n0 += G) seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, n0, f);
   }
 }
 
@@ -476,6 +479,229 @@ __global__ __launch_bounds__(kSegWaves* kWave) void warp_sum_seg_kernel(WarpArgs
   if (r.wb != 0.0f) seg_for_each<FLIP, 2, 0>(a, pb, r, it.b, it.xseg, x0, HW, add);
   else              seg_for_each<FLIP, 1, 0>(a, pb, r, it.b, it.xseg, x0, HW, add);
   if (x0 < a.W) *reinterpret_cast<float2*>(out + (long)it.b * HW + (long)it.y * a.W + x0) = make_float2(fminf(acc0, cap), fminf(acc1, cap));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row chains (round 6): softmax(warp(logits)) never leaves the CU.  trainer.py:443-449 / 451-456 warp the logits, take the softmax
+// over the planes, warp THAT again and sum over the planes; with per-plane disparities both warps are horizontal, so the second
+// one samples, for a target row, the softmax's rows ya / yb only — and its horizontal part does not depend on the target row:
+//   S_r(x) = sum_n hinterp(softmax_row_r[n], x + s2 d2_n),        o(y, x) = min(1, wa_y S_ya(x) + wb_y S_yb(x))
+// (the vertical weights factor out of the plane sum; fp32 reassociation only).  One workgroup per (chain, image, row r): the
+// segment form samples the row's logits (all planes of a pixel pair in registers), writes the normalised probabilities into an
+// LDS row buffer [N][W + 4] (125 KB at 49 x 640: one workgroup per CU) and then takes S_r from LDS with the exact per-pixel taps
+// (make_col_tap; zero guard cells are the padding).  The [B,N,H,W] intermediate of the two-kernel form — written and read back,
+// twice per call: 4 N of the path's 7 N planes of traffic — is gone; what remains are S rows, and pp_rows_finish_kernel applies the
+// vertical weights, the clamp and the disp_pp blend.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PD_PP_CHAIN_G
+#define PD_PP_CHAIN_G 4
+#endif
+#ifndef PD_PP_CHAIN_SPLIT
+#define PD_PP_CHAIN_SPLIT 1   // 0: one wave per segment (A/B)
+#endif
+struct ChainArgs {
+  WarpArgs w[2];          // first warp of chain 0 (image, plain) / chain 1 (mirrored image, PD_PP_FLIP_SRC)
+  const float* disp2[2];  // the second warp's disparities [B,N] and sign
+  float sign2[2];
+  float* S[2];            // [B,1,H,W] each
+  int B;
+};
+
+template <bool FLIP, int NR, int NMAX>
+__device__ __forceinline__ void chain_row(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int b, int y,
+                                          const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
+  const int W = a.W, N = a.N, HW = a.H * a.W, RS = W + 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* pb = a.planes + (long)b * N * HW;
+  for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) {   // zero guard cells: columns -2, -1, W, W + 1 of every plane
+    const int n = i >> 2, g = i & 3;
+    lds[n * RS + (g < 2 ? g : W + g)] = 0.0f;
+  }
+  // (one segment per wave, no loop around the unrolled planes: inside a loop every plane's shift and descriptors are
+  // loop-invariant, get hoisted, and 5 500 spilled SGPRs later the kernel lives in scratch)
+  const int seg = wave;
+  {
+    const int xseg = seg * kSegPix, x0 = xseg + 2 * lane;
+    float l0[NMAX], l1[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) l0[n] = l1[n] = -INFINITY;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    auto keep = [&](int n, float v0, float v1) {
+#pragma unroll
+      for (int q = 0; q < NMAX; ++q) if (q == n) { l0[q] = v0; l1[q] = v1; }
+      m0 = fmaxf(m0, v0); m1 = fmaxf(m1, v1);
+    };
+    // (one workgroup of nseg waves per CU: the loads in flight have to come from each wave — PD_PP_CHAIN_G planes at a time)
+    seg_for_each<FLIP, NR, NMAX, decltype(keep), PD_PP_CHAIN_G>(a, pb, r, b, xseg, x0, HW, keep);
+    float Z0 = 0.0f, Z1 = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      l0[n] = __expf(l0[n] - m0); l1[n] = __expf(l1[n] - m1);
+      Z0 += l0[n]; Z1 += l1[n];
+    }
+    if (x0 < W) {
+      const float i0 = 1.0f / Z0, i1 = 1.0f / Z1;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < N) *reinterpret_cast<float2*>(lds + n * RS + 2 + x0) = make_float2(l0[n] * i0, l1[n] * i1);
+    }
+  }
+  __syncthreads();
+  const float lim = (float)(W + 2);
+  {
+    const int x0 = seg * kSegPix + 2 * lane;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int n = 0; n < N; ++n) {
+      const float sdr = sign2 * disp2[b * N + n];
+      const float sd = (sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f) ? -lim : lim);   // plane_shift's clamp (NaN -> +lim)
+      const float* row = lds + n * RS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const ColTap t = make_col_tap((float)(x0 + i) + sd, a.Wm1, a.rcpWm1);
+        const int cell = min(max(t.x0, -2), W) + 2;
+        const float v = row[cell] * t.w0 + row[cell + 1] * t.w1;
+        if (i == 0) acc0 += v; else acc1 += v;
+      }
+    }
+    if (x0 < W) *reinterpret_cast<float2*>(S + (long)b * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+  }
+}
+
+// The same with the planes of a segment dealt to P waves (P x nseg waves per workgroup: 15 at W = 640).  One workgroup per CU is
+// all the row buffer allows, so the loads in flight and the issue slots of four SIMDs have to come from its own waves: with one
+// wave per segment (5 per CU) the kernel ran at 1.2 TB/s.  Wave (seg, part) samples planes [part * NPART, (part + 1) * NPART),
+// leaves (max, sum of exp relative to it) per pixel in LDS, takes the segment's max / sum from the P parts after a barrier, writes
+// its planes' probabilities, and after the next barrier sums ITS planes' taps of the second warp; part 0 adds the partial sums.
+template <bool FLIP, int NR, int NPART, int P>
+__device__ __forceinline__ void chain_row_split(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int b, int y,
+                                                const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
+  const int W = a.W, N = a.N, HW = a.H * a.W, RS = W + 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (W + kSegPix - 1) / kSegPix;
+  const int seg = wave % nseg, part = wave / nseg;
+  const int nb = part * NPART, ne = min(nb + NPART, N);
+  const int SW = nseg * kSegPix;                                 // stats row: one float2 per pixel of the padded row and part
+  float2* stats = reinterpret_cast<float2*>(lds + (size_t)N * RS);
+  const float* pb = a.planes + (long)b * N * HW;
+  for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) {   // zero guard cells: columns -2, -1, W, W + 1 of every plane
+    const int n = i >> 2, g = i & 3;
+    lds[n * RS + (g < 2 ? g : W + g)] = 0.0f;
+  }
+  const int xseg = seg * kSegPix, x0 = xseg + 2 * lane;
+  float l0[NPART], l1[NPART];
+#pragma unroll
+  for (int j = 0; j < NPART; ++j) l0[j] = l1[j] = -INFINITY;
+  float m0 = -INFINITY, m1 = -INFINITY;
+  auto keep = [&](int j, float v0, float v1) {
+#pragma unroll
+    for (int q = 0; q < NPART; ++q) if (q == j) { l0[q] = v0; l1[q] = v1; }
+    m0 = fmaxf(m0, v0); m1 = fmaxf(m1, v1);
+  };
+  seg_for_each<FLIP, NR, NPART, decltype(keep), kGroup>(a, pb, r, b, xseg, x0, HW, keep, nb, ne);
+  float Z0 = 0.0f, Z1 = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NPART; ++j) {   // (slots beyond the part's planes hold -inf: exp gives 0; a part without planes: m = -inf, Z = 0)
+    l0[j] = (m0 == -INFINITY) ? 0.0f : __expf(l0[j] - m0);
+    l1[j] = (m1 == -INFINITY) ? 0.0f : __expf(l1[j] - m1);
+    Z0 += l0[j]; Z1 += l1[j];
+  }
+  stats[part * SW + x0] = make_float2(m0, Z0);
+  stats[part * SW + x0 + 1] = make_float2(m1, Z1);
+  __syncthreads();
+  float M0 = -INFINITY, M1 = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < P; ++q) { M0 = fmaxf(M0, stats[q * SW + x0].x); M1 = fmaxf(M1, stats[q * SW + x0 + 1].x); }
+  float T0 = 0.0f, T1 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const float2 s0 = stats[q * SW + x0], s1 = stats[q * SW + x0 + 1];
+    T0 += (s0.x == -INFINITY) ? 0.0f : s0.y * __expf(s0.x - M0);
+    T1 += (s1.x == -INFINITY) ? 0.0f : s1.y * __expf(s1.x - M1);
+  }
+  const float c0 = (m0 == -INFINITY) ? 0.0f : __expf(m0 - M0) / T0, c1 = (m1 == -INFINITY) ? 0.0f : __expf(m1 - M1) / T1;
+  if (x0 < W) {
+#pragma unroll
+    for (int j = 0; j < NPART; ++j)
+      if (nb + j < ne) *reinterpret_cast<float2*>(lds + (nb + j) * RS + 2 + x0) = make_float2(l0[j] * c0, l1[j] * c1);
+  }
+  __syncthreads();   // (every wave has read the stats by now: the buffer is free for the partial sums)
+  const float lim = (float)(W + 2);
+  float acc0 = 0.0f, acc1 = 0.0f;
+  for (int n = nb; n < ne; ++n) {
+    const float sdr = sign2 * disp2[b * N + n];
+    const float sd = (sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f) ? -lim : lim);   // plane_shift's clamp (NaN -> +lim)
+    const float* row = lds + n * RS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const ColTap t = make_col_tap((float)(x0 + i) + sd, a.Wm1, a.rcpWm1);
+      const int cell = min(max(t.x0, -2), W) + 2;
+      const float v = row[cell] * t.w0 + row[cell + 1] * t.w1;
+      if (i == 0) acc0 += v; else acc1 += v;
+    }
+  }
+  if (part > 0) stats[part * SW + x0] = make_float2(acc0, acc1);
+  __syncthreads();
+  if (part == 0 && x0 < W) {
+#pragma unroll
+    for (int q = 1; q < P; ++q) { const float2 o = stats[q * SW + x0]; acc0 += o.x; acc1 += o.y; }
+    *reinterpret_cast<float2*>(S + (long)b * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+  }
+}
+
+template <int NPART, int P>
+__global__ __launch_bounds__(1024) void pp_chain_split_kernel(ChainArgs c) {
+  extern __shared__ float chain_lds[];
+  const int H = c.w[0].H;
+  const int item = blockIdx.x;
+  const int y = item % H, b = (item / H) % c.B, chain = item / (H * c.B);
+  const RowTaps r = row_taps(y, H);
+  if (chain == 0) {
+    if (r.wb != 0.0f) chain_row_split<false, 2, NPART, P>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+    else              chain_row_split<false, 1, NPART, P>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+  } else {
+    if (r.wb != 0.0f) chain_row_split<true, 2, NPART, P>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+    else              chain_row_split<true, 1, NPART, P>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+  }
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(512) void pp_chain_kernel(ChainArgs c) {   // (at most 8 waves: 256 VGPRs for the sample registers)
+  extern __shared__ float chain_lds[];
+  const int H = c.w[0].H;
+  const int item = blockIdx.x;                       // (chain, image, row): the rows of one image side by side
+  const int y = item % H, b = (item / H) % c.B, chain = item / (H * c.B);
+  const RowTaps r = row_taps(y, H);
+  if (chain == 0) {
+    if (r.wb != 0.0f) chain_row<false, 2, NMAX>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+    else              chain_row<false, 1, NMAX>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+  } else {
+    if (r.wb != 0.0f) chain_row<true, 2, NMAX>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+    else              chain_row<true, 1, NMAX>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+  }
+}
+
+// o_l / o_fr from the S rows (vertical weights of the second warp, the clamp of trainer.py:449 / 456) and the disp_pp blend
+__global__ __launch_bounds__(kBlock) void pp_rows_finish_kernel(int B, int H, int W, const float* __restrict__ S_l,
+                                                                const float* __restrict__ S_fr, const float* __restrict__ disp,
+                                                                float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long HW = (long)H * W, i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const int b = (int)(i / HW);
+  const long p = i - (long)b * HW;
+  const int y = (int)(p / W), x = (int)(p - (long)y * W);
+  const RowTaps r = row_taps(y, H);
+  const float* sl = S_l + (long)b * HW;
+  const float* sf = S_fr + (long)b * HW;
+  const float ol = fminf(sl[(long)r.ra * W + x] * r.wa + sl[(long)r.rb * W + x] * r.wb, 1.0f);
+  const float ofr = fminf(sf[(long)r.ra * W + x] * r.wa + sf[(long)r.rb * W + x] * r.wb, 1.0f);
+  const float d0 = disp[i], df = disp[((long)B + b) * HW + (long)y * W + (W - 1 - x)];
+  const float mean = d0 * 0.5f + df * 0.5f;
+  float pp = mean * ofr + d0 * (1.0f - ofr);
+  pp = pp * ol + df * (1.0f - ol);
+  out[i] = pp;
 }
 
 // disp_pp of trainer.py:458-461 from the two occlusion masks: one pass instead of eight elementwise launches.
@@ -614,6 +840,51 @@ extern "C" int pd_post_process(int B, int N, int H, int W, int flags, const floa
   float* o_l = workspace + (size_t)B * img;
   float* o_fr = o_l + (size_t)B * P;
   int rc;
+  // Row chains where the softmax of a row fits the CU's LDS: per-plane disparities, pixel pairs, N <= 64
+  const size_t chain_lds = (size_t)N * (W + 4) * sizeof(float);
+  if (!(flags & PD_PP_DISP_DENSE) && !switches().pp_seg_off && !switches().pp_chain_off && (W % 2 == 0) && W <= 8 * kSegPix && N <= 64 && H <= 65535 &&
+      chain_lds <= device_lds_bytes() && (long)2 * B * H < (1L << 31) && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(disp_pp)) & 7) == 0) {
+    ChainArgs c;
+    if ((rc = warp_args(c.w[0], B, N, H, W, +1.0f, 0, logits, dl_r))) return rc;
+    if ((rc = warp_args(c.w[1], B, N, H, W, -1.0f, PD_PP_FLIP_SRC, logits + (size_t)B * img, dl_l))) return rc;
+    c.disp2[0] = dl_l; c.sign2[0] = -1.0f;
+    c.disp2[1] = dl_r; c.sign2[1] = +1.0f;
+    c.S[0] = workspace; c.S[1] = workspace + (size_t)B * P;
+    c.B = B;
+    const int nseg = ceil_div(W, kSegPix);
+    const dim3 grid((unsigned)(2 * B * H));
+    // planes dealt to P = 3 waves per segment where the workgroup (3 nseg <= 16 waves) and its LDS (row buffer + one float2 per
+    // pixel and part) fit; else one wave per segment
+    const size_t split_lds = chain_lds + (size_t)3 * nseg * kSegPix * sizeof(float2);
+    if (PD_PP_CHAIN_SPLIT && 3 * nseg <= 16 && split_lds <= device_lds_bytes()) {
+      const dim3 block3(3 * nseg * kWave);
+#define PD_PP_SPLIT(NPART)                                                                                                        \
+      do {                                                                                                                        \
+        static LdsGrant granted;                                                                                                  \
+        if ((rc = grant_dynamic_lds((const void*)pp_chain_split_kernel<NPART, 3>, split_lds, &granted, "pp_chain_split_kernel"))) return rc; \
+        pp_chain_split_kernel<NPART, 3><<<grid, block3, split_lds, (hipStream_t)stream>>>(c);                                     \
+      } while (0)
+      if (N <= 33) PD_PP_SPLIT(11); else if (N <= 54) PD_PP_SPLIT(18); else PD_PP_SPLIT(22);
+#undef PD_PP_SPLIT
+      if ((rc = check_launch("pp_chain_split_kernel"))) return rc;
+      pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.S[0], c.S[1], disp, disp_pp);
+      if ((rc = check_launch("pp_rows_finish_kernel"))) return rc;
+      return pd_warp_sum(B, N, H, W, +1.0f, flags, probability, dl_r, 1.0f, mask_novel, stream);                         // :463-465
+    }
+    const dim3 block(nseg * kWave);   // one wave per segment
+#define PD_PP_CHAIN(NMAX)                                                                                                    \
+    do {                                                                                                                    \
+      static LdsGrant granted;                                                                                              \
+      if ((rc = grant_dynamic_lds((const void*)pp_chain_kernel<NMAX>, chain_lds, &granted, "pp_chain_kernel"))) return rc;  \
+      pp_chain_kernel<NMAX><<<grid, block, chain_lds, (hipStream_t)stream>>>(c);                                            \
+    } while (0)
+    if (N <= 32) PD_PP_CHAIN(32); else if (N <= 52) PD_PP_CHAIN(52); else PD_PP_CHAIN(64);
+#undef PD_PP_CHAIN
+    if ((rc = check_launch("pp_chain_kernel"))) return rc;
+    pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.S[0], c.S[1], disp, disp_pp);
+    if ((rc = check_launch("pp_rows_finish_kernel"))) return rc;
+    return pd_warp_sum(B, N, H, W, +1.0f, flags, probability, dl_r, 1.0f, mask_novel, stream);                           // :463-465
+  }
   if ((rc = pd_warp_softmax(B, N, H, W, +1.0f, flags, logits, dl_r, planes, stream))) return rc;                         // :443-446
   if ((rc = pd_warp_sum(B, N, H, W, -1.0f, flags, planes, dl_l, 1.0f, o_l, stream))) return rc;                         // :447-449
   if ((rc = pd_warp_softmax(B, N, H, W, -1.0f, flags | PD_PP_FLIP_SRC, logits + (size_t)B * img, dl_l, planes, stream))) return rc;   // :451-453

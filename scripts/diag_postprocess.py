@@ -51,7 +51,7 @@ def main():
     hw4 = H * W * 4 * B
     bytes_ = {"warp_softmax +1": 2 * N * hw4, "warp_softmax -1 flip": 2 * N * hw4, "warp_sum -1": (N + 1) * hw4, "warp_sum +1": (N + 1) * hw4,
               "pp_combine": 5 * hw4, "post_process_disp": (7 * N + 3) * hw4, "... stepwise": (7 * N + 3) * hw4}
-    print("PD_PP_SEG=%s PD_PP_ROWS=%s  %dx%dx%dx%d" % (os.environ.get("PD_PP_SEG", "-"), os.environ.get("PD_PP_ROWS", "-"), B, N, H, W))
+    print("PD_PP_SEG=%s PD_PP_ROWS=%s PD_PP_CHAIN=%s  %dx%dx%dx%d" % (os.environ.get("PD_PP_SEG", "-"), os.environ.get("PD_PP_ROWS", "-"), os.environ.get("PD_PP_CHAIN", "-"), B, N, H, W))
     for name, fn in rows:
         t = timed(fn)
         print("%-22s %.4f ms  %7.1f GB/s" % (name, t, bytes_[name] / (t * 1e-3) / 1e9))

@@ -1281,8 +1281,10 @@ def test_post_process_segment_kernels_vs_oracle_and_row_kernels(H, W, N, dmax):
     got = ops.post_process_disp(logits.cuda(), prob.cuda(), disp.cuda(), dl.cuda())
     for a_, b_ in zip(got, want):
         assert rel_err(a_.cpu(), b_) < TOL
+    # pd_post_process against the six operator calls: equal bit for bit where it IS those calls (N > 64), within fp32
+    # reassociation where the row chains take the vertical weights out of the plane sum (N <= 64, W <= 1024)
     for a_, b_ in zip(got, ops.post_process_disp_stepwise(logits.cuda(), prob.cuda(), disp.cuda(), dl.cuda())):
-        assert torch.equal(a_, b_)          # pd_post_process is the six operator calls in one
+        assert torch.equal(a_, b_) if N > 64 else float((a_ - b_).abs().max()) <= 3e-6 * max(float(b_.abs().max()), 1.0), float((a_ - b_).abs().max())
     here = {}
     for sign, flip in ((1.0, False), (-1.0, False), (-1.0, True), (1.0, True)):
         here[(sign, flip)] = (ops.warp_softmax(logits[:B].cuda(), dl[:B].cuda(), sign, flip_src=flip).cpu(),
