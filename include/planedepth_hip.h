@@ -351,12 +351,13 @@ int pd_smooth_loss_bwd_padded(int B, int C, int H, int W, int x_pad, const float
  *   pd_warp_softmax  out[b,n] = softmax over n of planes[b,n] sampled at (x + sign*disp[b,n], y)   [B,N,H,W] -> [B,N,H,W]
  *   pd_warp_sum      out[b,0] = min(cap, sum over n of planes[b,n] sampled at (x + sign*disp[b,n], y))      -> [B,1,H,W]
  * bilinear, zeros padding, align_corners=True, coordinates through the reference's normalise / un-normalise round trip.
- * disp [B,N] or, with PD_PP_DISP_DENSE, [B,N,H,W]; PD_PP_FLIP_SRC reads `planes` mirrored along x (the .flip(-1) of
+ * disp [B,N], with PD_PP_DISP_ROWS [B,N,H] (one disparity per plane and row: the decoder's xz planes) or, with PD_PP_DISP_DENSE,
+ * [B,N,H,W]; PD_PP_FLIP_SRC reads `planes` mirrored along x (the .flip(-1) of
  * trainer.py:451) without a flipped copy.  Per-plane disparities with an even W and N <= 64 (pd_warp_sum: any N) take the segment
  * form (two pixels per lane, 12-byte taps, the softmax's samples of all planes in registers: sampled once); PD_PP_SEG=0 keeps
  * the one-pixel-per-lane row kernels, PD_PP_ROWS=0 the per-pixel gather form (both exact: cross-checks).
  */
-enum pd_pp_flags { PD_PP_DISP_DENSE = 1, PD_PP_FLIP_SRC = 2 };
+enum pd_pp_flags { PD_PP_DISP_DENSE = 1, PD_PP_FLIP_SRC = 2, PD_PP_DISP_ROWS = 4 };
 int pd_warp_softmax(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp,
                     float* out, pd_stream_t stream);
 int pd_warp_sum(int B, int N, int H, int W, float sign, int flags, const float* planes, const float* disp, float cap,
@@ -371,7 +372,7 @@ int pd_pp_combine(int B, int H, int W, const float* disp, const float* o_fr, con
  * even W <= 1024, N <= 64: the "row chains" keep softmax(warp(logits)) in LDS and take the second warp's plane sum from there, the
  * [B,N,H,W] intermediate never reaches memory; PD_PP_CHAIN=0 or any other shape: the six launches of the single warps): logits / probability [2B,N,H,W] and disp [2B,1,H,W] are the fixed
  * model's outputs for cat([image, mirrored image]) (B = half of that batch; of `probability` only the first B images are read),
- * disp_layered [2B,N] or, PD_PP_DISP_DENSE, [2B,N,H,W]; workspace: pd_post_process_workspace_floats floats;
+ * disp_layered [2B,N], PD_PP_DISP_ROWS [2B,N,H] or PD_PP_DISP_DENSE [2B,N,H,W]; workspace: pd_post_process_workspace_floats floats;
  * -> disp_pp, mask_novel [B,1,H,W]. */
 size_t pd_post_process_workspace_floats(int B, int N, int H, int W);
 int pd_post_process(int B, int N, int H, int W, int flags, const float* logits, const float* probability, const float* disp,

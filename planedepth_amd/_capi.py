@@ -19,7 +19,7 @@ PD_PH_MEAN_ZEROED = 512
 PD_BWD_PLANE_ZEROED = 1024
 PD_PAD_ZEROS, PD_PAD_BORDER = 0, 1
 PD_TAIL_MIXTURE, PD_TAIL_DISP_DENSE = 1, 2
-PD_PP_DISP_DENSE, PD_PP_FLIP_SRC = 1, 2
+PD_PP_DISP_DENSE, PD_PP_FLIP_SRC, PD_PP_DISP_ROWS = 1, 2, 4
 PD_HMAT_PLANES, PD_HMAT_UNIFORM, PD_HMAT_STEREO_ROWS = 0, 1, 2
 PD_IMPL_AUTO, PD_IMPL_GENERAL, PD_IMPL_FAST_ROWS, PD_IMPL_TILE, PD_IMPL_ROWS1, PD_IMPL_UNIFORM_DIRECT = 0, 1, 2, 3, 4, 5
 PD_IMPL_EXACT_ROWS = 6

@@ -17,7 +17,10 @@ namespace pd {
 
 struct WarpArgs {
   int N, H, W;
-  int dense, flip;
+  int dense, flip, rows;   // rows: disp is [B,N,H] — one disparity per (plane, row): xz planes (PD_PP_DISP_ROWS)
+  int dimg, dplane, ymask; // disparity of (b, n, y) when !dense: disp[b * dimg + n * dplane + (y & ymask)] — (N, 1, 0) per plane,
+                           // (N H, H, ~0) per row: 32-bit, branch-free (a select between two 64-bit addresses per plane cost the
+                           // unrolled segment kernels 90 scalar instructions a plane)
   float sign;
   float Wm1, rcpWm1;   // W - 1 and its correctly rounded reciprocal (host-computed: 1/(W-1) in double, rounded once)
   const float* planes;
@@ -36,6 +39,7 @@ typedef float v2f_u4 __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte
 constexpr int kGroup = 4;
 
 struct RowTaps {        // per pixel, plane-independent
+  int y;                // the target row itself
   int ra, rb;           // clamped source rows
   float wa, wb;         // their weights (0 when the row is outside the image)
 };
@@ -45,6 +49,7 @@ __device__ __forceinline__ RowTaps row_taps(int y, int H) {
   const bool va = (yf >= 0.0f) && (yf <= (float)(H - 1)), vb = (yf1 >= 0.0f) && (yf1 <= (float)(H - 1));
   const int y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H);
   RowTaps r;
+  r.y = y;
   r.ra = min(max(y0, 0), H - 1);
   r.rb = min(max(y0 + 1, 0), H - 1);
   r.wa = va ? yf1 - iy : 0.0f;
@@ -74,7 +79,8 @@ __device__ __forceinline__ ColPair col_pair(float ix, int W) {
 }
 
 __device__ __forceinline__ float plane_ix(const WarpArgs& a, int b, int n, int x, int y) {
-  const float d = a.dense ? a.disp[(((long)b * a.N + n) * a.H + y) * a.W + x] : a.disp[b * a.N + n];
+  const float d = a.dense ? a.disp[(((long)b * a.N + n) * a.H + y) * a.W + x]
+                          : a.disp[b * a.dimg + n * a.dplane + (y & a.ymask)];
   // the division by W-1 through its refined reciprocal: the same bits as IEEE division (pd_common.h), a third of the cost
   return normalise_roundtrip_rcp((float)x + a.sign * d, a.Wm1, a.rcpWm1);
 }
@@ -198,8 +204,8 @@ __device__ __forceinline__ RowPair row_pair(const ColTap& t, int W) {
 }
 
 // the shift s*d_n, clamped like the sweep's staged shifts (beyond +-(W+1) nothing is in view; keeps x0*4 from aliasing)
-__device__ __forceinline__ float plane_shift(const WarpArgs& a, int b, int n) {
-  const float sd = a.sign * a.disp[b * a.N + n], lim = (float)(a.W + 2);
+__device__ __forceinline__ float plane_shift(const WarpArgs& a, int b, int n, int y) {
+  const float sd = a.sign * a.disp[b * a.dimg + n * a.dplane + (y & a.ymask)], lim = (float)(a.W + 2);
   return (sd >= -lim && sd <= lim) ? sd : ((sd < 0.0f) ? -lim : lim);   // NaN -> +lim
 }
 
@@ -210,7 +216,7 @@ __device__ __forceinline__ void rows_group(const WarpArgs& a, const float* __res
   v2f_b va[U], vb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    rp[u] = row_pair<FLIP>(make_col_tap((float)x + plane_shift(a, b, n0 + u), a.Wm1, a.rcpWm1), a.W);
+    rp[u] = row_pair<FLIP>(make_col_tap((float)x + plane_shift(a, b, n0 + u, r.y), a.Wm1, a.rcpWm1), a.W);
     const float* pl = pb + (long)(n0 + u) * HW;   // wave-uniform
     va[u] = pp_load2(pp_row_rsrc(pl + (long)r.ra * a.W, a.W), rp[u].off);
     if (NR == 2) vb[u] = pp_load2(pp_row_rsrc(pl + (long)r.rb * a.W, a.W), rp[u].off);
@@ -300,10 +306,21 @@ struct SegPlane {   // wave-uniform: one plane's shift for this segment
   int k;
   bool general;
 };
+// The shifts of planes nbase .. nbase + 63, one per lane (plane_shift's value: sign, clamp): ONE vector load per wave and 64 planes,
+// whatever the disparities' layout; a plane's shift is then a v_readlane away.  (Scalar loads per plane were fine while the
+// per-plane layout let the compiler fold n into the load's immediate and fetch sixteen planes at a time; with a run-time stride
+// every plane waited for its own s_load: +30-50 % on the chain kernels.)
+__device__ __forceinline__ float seg_shifts(const WarpArgs& a, int b, int y, int nbase) {
+  const int n = min(nbase + (int)(threadIdx.x & (kWave - 1)), a.N - 1);
+  return plane_shift(a, b, n, y);
+}
+__device__ __forceinline__ float shift_of(float shifts, int j) {   // j: wave-uniform lane index
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(shifts), j));
+}
 template <bool FLIP>
-__device__ __forceinline__ SegPlane seg_plane(const WarpArgs& a, int b, int n, int xseg) {
+__device__ __forceinline__ SegPlane seg_plane(const WarpArgs& a, float sd) {
   SegPlane p;
-  p.sd = plane_shift(a, b, n);
+  p.sd = sd;
   const float fl = floorf(p.sd), fr = p.sd - fl;
   p.k = (int)fl;
   const float tol = irregular_tol(a.W);
@@ -356,7 +373,7 @@ __device__ __forceinline__ void seg_values(const WarpArgs& a, const RowTaps& r, 
 // f(n, v0, v1) for every plane of the lane's two pixels, in plane order; loads of kGroup planes in flight
 template <bool FLIP, int NR, int G, typename F>
 __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
-                                          int x0, int HW, int n0, F& f, int nbase = 0, int nend = 1 << 30) {
+                                          int x0, int HW, int n0, F& f, float shifts, int sbase, int nbase = 0, int nend = 1 << 30) {
   // planes nbase + n0 .. nbase + n0 + G - 1 (those below min(nend, N)); the callback sees the index RELATIVE to nbase, which is a
   // compile-time constant where the caller's loop is unrolled
   const float x0f = (float)x0;
@@ -368,7 +385,7 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int n = min(nbase + n0 + u, a.N - 1);
-      sp[u] = seg_plane<FLIP>(a, b, n, xseg);
+      sp[u] = seg_plane<FLIP>(a, shift_of(shifts, n - sbase));
       const float* pl = pb + (long)n * HW;
       const SegAim aim = seg_aim(FLIP ? a.W - 3 - (x0 + sp[u].k) : x0 + sp[u].k);
       adj[u] = aim.adj;
@@ -399,16 +416,21 @@ __device__ __forceinline__ void seg_group(const WarpArgs& a, const float* __rest
 // NMAX == 0: a run-time loop
 template <bool FLIP, int NR, int G, typename F, int... I>
 __device__ __forceinline__ void seg_groups(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
-                                           int x0, int HW, F& f, std::integer_sequence<int, I...>, int nbase, int nend) {
-  ((nbase + I * G < min(nend, a.N) ? seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, I * G, f, nbase, nend) : (void)0), ...);
+                                           int x0, int HW, F& f, std::integer_sequence<int, I...>, int nbase, int nend, float shifts) {
+  ((nbase + I * G < min(nend, a.N) ? seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, I * G, f, shifts, 0, nbase, nend) : (void)0), ...);
 }
 template <bool FLIP, int NR, int NMAX, typename F, int G = kGroup>   // G planes' loads in flight per wave
 __device__ __forceinline__ void seg_for_each(const WarpArgs& a, const float* __restrict__ pb, const RowTaps& r, int b, int xseg,
                                              int x0, int HW, F f, int nbase = 0, int nend = 1 << 30) {
-  if constexpr (NMAX > 0) {
-    seg_groups<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, f, std::make_integer_sequence<int, (NMAX + G - 1) / G>{}, nbase, nend);
+  if constexpr (NMAX > 0) {   // (at most 64 planes: one register of shifts)
+    const float shifts = seg_shifts(a, b, r.y, 0);
+    seg_groups<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, f, std::make_integer_sequence<int, (NMAX + G - 1) / G>{}, nbase, nend, shifts);
   } else {
-    for (int n0 = 0; n0 < a.N; n0 += G) seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, n0, f);
+    float shifts = 0.0f;
+    for (int n0 = 0; n0 < a.N; n0 += G) {
+      if ((n0 & (kWave - 1)) == 0) shifts = seg_shifts(a, b, r.y, n0);   // (G divides 64)
+      seg_group<FLIP, NR, G>(a, pb, r, b, xseg, x0, HW, n0, f, shifts, n0 & ~(kWave - 1));
+    }
   }
 }
 
@@ -501,16 +523,32 @@ __global__ __launch_bounds__(kSegWaves* kWave) void warp_sum_seg_kernel(WarpArgs
 #endif
 struct ChainArgs {
   WarpArgs w[2];          // first warp of chain 0 (image, plain) / chain 1 (mirrored image, PD_PP_FLIP_SRC)
-  const float* disp2[2];  // the second warp's disparities [B,N] and sign
+  const float* disp2[2];  // the second warp's disparities [B,N] ([B,N,H] with rows2) and sign
   float sign2[2];
-  float* S[2];            // [B,1,H,W] each
-  int B;
+  float* S[2];            // [3][B,1,H,W] each: S_r with the shifts of target row r, r - 1, r + 1 (the last two with rows2 only,
+  int B, rows2;           // and only where that neighbour blends row r in)
 };
+// Which targets need S of source row r: r itself always; with per-row shifts also the neighbours t = r -+ 1 whose vertical taps
+// reach r (their shift differs from row r's) — the inexact rows of the y round trip, a quarter of them at H = 192.
+__device__ __forceinline__ bool chain_needs(int r, int t, int H) {
+  if (t < 0 || t >= H) return false;
+  const RowTaps q = row_taps(t, H);
+  return (q.ra == r && q.wa != 0.0f) || (q.rb == r && q.wb != 0.0f);
+}
+// the second warp's shifts of planes 0 .. 63 under target row yt, one per lane (plane_shift's clamp)
+__device__ __forceinline__ float chain_shifts(const float* __restrict__ disp2, float sign2, int rows2, int b, int N, int H, int yt,
+                                              float lim) {
+  const int n = min((int)(threadIdx.x & (kWave - 1)), N - 1);
+  const float sdr = sign2 * disp2[rows2 ? (b * N + n) * H + yt : b * N + n];
+  return (sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f) ? -lim : lim);   // NaN -> +lim
+}
 
-template <bool FLIP, int NR, int NMAX>
-__device__ __forceinline__ void chain_row(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int b, int y,
-                                          const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
+template <bool FLIP, int NR, int NMAX, bool ROWS2>
+__device__ __forceinline__ void chain_row(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int rows2_, int B, int b,
+                                          int y, const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
   const int W = a.W, N = a.N, HW = a.H * a.W, RS = W + 4;
+  constexpr int rows2 = ROWS2 ? 1 : 0;   // (a template flag: as a run-time one it cost the per-plane case 30-50 % — NOTEBOOK 11.4)
+  (void)rows2_;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* pb = a.planes + (long)b * N * HW;
@@ -549,22 +587,24 @@ __device__ __forceinline__ void chain_row(const WarpArgs& a, const float* __rest
   }
   __syncthreads();
   const float lim = (float)(W + 2);
-  {
+  for (int v = 0; v < (rows2 ? 3 : 1); ++v) {   // S_r under the shifts of target row y, y - 1, y + 1 (workgroup-uniform)
+    const int yt = (v == 0) ? y : ((v == 1) ? y - 1 : y + 1);
+    if (v > 0 && !chain_needs(y, yt, a.H)) continue;
     const int x0 = seg * kSegPix + 2 * lane;
     float acc0 = 0.0f, acc1 = 0.0f;
+    const float sh2 = chain_shifts(disp2, sign2, rows2, b, N, a.H, yt, lim);
     for (int n = 0; n < N; ++n) {
-      const float sdr = sign2 * disp2[b * N + n];
-      const float sd = (sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f) ? -lim : lim);   // plane_shift's clamp (NaN -> +lim)
+      const float sd = shift_of(sh2, n);
       const float* row = lds + n * RS;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const ColTap t = make_col_tap((float)(x0 + i) + sd, a.Wm1, a.rcpWm1);
         const int cell = min(max(t.x0, -2), W) + 2;
-        const float v = row[cell] * t.w0 + row[cell + 1] * t.w1;
-        if (i == 0) acc0 += v; else acc1 += v;
+        const float val = row[cell] * t.w0 + row[cell + 1] * t.w1;
+        if (i == 0) acc0 += val; else acc1 += val;
       }
     }
-    if (x0 < W) *reinterpret_cast<float2*>(S + (long)b * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+    if (x0 < W) *reinterpret_cast<float2*>(S + ((long)v * B + b) * HW + (long)y * W + x0) = make_float2(acc0, acc1);
   }
 }
 
@@ -573,22 +613,29 @@ __device__ __forceinline__ void chain_row(const WarpArgs& a, const float* __rest
 // wave per segment (5 per CU) the kernel ran at 1.2 TB/s.  Wave (seg, part) samples planes [part * NPART, (part + 1) * NPART),
 // leaves (max, sum of exp relative to it) per pixel in LDS, takes the segment's max / sum from the P parts after a barrier, writes
 // its planes' probabilities, and after the next barrier sums ITS planes' taps of the second warp; part 0 adds the partial sums.
-template <bool FLIP, int NR, int NPART, int P>
-__device__ __forceinline__ void chain_row_split(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int b, int y,
-                                                const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
+template <bool FLIP, int NR, int NPART, int P, bool ROWS2, bool ALIAS>
+__device__ __forceinline__ void chain_row_split(const WarpArgs& a, const float* __restrict__ disp2, float sign2, int rows2_, int B,
+                                                int b, int y, const RowTaps& r, float* __restrict__ lds, float* __restrict__ S) {
   const int W = a.W, N = a.N, HW = a.H * a.W, RS = W + 4;
+  constexpr int rows2 = ROWS2 ? 1 : 0;   // (a template flag: as a run-time one it cost the per-plane case 30-50 % — NOTEBOOK 11.4)
+  (void)rows2_;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nseg = (W + kSegPix - 1) / kSegPix;
   const int seg = wave % nseg, part = wave / nseg;
   const int nb = part * NPART, ne = min(nb + NPART, N);
   const int SW = nseg * kSegPix;                                 // stats row: one float2 per pixel of the padded row and part
-  float2* stats = reinterpret_cast<float2*>(lds + (size_t)N * RS);
+  // ALIAS (the row buffer alone fills the CU's LDS: 63 planes x 640): the parts' statistics and, later, their partial sums live
+  // INSIDE the row buffer — while no probabilities are there yet, and after the last one has been read; two more barriers
+  float2* stats = ALIAS ? reinterpret_cast<float2*>(lds) : reinterpret_cast<float2*>(lds + (size_t)N * RS);
   const float* pb = a.planes + (long)b * N * HW;
-  for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) {   // zero guard cells: columns -2, -1, W, W + 1 of every plane
-    const int n = i >> 2, g = i & 3;
-    lds[n * RS + (g < 2 ? g : W + g)] = 0.0f;
-  }
+  auto zero_guards = [&]() {
+    for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) {   // zero guard cells: columns -2, -1, W, W + 1 of every plane
+      const int n = i >> 2, g = i & 3;
+      lds[n * RS + (g < 2 ? g : W + g)] = 0.0f;
+    }
+  };
+  if (!ALIAS) zero_guards();
   const int xseg = seg * kSegPix, x0 = xseg + 2 * lane;
   float l0[NPART], l1[NPART];
 #pragma unroll
@@ -621,6 +668,10 @@ __device__ __forceinline__ void chain_row_split(const WarpArgs& a, const float* 
     T1 += (s1.x == -INFINITY) ? 0.0f : s1.y * __expf(s1.x - M1);
   }
   const float c0 = (m0 == -INFINITY) ? 0.0f : __expf(m0 - M0) / T0, c1 = (m1 == -INFINITY) ? 0.0f : __expf(m1 - M1) / T1;
+  if (ALIAS) {   // every wave has its statistics in registers before the first probability overwrites them
+    __syncthreads();
+    zero_guards();
+  }
   if (x0 < W) {
 #pragma unroll
     for (int j = 0; j < NPART; ++j)
@@ -628,29 +679,60 @@ __device__ __forceinline__ void chain_row_split(const WarpArgs& a, const float* 
   }
   __syncthreads();   // (every wave has read the stats by now: the buffer is free for the partial sums)
   const float lim = (float)(W + 2);
-  float acc0 = 0.0f, acc1 = 0.0f;
-  for (int n = nb; n < ne; ++n) {
-    const float sdr = sign2 * disp2[b * N + n];
-    const float sd = (sdr >= -lim && sdr <= lim) ? sdr : ((sdr < 0.0f) ? -lim : lim);   // plane_shift's clamp (NaN -> +lim)
-    const float* row = lds + n * RS;
+  constexpr int NV = ROWS2 ? 3 : 1;
+  float accv[NV][2];
+  bool need[NV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const ColTap t = make_col_tap((float)(x0 + i) + sd, a.Wm1, a.rcpWm1);
-      const int cell = min(max(t.x0, -2), W) + 2;
-      const float v = row[cell] * t.w0 + row[cell + 1] * t.w1;
-      if (i == 0) acc0 += v; else acc1 += v;
+  for (int v = 0; v < NV; ++v) {   // S_r under the shifts of target row y, y - 1, y + 1 (workgroup-uniform)
+    const int yt = (v == 0) ? y : ((v == 1) ? y - 1 : y + 1);
+    need[v] = (v == 0) || chain_needs(y, yt, a.H);
+    accv[v][0] = accv[v][1] = 0.0f;
+    if (!need[v]) continue;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    const float sh2 = chain_shifts(disp2, sign2, rows2, b, N, a.H, yt, lim);
+    for (int n = nb; n < ne; ++n) {
+      const float sd = shift_of(sh2, n);
+      const float* row = lds + n * RS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const ColTap t = make_col_tap((float)(x0 + i) + sd, a.Wm1, a.rcpWm1);
+        const int cell = min(max(t.x0, -2), W) + 2;
+        const float val = row[cell] * t.w0 + row[cell + 1] * t.w1;
+        if (i == 0) acc0 += val; else acc1 += val;
+      }
+    }
+    accv[v][0] = acc0; accv[v][1] = acc1;
+    if (!ALIAS) {   // the partial sums go through the statistics' buffer, variant by variant
+      if (part > 0) stats[part * SW + x0] = make_float2(acc0, acc1);
+      __syncthreads();
+      if (part == 0 && x0 < W) {
+#pragma unroll
+        for (int q = 1; q < P; ++q) { const float2 o = stats[q * SW + x0]; acc0 += o.x; acc1 += o.y; }
+        *reinterpret_cast<float2*>(S + ((long)v * B + b) * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+      }
+      if (ROWS2) __syncthreads();   // (the partial sums of the next variant go into the same buffer)
     }
   }
-  if (part > 0) stats[part * SW + x0] = make_float2(acc0, acc1);
-  __syncthreads();
-  if (part == 0 && x0 < W) {
+  if (ALIAS) {   // the probabilities have been read for the last time: the partial sums of every variant go where they were
+    __syncthreads();
 #pragma unroll
-    for (int q = 1; q < P; ++q) { const float2 o = stats[q * SW + x0]; acc0 += o.x; acc1 += o.y; }
-    *reinterpret_cast<float2*>(S + (long)b * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+    for (int v = 0; v < NV; ++v)
+      if (need[v] && part > 0) stats[(v * P + part) * SW + x0] = make_float2(accv[v][0], accv[v][1]);
+    __syncthreads();
+    if (part == 0 && x0 < W) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (!need[v]) continue;
+        float acc0 = accv[v][0], acc1 = accv[v][1];
+#pragma unroll
+        for (int q = 1; q < P; ++q) { const float2 o = stats[(v * P + q) * SW + x0]; acc0 += o.x; acc1 += o.y; }
+        *reinterpret_cast<float2*>(S + ((long)v * B + b) * HW + (long)y * W + x0) = make_float2(acc0, acc1);
+      }
+    }
   }
 }
 
-template <int NPART, int P>
+template <int NPART, int P, bool ROWS2, bool ALIAS>
 __global__ __launch_bounds__(1024) void pp_chain_split_kernel(ChainArgs c) {
   extern __shared__ float chain_lds[];
   const int H = c.w[0].H;
@@ -658,15 +740,15 @@ __global__ __launch_bounds__(1024) void pp_chain_split_kernel(ChainArgs c) {
   const int y = item % H, b = (item / H) % c.B, chain = item / (H * c.B);
   const RowTaps r = row_taps(y, H);
   if (chain == 0) {
-    if (r.wb != 0.0f) chain_row_split<false, 2, NPART, P>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
-    else              chain_row_split<false, 1, NPART, P>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+    if (r.wb != 0.0f) chain_row_split<false, 2, NPART, P, ROWS2, ALIAS>(c.w[0], c.disp2[0], c.sign2[0], c.rows2, c.B, b, y, r, chain_lds, c.S[0]);
+    else              chain_row_split<false, 1, NPART, P, ROWS2, ALIAS>(c.w[0], c.disp2[0], c.sign2[0], c.rows2, c.B, b, y, r, chain_lds, c.S[0]);
   } else {
-    if (r.wb != 0.0f) chain_row_split<true, 2, NPART, P>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
-    else              chain_row_split<true, 1, NPART, P>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+    if (r.wb != 0.0f) chain_row_split<true, 2, NPART, P, ROWS2, ALIAS>(c.w[1], c.disp2[1], c.sign2[1], c.rows2, c.B, b, y, r, chain_lds, c.S[1]);
+    else              chain_row_split<true, 1, NPART, P, ROWS2, ALIAS>(c.w[1], c.disp2[1], c.sign2[1], c.rows2, c.B, b, y, r, chain_lds, c.S[1]);
   }
 }
 
-template <int NMAX>
+template <int NMAX, bool ROWS2>
 __global__ __launch_bounds__(512) void pp_chain_kernel(ChainArgs c) {   // (at most 8 waves: 256 VGPRs for the sample registers)
   extern __shared__ float chain_lds[];
   const int H = c.w[0].H;
@@ -674,16 +756,26 @@ __global__ __launch_bounds__(512) void pp_chain_kernel(ChainArgs c) {   // (at m
   const int y = item % H, b = (item / H) % c.B, chain = item / (H * c.B);
   const RowTaps r = row_taps(y, H);
   if (chain == 0) {
-    if (r.wb != 0.0f) chain_row<false, 2, NMAX>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
-    else              chain_row<false, 1, NMAX>(c.w[0], c.disp2[0], c.sign2[0], b, y, r, chain_lds, c.S[0]);
+    if (r.wb != 0.0f) chain_row<false, 2, NMAX, ROWS2>(c.w[0], c.disp2[0], c.sign2[0], c.rows2, c.B, b, y, r, chain_lds, c.S[0]);
+    else              chain_row<false, 1, NMAX, ROWS2>(c.w[0], c.disp2[0], c.sign2[0], c.rows2, c.B, b, y, r, chain_lds, c.S[0]);
   } else {
-    if (r.wb != 0.0f) chain_row<true, 2, NMAX>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
-    else              chain_row<true, 1, NMAX>(c.w[1], c.disp2[1], c.sign2[1], b, y, r, chain_lds, c.S[1]);
+    if (r.wb != 0.0f) chain_row<true, 2, NMAX, ROWS2>(c.w[1], c.disp2[1], c.sign2[1], c.rows2, c.B, b, y, r, chain_lds, c.S[1]);
+    else              chain_row<true, 1, NMAX, ROWS2>(c.w[1], c.disp2[1], c.sign2[1], c.rows2, c.B, b, y, r, chain_lds, c.S[1]);
   }
 }
 
-// o_l / o_fr from the S rows (vertical weights of the second warp, the clamp of trainer.py:449 / 456) and the disp_pp blend
-__global__ __launch_bounds__(kBlock) void pp_rows_finish_kernel(int B, int H, int W, const float* __restrict__ S_l,
+// o_l / o_fr from the S rows (vertical weights of the second warp, the clamp of trainer.py:449 / 456) and the disp_pp blend.
+// S is [3][B,1,H,W]: source row rho contributes to target y through the variant computed with y's shifts — 0 for rho == y,
+// 1 for rho == y + 1, 2 for rho == y - 1 (`rows2`; with per-plane shifts variant 0 serves everyone).  A zero weight reads nothing.
+__device__ __forceinline__ float chain_o(const float* __restrict__ S, int B, int b, long HW, int W, int x, int y, const RowTaps& r,
+                                         int rows2) {
+#pragma clang fp contract(off)
+  float o = 0.0f;
+  if (r.wa != 0.0f) o = S[((long)((!rows2 || r.ra == y) ? 0 : ((r.ra == y + 1) ? 1 : 2)) * B + b) * HW + (long)r.ra * W + x] * r.wa;
+  if (r.wb != 0.0f) o = o + S[((long)((!rows2 || r.rb == y) ? 0 : ((r.rb == y + 1) ? 1 : 2)) * B + b) * HW + (long)r.rb * W + x] * r.wb;
+  return fminf(o, 1.0f);
+}
+__global__ __launch_bounds__(kBlock) void pp_rows_finish_kernel(int B, int H, int W, int rows2, const float* __restrict__ S_l,
                                                                 const float* __restrict__ S_fr, const float* __restrict__ disp,
                                                                 float* __restrict__ out) {
 #pragma clang fp contract(off)
@@ -693,10 +785,7 @@ __global__ __launch_bounds__(kBlock) void pp_rows_finish_kernel(int B, int H, in
   const long p = i - (long)b * HW;
   const int y = (int)(p / W), x = (int)(p - (long)y * W);
   const RowTaps r = row_taps(y, H);
-  const float* sl = S_l + (long)b * HW;
-  const float* sf = S_fr + (long)b * HW;
-  const float ol = fminf(sl[(long)r.ra * W + x] * r.wa + sl[(long)r.rb * W + x] * r.wb, 1.0f);
-  const float ofr = fminf(sf[(long)r.ra * W + x] * r.wa + sf[(long)r.rb * W + x] * r.wb, 1.0f);
+  const float ol = chain_o(S_l, B, b, HW, W, x, y, r, rows2), ofr = chain_o(S_fr, B, b, HW, W, x, y, r, rows2);
   const float d0 = disp[i], df = disp[((long)B + b) * HW + (long)y * W + (W - 1 - x)];
   const float mean = d0 * 0.5f + df * 0.5f;
   float pp = mean * ofr + d0 * (1.0f - ofr);
@@ -739,10 +828,14 @@ static int warp_args(WarpArgs& a, int B, int N, int H, int W, float sign, int fl
                      const float* disp) {
   PD_REQUIRE(B > 0 && B <= 65535 && N > 0 && H > 0 && W > 1, "bad shape");
   PD_REQUIRE((long)H * W < (1L << 31), "image too large");
-  PD_REQUIRE((flags & ~(PD_PP_DISP_DENSE | PD_PP_FLIP_SRC)) == 0, "unknown flags");
+  PD_REQUIRE((flags & ~(PD_PP_DISP_DENSE | PD_PP_FLIP_SRC | PD_PP_DISP_ROWS)) == 0, "unknown flags");
+  PD_REQUIRE(!((flags & PD_PP_DISP_DENSE) && (flags & PD_PP_DISP_ROWS)), "PD_PP_DISP_DENSE and PD_PP_DISP_ROWS exclude each other");
   PD_REQUIRE(planes && disp, "NULL pointer");
   a.N = N; a.H = H; a.W = W;
   a.dense = (flags & PD_PP_DISP_DENSE) != 0;
+  a.rows = (flags & PD_PP_DISP_ROWS) != 0;
+  PD_REQUIRE(!a.rows || (long)B * N * H < (1L << 31), "too many (image, plane, row) disparities for 32-bit indices");
+  a.dimg = a.rows ? N * H : N; a.dplane = a.rows ? H : 1; a.ymask = a.rows ? ~0 : 0;
   a.flip = (flags & PD_PP_FLIP_SRC) != 0;
   a.sign = sign; a.planes = planes; a.disp = disp;
   a.Wm1 = (float)(W - 1);
@@ -824,18 +917,19 @@ extern "C" int pd_pp_combine(int B, int H, int W, const float* disp, const float
 // The whole of trainer.py:443-465 behind one call: six launches on `stream`, no host work in between (as separate operator
 // calls the ~0.2 ms of kernels at 8 x 49 x 192 x 640 were paced by the host's per-call overhead).
 extern "C" size_t pd_post_process_workspace_floats(int B, int N, int H, int W) {
-  return (size_t)B * N * H * W + (size_t)2 * B * H * W;
+  return (size_t)B * N * H * W + (size_t)6 * B * H * W;   // the single warps' [B,N,H,W] intermediate + o_l / o_fr, or the chains' 2 x 3 S maps
 }
 
 extern "C" int pd_post_process(int B, int N, int H, int W, int flags, const float* logits, const float* probability,
                                const float* disp, const float* disp_layered, float* workspace, float* disp_pp, float* mask_novel,
                                pd_stream_t stream) {
   PD_REQUIRE(B > 0 && N > 0 && H > 0 && W > 1, "bad shape");
-  PD_REQUIRE((flags & ~PD_PP_DISP_DENSE) == 0, "unknown flags");
+  PD_REQUIRE((flags & ~(PD_PP_DISP_DENSE | PD_PP_DISP_ROWS)) == 0, "unknown flags");
   PD_REQUIRE(logits && probability && disp && disp_layered && workspace && disp_pp && mask_novel, "NULL pointer");
   const size_t P = (size_t)H * W, img = (size_t)N * P;
   const float* dl_r = disp_layered;                                                              // the image's planes
-  const float* dl_l = disp_layered + ((flags & PD_PP_DISP_DENSE) ? (size_t)B * img : (size_t)B * N);   // the mirrored image's
+  const float* dl_l = disp_layered + ((flags & PD_PP_DISP_DENSE) ? (size_t)B * img                  // the mirrored image's
+                                                                  : ((flags & PD_PP_DISP_ROWS) ? (size_t)B * N * H : (size_t)B * N));
   float* planes = workspace;
   float* o_l = workspace + (size_t)B * img;
   float* o_fr = o_l + (size_t)B * P;
@@ -845,43 +939,54 @@ extern "C" int pd_post_process(int B, int N, int H, int W, int flags, const floa
   if (!(flags & PD_PP_DISP_DENSE) && !switches().pp_seg_off && !switches().pp_chain_off && (W % 2 == 0) && W <= 8 * kSegPix && N <= 64 && H <= 65535 &&
       chain_lds <= device_lds_bytes() && (long)2 * B * H < (1L << 31) && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(disp_pp)) & 7) == 0) {
     ChainArgs c;
-    if ((rc = warp_args(c.w[0], B, N, H, W, +1.0f, 0, logits, dl_r))) return rc;
-    if ((rc = warp_args(c.w[1], B, N, H, W, -1.0f, PD_PP_FLIP_SRC, logits + (size_t)B * img, dl_l))) return rc;
+    const int rowsf = flags & PD_PP_DISP_ROWS;
+    if ((rc = warp_args(c.w[0], B, N, H, W, +1.0f, rowsf, logits, dl_r))) return rc;
+    if ((rc = warp_args(c.w[1], B, N, H, W, -1.0f, rowsf | PD_PP_FLIP_SRC, logits + (size_t)B * img, dl_l))) return rc;
     c.disp2[0] = dl_l; c.sign2[0] = -1.0f;
     c.disp2[1] = dl_r; c.sign2[1] = +1.0f;
-    c.S[0] = workspace; c.S[1] = workspace + (size_t)B * P;
-    c.B = B;
+    c.S[0] = workspace; c.S[1] = workspace + (size_t)3 * B * P;   // [3][B,1,H,W] each
+    c.B = B; c.rows2 = rowsf ? 1 : 0;
     const int nseg = ceil_div(W, kSegPix);
     const dim3 grid((unsigned)(2 * B * H));
     // planes dealt to P = 3 waves per segment where the workgroup (3 nseg <= 16 waves) and its LDS (row buffer + one float2 per
     // pixel and part) fit; else one wave per segment
-    const size_t split_lds = chain_lds + (size_t)3 * nseg * kSegPix * sizeof(float2);
-    if (PD_PP_CHAIN_SPLIT && 3 * nseg <= 16 && split_lds <= device_lds_bytes()) {
+    const size_t side_lds = chain_lds + (size_t)3 * nseg * kSegPix * sizeof(float2);
+    const bool alias = side_lds > device_lds_bytes();   // the parts' statistics / partial sums inside the row buffer (needs 9 maps of
+    const size_t split_lds = alias ? chain_lds : side_lds;   // nseg x 128 float2 there: N >= 18 at W = 640)
+    if (PD_PP_CHAIN_SPLIT && 3 * nseg <= 16 && (!alias || (size_t)9 * nseg * kSegPix * sizeof(float2) <= chain_lds)) {
       const dim3 block3(3 * nseg * kWave);
-#define PD_PP_SPLIT(NPART)                                                                                                        \
+#define PD_PP_SPLIT_(NPART, R2, AL)                                                                                                 \
       do {                                                                                                                        \
         static LdsGrant granted;                                                                                                  \
-        if ((rc = grant_dynamic_lds((const void*)pp_chain_split_kernel<NPART, 3>, split_lds, &granted, "pp_chain_split_kernel"))) return rc; \
-        pp_chain_split_kernel<NPART, 3><<<grid, block3, split_lds, (hipStream_t)stream>>>(c);                                     \
+        if ((rc = grant_dynamic_lds((const void*)pp_chain_split_kernel<NPART, 3, R2, AL>, split_lds, &granted, "pp_chain_split_kernel"))) return rc; \
+        pp_chain_split_kernel<NPART, 3, R2, AL><<<grid, block3, split_lds, (hipStream_t)stream>>>(c);                             \
+      } while (0)
+#define PD_PP_SPLIT(NPART)                                                                              \
+      do {                                                                                              \
+        if (alias) { if (c.rows2) PD_PP_SPLIT_(NPART, true, true); else PD_PP_SPLIT_(NPART, false, true); } \
+        else       { if (c.rows2) PD_PP_SPLIT_(NPART, true, false); else PD_PP_SPLIT_(NPART, false, false); } \
       } while (0)
       if (N <= 33) PD_PP_SPLIT(11); else if (N <= 54) PD_PP_SPLIT(18); else PD_PP_SPLIT(22);
+#undef PD_PP_SPLIT_
 #undef PD_PP_SPLIT
       if ((rc = check_launch("pp_chain_split_kernel"))) return rc;
-      pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.S[0], c.S[1], disp, disp_pp);
+      pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.rows2, c.S[0], c.S[1], disp, disp_pp);
       if ((rc = check_launch("pp_rows_finish_kernel"))) return rc;
       return pd_warp_sum(B, N, H, W, +1.0f, flags, probability, dl_r, 1.0f, mask_novel, stream);                         // :463-465
     }
     const dim3 block(nseg * kWave);   // one wave per segment
-#define PD_PP_CHAIN(NMAX)                                                                                                    \
+#define PD_PP_CHAIN_(NMAX, R2)                                                                                               \
     do {                                                                                                                    \
       static LdsGrant granted;                                                                                              \
-      if ((rc = grant_dynamic_lds((const void*)pp_chain_kernel<NMAX>, chain_lds, &granted, "pp_chain_kernel"))) return rc;  \
-      pp_chain_kernel<NMAX><<<grid, block, chain_lds, (hipStream_t)stream>>>(c);                                            \
+      if ((rc = grant_dynamic_lds((const void*)pp_chain_kernel<NMAX, R2>, chain_lds, &granted, "pp_chain_kernel"))) return rc;  \
+      pp_chain_kernel<NMAX, R2><<<grid, block, chain_lds, (hipStream_t)stream>>>(c);                                        \
     } while (0)
+#define PD_PP_CHAIN(NMAX) do { if (c.rows2) PD_PP_CHAIN_(NMAX, true); else PD_PP_CHAIN_(NMAX, false); } while (0)
     if (N <= 32) PD_PP_CHAIN(32); else if (N <= 52) PD_PP_CHAIN(52); else PD_PP_CHAIN(64);
 #undef PD_PP_CHAIN
+#undef PD_PP_CHAIN_
     if ((rc = check_launch("pp_chain_kernel"))) return rc;
-    pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.S[0], c.S[1], disp, disp_pp);
+    pp_rows_finish_kernel<<<(unsigned)(((long)B * P + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(B, H, W, c.rows2, c.S[0], c.S[1], disp, disp_pp);
     if ((rc = check_launch("pp_rows_finish_kernel"))) return rc;
     return pd_warp_sum(B, N, H, W, +1.0f, flags, probability, dl_r, 1.0f, mask_novel, stream);                           // :463-465
   }

@@ -12,23 +12,27 @@ from ._buffers import torch, _timed, _desc, _contig, _zero_scalar, _zero_block, 
 # ---------------------------------------------------------------------------------------------------------------------
 # Post-process warps — forward only, as in the reference (no_grad networks, detached result)
 # ---------------------------------------------------------------------------------------------------------------------
-def _pp_disp(disp_layered, B, N, H, W):
-    """(tensor, flags): per-plane [B,N] when the map is an H/W-expanded view, else the dense [B,N,H,W] map."""
+def _pp_disp(disp_layered, B, N, H, W, row_uniform=False):
+    """(tensor, flags): per-plane [B,N] when the map is an H/W-expanded view; [B,N,H] + PD_PP_DISP_ROWS when it is constant
+    along x — an x-expanded view, or a dense map under the caller's ``row_uniform`` promise (xy and xz planes:
+    networks/depth_decoder.py:153-181; yz planes are not) —; else the dense [B,N,H,W] map."""
     if tuple(disp_layered.shape) != (B, N, H, W):
         disp_layered = disp_layered.expand(B, N, H, W)
     if disp_layered.stride(2) == 0 and disp_layered.stride(3) == 0:
         return disp_layered[:, :, 0, 0].contiguous(), 0
+    if disp_layered.stride(3) == 0 or row_uniform:
+        return disp_layered[:, :, :, 0].contiguous(), C.PD_PP_DISP_ROWS
     return disp_layered.contiguous(), C.PD_PP_DISP_DENSE
 
 
-def warp_softmax(planes, disp_layered, sign, flip_src=False):
+def warp_softmax(planes, disp_layered, sign, flip_src=False, row_uniform=False):
     """softmax over the planes of ``planes`` sampled at x + sign * disp (trainer.py:443-446 / 451-453)."""
     lib = C.load()
     C.require_gpu_tensor("planes", planes)
     B, N, H, W = planes.shape
     with torch.no_grad():
         planes = planes.detach().contiguous()
-        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
+        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W, row_uniform)
         out = torch.empty_like(planes)
         with C.on_device(planes.device):
             C.check(lib.pd_warp_softmax(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
@@ -37,14 +41,14 @@ def warp_softmax(planes, disp_layered, sign, flip_src=False):
     return out
 
 
-def warp_sum(planes, disp_layered, sign, cap=1.0, flip_src=False):
+def warp_sum(planes, disp_layered, sign, cap=1.0, flip_src=False, row_uniform=False):
     """min(cap, sum over the planes of ``planes`` sampled at x + sign * disp) (trainer.py:447-449, 454-456, 463-465)."""
     lib = C.load()
     C.require_gpu_tensor("planes", planes)
     B, N, H, W = planes.shape
     with torch.no_grad():
         planes = planes.detach().contiguous()
-        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W)
+        disp, flags = _pp_disp(disp_layered.detach(), B, N, H, W, row_uniform)
         out = torch.empty(B, 1, H, W, device=planes.device, dtype=torch.float32)
         with C.on_device(planes.device):
             C.check(lib.pd_warp_sum(B, N, H, W, float(sign), flags | (C.PD_PP_FLIP_SRC if flip_src else 0),
@@ -71,9 +75,11 @@ def pp_combine(disp, o_fr, o_l):
     return out
 
 
-def post_process_disp(logits, probability, disp, disp_layered):
+def post_process_disp(logits, probability, disp, disp_layered, row_uniform=False):
     """trainer.py:421-466 given the fixed model's outputs for cat([image, mirrored image]) -> (disp_pp, mask_novel): ONE C-ABI
-    call (pd_post_process: two warp-softmaxes, three warp-sums, the blend — six launches, no host work in between)."""
+    call (pd_post_process: row chains where a row's softmax fits the CU's LDS, else two warp-softmaxes, three warp-sums and the
+    blend).  ``row_uniform=True`` promises a dense ``disp_layered`` that is constant along x (no yz planes): it is then read as
+    one disparity per (plane, row) and the row kernels / chains serve it instead of the per-pixel gather form."""
     lib = C.load()
     C.require_gpu_tensor("logits", logits)
     B2, N, H, W = logits.shape
@@ -81,7 +87,7 @@ def post_process_disp(logits, probability, disp, disp_layered):
     with torch.no_grad():
         prob = probability.tensor() if hasattr(probability, "tensor") else probability
         logits, prob, disp = (_contig(t.detach()) for t in (logits, prob, disp))
-        dl, flags = _pp_disp(disp_layered.detach(), B2, N, H, W)
+        dl, flags = _pp_disp(disp_layered.detach(), B2, N, H, W, row_uniform)
         dev = logits.device
         ws = torch.empty(lib.pd_post_process_workspace_floats(B, N, H, W), device=dev, dtype=torch.float32)
         disp_pp = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
@@ -92,18 +98,19 @@ def post_process_disp(logits, probability, disp, disp_layered):
     return disp_pp, mask_novel
 
 
-def post_process_disp_stepwise(logits, probability, disp, disp_layered):
+def post_process_disp_stepwise(logits, probability, disp, disp_layered, row_uniform=False):
     """The same through the single operators (cross-check of pd_post_process; what round 5 ran)."""
     B = probability.shape[0] // 2
     with torch.no_grad():
         dl_r, dl_l = disp_layered[:B], disp_layered[B:]
-        plr = warp_softmax(logits[:B], dl_r, +1.0)                       # :443-446
-        o_l = warp_sum(plr, dl_l, -1.0)                                  # :447-449
-        pfrl = warp_softmax(logits[B:], dl_l, -1.0, flip_src=True)       # :451-453 (the flip is folded into the read)
-        o_fr = warp_sum(pfrl, dl_r, +1.0)                                # :454-456
+        ru = dict(row_uniform=row_uniform)
+        plr = warp_softmax(logits[:B], dl_r, +1.0, **ru)                 # :443-446
+        o_l = warp_sum(plr, dl_l, -1.0, **ru)                            # :447-449
+        pfrl = warp_softmax(logits[B:], dl_l, -1.0, flip_src=True, **ru)  # :451-453 (the flip is folded into the read)
+        o_fr = warp_sum(pfrl, dl_r, +1.0, **ru)                          # :454-456
         disp_pp = pp_combine(disp, o_fr, o_l)                            # :458-461
         prob = probability.tensor() if hasattr(probability, "tensor") else probability
-        mask_novel = warp_sum(prob[:B], dl_r, +1.0)                      # :463-465
+        mask_novel = warp_sum(prob[:B], dl_r, +1.0, **ru)                # :463-465
     return disp_pp, mask_novel
 
 

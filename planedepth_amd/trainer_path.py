@@ -258,8 +258,23 @@ def generate_post_process_disp(self, inputs):
         outputs = self.models["fal"](input_images)
     else:
         raise ValueError("unknown net_type %r" % (opt.net_type,))
-    disp_pp, mask_novel = ops.post_process_disp(outputs["logits"], outputs["probability"], outputs["disp"],
-                                                outputs["disp_layered"])
+    # xy and xz planes have disparities that are constant along x (depth_decoder.py:153-181); yz planes do not (:221-236): taken
+    # from the options and verified on the data once per trainer object, as pred_novel_images does (opt.pd_check_contract)
+    dl = outputs["disp_layered"]
+    row_uniform = getattr(opt, "yz_levels", None) == 0
+    check = getattr(opt, "pd_check_contract", None)
+    if os.environ.get("PD_CHECK_CONTRACT"):
+        check = True
+    if check is None:
+        check = not getattr(self, "_pd_pp_contract_checked", False)
+    if check and row_uniform and dl.dim() == 4 and dl.shape[-1] > 1 and not bool((dl == dl[..., :1]).all()):
+        raise ValueError("opt.yz_levels == 0 promises disparities that are constant along x, but disp_layered is not")
+    try:
+        self._pd_pp_contract_checked = True
+    except AttributeError:
+        pass
+    disp_pp, mask_novel = ops.post_process_disp(outputs["logits"], outputs["probability"], outputs["disp"], dl,
+                                                row_uniform=row_uniform)
     return disp_pp.detach(), mask_novel.detach()
 
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--xz", type=int, default=0, help="the last K planes get a disparity that grows with the row (ground planes): a [B,N,H,1] map expanded along x")
     a = ap.parse_args()
     B, N, H, W = a.batch, a.planes, a.height, a.width
     dev = torch.device("cuda:0")
@@ -25,6 +26,11 @@ def main():
     prob = torch.softmax(torch.randn(2 * B, N, H, W, generator=g), 1).to(dev)
     lv = torch.arange(N, dtype=torch.float32)[None, :, None, None] + torch.rand(2 * B, N, 1, 1, generator=g) - 0.5
     dl = (300.0 * (2.0 / 300.0) ** (lv / (N - 1))).to(dev).expand(-1, -1, H, W)
+    if a.xz:
+        rows = dl[:, :, :, :1].clone()                                    # [2B,N,H,1]
+        gain = torch.linspace(0.2, 3.0, H, device=dev).view(1, 1, H, 1)
+        rows[:, N - a.xz:] = rows[:, N - a.xz:] * gain
+        dl = rows.expand(-1, -1, -1, W)
     disp = (prob * dl).sum(1, True)
 
     def timed(fn):

@@ -1185,8 +1185,8 @@ def test_smooth_loss_against_reference_vector_and_oracle():
     assert float(dx.grad[..., :x0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tag", ["xy", "rows"])
-def test_post_process_against_reference_vectors(tag):
+@pytest.mark.parametrize("tag,promise", [("xy", False), ("rows", False), ("rows", True)])
+def test_post_process_against_reference_vectors(tag, promise):
     """the fused post-process warps against Trainer.generate_post_process_disp's own output
     (tests/golden/post_process.npz), through the trainer-level entry point with a stub for the fixed networks."""
     import types
@@ -1199,7 +1199,9 @@ def test_post_process_against_reference_vectors(tag):
     if tag == "xy":  # hand it over the way the decoder does for xy planes: an expanded view of [2B,N,1,1]
         dl = dl[:, :, :1, :1].contiguous().expand(-1, -1, H, W)
     fixed = dict(logits=z["logits"], probability=z["probability"], disp=z["disp"], disp_layered=dl)
-    ns = types.SimpleNamespace(opt=types.SimpleNamespace(num_ep=1, net_type="ResNet"),
+    # promise: opt.yz_levels == 0 — the dense map of the xz-plane fixture is then read as one disparity per (plane, row) and served
+    # by the row kernels / row chains (PD_PP_DISP_ROWS) instead of the per-pixel gather form
+    ns = types.SimpleNamespace(opt=types.SimpleNamespace(num_ep=1, net_type="ResNet", **(dict(yz_levels=0) if promise else {})),
                                fixed_models={"encoder": lambda x: None, "depth": lambda f, g: fixed})
     inputs = {("color_aug", "l"): torch.zeros(B2 // 2, 3, H, W, device="cuda"),
               "grid": torch.zeros(B2 // 2, 2, H, W, device="cuda")}
@@ -1303,6 +1305,40 @@ def test_post_process_segment_kernels_vs_oracle_and_row_kernels(H, W, N, dmax):
     for key, (sm, su) in here.items():
         assert float((sm - rows[key][0]).abs().max()) < 2e-6, key
         assert float((su - rows[key][1]).abs().max()) < 2e-6, key
+
+
+@pytest.mark.parametrize("H,W,N,n_xz", [(12, 128, 20, 6), (9, 256, 49, 14), (7, 130, 63, 14), (6, 770, 24, 5), (5, 384, 70, 9)])
+def test_post_process_with_per_row_disparities(H, W, N, n_xz):
+    """PD_PP_DISP_ROWS: the last ``n_xz`` planes get a disparity that changes with the row (the decoder's ground planes: a dense
+    [2B,N,H,W] map that is constant along x).  Under the ``row_uniform`` promise the row kernels and, through pd_post_process, the
+    row chains serve it — a chain takes the plane sum of source row r once per TARGET row that blends r in (the shifts of the second
+    warp are the target row's): against the oracle at 1e-4, against the dense (per-pixel gather) form and against the single
+    warps within fp32 reassociation."""
+    from oracle import planedepth_oracle as orc
+    from planedepth_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(3000 + W + N)
+    logits = torch.randn(2 * B, N, H, W, generator=g) * 2
+    sigma = torch.rand(2 * B, N, H, W, generator=g) * 0.9 + 0.05
+    w = torch.softmax(logits, 1) / sigma
+    prob = w / w.sum(1, True)
+    base = torch.rand(2 * B, N, 1, 1, generator=g) * min(120.0, W * 0.6)
+    rows = base.expand(-1, -1, H, 1).clone()
+    rows[:, N - n_xz:] = rows[:, N - n_xz:] * torch.linspace(0.1, 2.5, H).view(1, 1, H, 1) * (0.5 + torch.rand(2 * B, n_xz, 1, 1, generator=g))
+    dl = rows.expand(-1, -1, -1, W).contiguous()                      # what the decoder's cat() hands over
+    disp = (prob * dl).sum(1, True)
+    want = orc.post_process_disp(logits, prob, disp, dl)
+    args = (logits.cuda(), prob.cuda(), disp.cuda(), dl.cuda())
+    got = ops.post_process_disp(*args, row_uniform=True)
+    dense = ops.post_process_disp(*args)                               # no promise: PD_PP_DISP_DENSE
+    step = ops.post_process_disp_stepwise(*args, row_uniform=True)
+    for a_, b_, c_, d_ in zip(got, want, dense, step):
+        assert rel_err(a_.cpu(), b_) < TOL
+        assert float((a_ - c_).abs().max()) <= 3e-6 * max(float(c_.abs().max()), 1.0)
+        assert float((a_ - d_).abs().max()) <= 3e-6 * max(float(d_.abs().max()), 1.0)
+    got_view = ops.post_process_disp(args[0], args[1], args[2], rows.cuda().expand(-1, -1, -1, W))   # an x-expanded view: no promise needed
+    for a_, b_ in zip(got, got_view):
+        assert torch.equal(a_, b_)
 
 
 def test_plane_disparities_vs_the_decoders_expression():
