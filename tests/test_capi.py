@@ -77,7 +77,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.pd_warp_sum(1, 4, 8, 8, 1.0, 0, None, None, 1.0, None, None) == 1
     assert lib.pd_pp_combine(1, 8, 8, None, None, None, None, None) == 1
     assert lib.pd_post_process(1, 4, 8, 8, 0, None, None, None, None, None, None, None, None) == 1
-    assert lib.pd_post_process_workspace_floats(2, 4, 8, 8) == 2 * 4 * 64 + 2 * 2 * 64
+    assert lib.pd_post_process_workspace_floats(2, 4, 8, 8) == 2 * 4 * 64 + 6 * 2 * 64   # [B,N,H,W] + the chains' 2 x 3 S maps
     assert lib.pd_plane_levels_fwd(4, 4, 2.0, 300.0, 1.0, None, None, None, None) == 1
     assert lib.pd_plane_levels_bwd(4, 4, 2.0, 300.0, 1.0, None, None, None, None, None) == 1
     assert lib.pd_cat_flip(0, 3, 8, 8, None, None, 0, None, None) == 1
