@@ -71,6 +71,12 @@ constexpr int kStreamAbl = PD_STREAM_ABL;
 #define PD_STREAM_DEAD 1  // (plane, segment) items none of whose slots has a target inside the row (shift beyond the segment: the near planes'
 #endif                    // leading segments) issue no memory reads (zero-extent descriptors), read no context, do no arithmetic and store
                           // the zeros they have to store: 11 of the 245 items of a headline row (round 6)
+#ifndef PD_STREAM_PRIO
+#define PD_STREAM_PRIO 1  // wave priority of a row workgroup's phases (s_setprio): 1 = the staging and the ring's first loads at 3, the item loop
+#endif                    // at 0 — a workgroup that has just arrived on the CU gets through its dependent round trips ahead of the two that are
+                          // streaming (-0.9 % alone, -2.2 % with the max-ilp scheduler, __graft_entry__.FILE_FLAGS); 2 = the first D+1 items at 3
+                          // as well (where -mllvm -amdgpu-set-wave-priority puts it: the same within the noise); 0 = none.  Measured and dropped
+                          // (NOTEBOOK 11.5): a rotating leader per SIMD as in the forward (+13 %), loads above arithmetic or below it (+1-4 %)
 #ifndef PD_STREAM_OCC
 #define PD_STREAM_OCC 4  // launch bound (1024 threads): the allocator's cap is 128 VGPRs; the kernel uses 76 = 6 waves per SIMD
 #endif
@@ -406,7 +412,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   const int lane = threadIdx.x & (kWave - 1);
   const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nseg = (W + kSeg - 1) / kSeg;
-  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);
+  const int want_plane = __builtin_amdgcn_readfirstlane(o.g_plane != nullptr ? 1 : 0);   // (as a template parameter: 83 VGPRs, 0.189 -> 0.200-0.205 ms)
   const int gl_bytes = __builtin_amdgcn_readfirstlane(o.g_logits ? W * 4 : 0);   // 0: the stores become no-ops
   const int gs_bytes = __builtin_amdgcn_readfirstlane(o.g_sigma ? W * 4 : 0);
   const float Wm1 = (float)(W - 1), rcpWm1 = refined_rcp(Wm1);
@@ -436,6 +442,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   };
 
   // ---- stage the row: per-target-pixel context, blended colour row, per-plane shifts -----------------------------
+  if (PD_STREAM_PRIO) __builtin_amdgcn_s_setprio(3);   // a workgroup that has just arrived gets through its dependent round trips ahead of the streaming ones
   int special;
   stream_stage_ctx<MIX, NROWS, PK, TAIL>(a, o, r, L, HW);
   if (threadIdx.x == 0) *L.special = 0;
@@ -504,6 +511,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
   if (i0 < i1) {
 #pragma unroll
     for (int j = 0; j < D; ++j) prefetch(g[j]);
+    if (PD_STREAM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     int it = i0;
     for (; it + (D + 1) <= i1; it += D + 1) {
 #pragma unroll
@@ -511,6 +519,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
         prefetch(g[(j + D) % (D + 1)]);
         step(g[j]);
       }
+      if (PD_STREAM_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     }
 #pragma unroll
     for (int j = 0; j <= D; ++j) {
@@ -555,6 +564,7 @@ __device__ __forceinline__ void stream_body(const SweepArgs& a, const BwdOut& o,
     }
     __syncthreads();
   }
+  if (PD_STREAM_PRIO) __builtin_amdgcn_s_setprio(0);
   if (want_plane) {
     const float gix_scale = (Wm1 / 2) * 2.0f / Wm1 * a.sign;  // d ix / d disp through un-normalise, *2, /(W-1)
     if (a.flags & PD_DISP_ROWS) {  // one disparity per (plane, row): this workgroup owns the whole sum
