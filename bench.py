@@ -87,6 +87,11 @@ def parse():
                          "or ResNet-50 + dense-ASPP-shaped (156.6 MB, configs[2])")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     ap.add_argument("--keep_gc", action="store_true", help="leave Python's cyclic garbage collector on during the timed windows (A/B)")
+    ap.add_argument("--autograd_threads", action="store_true",
+                    help="leave autograd's device thread on for the timed windows (A/B).  Default: torch.autograd.set_multithreading_enabled(False) "
+                         "around the launch probe and the timed windows — one process per GPU has no use for the hand-over of every "
+                         "backward to another thread, which costs the host 0.1 ms per step whenever the two threads sit on distant cores "
+                         "(scripts/diag_step_host.py: 97-116 us per step against 118-210)")
     ap.add_argument("--windows", type=int, default=7, help="further timed windows of --steps steps after the one `value` reports (spread)")
     return ap.parse_args()
 
@@ -896,6 +901,8 @@ def main():
     if not args.keep_gc:
         gc.collect()
         gc.freeze()
+    if not args.autograd_threads:
+        torch.autograd.set_multithreading_enabled(False)   # (back on after the timed windows)
     # ---- how the timed steps are issued ----
     # every rank must take the same path through the probe's collectives: a capture that failed anywhere means eager everywhere
     if args.launch in ("auto", "graph") and parallel.max_over_ranks(0.0 if graph_step is not None else 1.0, device) > 0.0:
@@ -952,6 +959,8 @@ def main():
     if not args.keep_gc:
         gc.enable()
         gc.unfreeze()
+    if not args.autograd_threads:
+        torch.autograd.set_multithreading_enabled(True)
     hbm_copy_after = measured_copy_rate(device) if "copy" not in args.skip_context else None
     result = {
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
@@ -960,6 +969,7 @@ def main():
         "launch": "HIP graph replay of one captured step" if used_graph else "eager (one host launch per kernel)",
         "launch_policy": args.launch, "launch_probe": launch_probe,
         "host_gc": "on" if args.keep_gc else "collected, frozen and disabled for the timed windows",
+        "host_autograd": "device thread (torch's default)" if args.autograd_threads else "calling thread (torch.autograd.set_multithreading_enabled(False)) for the launch probe and the timed windows",
         "pre_timed_steps": pre_timed,
         "windows": ({"n": len(window_rates), "steps_each": args.steps, "median": round(sorted(window_rates)[len(window_rates) // 2], 1),
                      "min": round(min(window_rates), 1), "max": round(max(window_rates), 1),

@@ -65,7 +65,7 @@ def _zero_scalar(device, slots=4096):
     a replay must start from zero every time."""
     if torch.cuda.is_current_stream_capturing():
         return torch.zeros(1, device=device, dtype=torch.float32)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # zeroed on the stream its slots are used on
+    key = (device.index, C.raw_stream(device))   # zeroed on the stream its slots are used on
     st = _ZERO_POOL.get(key)
     if st is None or st[1] >= slots:
         st = _ZERO_POOL[key] = [torch.zeros(slots, device=device, dtype=torch.float32), 0]
@@ -87,7 +87,7 @@ def _zero_block(device, shape):
         n *= int(k)
     if torch.cuda.is_current_stream_capturing() or not S.ZERO_POOL or n > _ZERO_BLOCK_FLOATS // 8:
         return torch.zeros(shape, device=device, dtype=torch.float32)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, C.raw_stream(device))
     st = _ZERO_BLOCKS.get(key)
     if st is None or st[1] + n > _ZERO_BLOCK_FLOATS:
         st = _ZERO_BLOCKS[key] = [torch.zeros(_ZERO_BLOCK_FLOATS, device=device, dtype=torch.float32), 0]
