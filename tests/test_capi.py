@@ -207,3 +207,19 @@ def test_timing_ablation_switches_refuse_to_compile_without_the_diagnostics_flag
     assert bad.returncode != 0 and "need -DPD_DIAGNOSTICS" in bad.stderr, bad.stderr[-500:]
     good = subprocess.run(cmd + ["-DPD_DIAGNOSTICS"], capture_output=True, text=True)
     assert good.returncode == 0, good.stderr[-500:]
+
+
+def test_per_source_compiler_flags_name_real_sources_and_enter_the_source_hash(monkeypatch):
+    """__graft_entry__.FILE_FLAGS (the instruction scheduler per source, NOTEBOOK 11.5): every key is a source that exists, the
+    flags are scheduler switches only (nothing that could change the arithmetic), and they are part of the hash that decides
+    whether the library on disk is rebuilt — a library built with other flags must not pass for the tree's."""
+    import __graft_entry__ as entry
+    for name, flags in entry.FILE_FLAGS.items():
+        assert os.path.isfile(os.path.join(entry.CSRC, name)), name
+        assert flags[0::2] == ["-mllvm"] * (len(flags) // 2) and all(f.startswith("-amdgpu-sched-strategy=") for f in flags[1::2]), flags
+    assert not any(f.startswith(("-ffast", "-ffp", "-O", "-funsafe")) for f in entry.BASE_FLAGS if f != "-O3")
+    before = entry.source_hash()
+    monkeypatch.setitem(entry.FILE_FLAGS, "pd_smooth.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])
+    assert entry.source_hash() != before
+    monkeypatch.undo()
+    assert entry.source_hash() == before
