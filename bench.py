@@ -454,10 +454,12 @@ def next_rows_times(args, device, iters=100):
         "reprojection_loss_ssim_l1": {"fwd_bwd_ms": round(t_r, 4), "fwd_bwd_device_ms": g_r, "shape": [B, 3, H, W]},
         "post_process": {"ms": round(t_p, 4), "GBs": round(post_bytes / (t_p * 1e-3) / 1e9, 1),
                          "shape": [2 * Bp, N, H, W]},
-        "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot (host-paced "
-                "where the Python / autograd overhead exceeds the kernels' time: fwd_bwd_ms of the two small operators and of "
-                "the PladeNet tail is the box's CPU speed (its per-plane disparities come from ops.plane_disparities: one launch each "
-                "way instead of the ten elementwise ones of round 5); fwd_bwd_device_ms is the same call replayed from a HIP graph, i.e. the device's share, and "
+        "note": "average over %d back-to-back calls of the public operators, one CUDA-event pair around the lot; fwd_bwd_device_ms is the same "
+                "call replayed from a HIP graph, i.e. the device's share (and what plade_tail_render's GB/s is computed from).  With autograd on "
+                "the calling thread (host_autograd; torch.autograd.set_multithreading_enabled(False)) the eager figures of the small operators sit "
+                "at their device times; under torch's device thread (--autograd_threads) they are host-paced at 0.09-0.15 ms (the hand-over of "
+                "every backward to another thread, NOTEBOOK 11.6).  PladeNet's per-plane disparities come from ops.plane_disparities (one launch "
+                "each way); "
                 "what plade_tail_render's GB/s is computed from)" % iters,
     }
 
@@ -902,7 +904,7 @@ def main():
         gc.collect()
         gc.freeze()
     if not args.autograd_threads:
-        torch.autograd.set_multithreading_enabled(False)   # (back on after the timed windows)
+        torch.autograd.set_multithreading_enabled(False)   # (back on ahead of the DDP step block)
     # ---- how the timed steps are issued ----
     # every rank must take the same path through the probe's collectives: a capture that failed anywhere means eager everywhere
     if args.launch in ("auto", "graph") and parallel.max_over_ranks(0.0 if graph_step is not None else 1.0, device) > 0.0:
@@ -959,8 +961,6 @@ def main():
     if not args.keep_gc:
         gc.enable()
         gc.unfreeze()
-    if not args.autograd_threads:
-        torch.autograd.set_multithreading_enabled(True)
     hbm_copy_after = measured_copy_rate(device) if "copy" not in args.skip_context else None
     result = {
         "metric": METRIC, "value": round(value, 2), "unit": "images/sec",
@@ -969,7 +969,7 @@ def main():
         "launch": "HIP graph replay of one captured step" if used_graph else "eager (one host launch per kernel)",
         "launch_policy": args.launch, "launch_probe": launch_probe,
         "host_gc": "on" if args.keep_gc else "collected, frozen and disabled for the timed windows",
-        "host_autograd": "device thread (torch's default)" if args.autograd_threads else "calling thread (torch.autograd.set_multithreading_enabled(False)) for the launch probe and the timed windows",
+        "host_autograd": "device thread (torch's default)" if args.autograd_threads else "calling thread (torch.autograd.set_multithreading_enabled(False)) for the launch probe, the timed windows and the operator legs after them (fast_rows_option, next_rows); torch's default for the ddp_step block",
         "pre_timed_steps": pre_timed,
         "windows": ({"n": len(window_rates), "steps_each": args.steps, "median": round(sorted(window_rates)[len(window_rates) // 2], 1),
                      "min": round(min(window_rates), 1), "max": round(max(window_rates), 1),
@@ -1080,6 +1080,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
+    if not args.autograd_threads:
+        torch.autograd.set_multithreading_enabled(True)   # the DDP step block runs under torch's default
     if not args.no_ddp_step and args.warp_type == "disp_warp" and not (args.xz_levels or args.yz_levels):
         # The headline line must not die with the secondary block — neither by an exception nor by a collective that never
         # returns (a rank that failed while the others wait in an all-reduce: RCCL's watchdog would abort the process before
