@@ -188,7 +188,10 @@ def raw_stream(device=None):
     per call — ~10 us, four times per training step here (two launches, two pool look-ups: 40 of the step's 214 us of host time);
     the raw getter is a plain C call."""
     if _RAW_STREAM is not None:
-        idx = getattr(device, "index", device)
+        if device is None or isinstance(device, int):
+            idx = device
+        else:
+            idx = (device if isinstance(device, torch.device) else torch.device(device)).index
         return _RAW_STREAM(torch.cuda.current_device() if idx is None else int(idx))
     return torch.cuda.current_stream(device).cuda_stream
 
