@@ -894,7 +894,7 @@ def main():
     pre_timed["steps_total"] = pre_timed["in_step_kernel_timing_steps"] + args.warmup + pre_timed["hip_graph_capture_steps"]
     if "copy" not in args.skip_context:
         hbm_copy = measured_copy_rate(device)
-    # Host hygiene for the 5 ms windows: an eager step costs the host 0.17-0.24 ms of the 0.27 ms the device needs, so a pause of
+    # Host hygiene for the 5 ms windows: an eager step costs the host 0.10-0.12 ms (0.20-0.25 in the bad mode of torch's device thread, NOTEBOOK 11.6) of the 0.26 ms the device needs, so a pause of
     # Python's cyclic collector (a generation-2 pass walks everything the set-up legs left behind) lands in a window twice: as
     # the pause itself, and as the ~50 slower steps after any idle gap long enough for the device to clock down (measured: a
     # collect() right in front of the warm-up steps cost the first window 10 %).  Collected and frozen HERE, with the launch
